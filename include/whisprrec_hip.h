@@ -1,0 +1,168 @@
+/*
+ * whisprrec_hip.h — C-ABI of libwhisprrec_hip.so: the MI355X (gfx950) implementation of WhisprRec's
+ * embedding-CF training hot path.
+ *
+ * The reference (HeyWeCome/WhisprRec) is pure Python and has no FFI; its "operator boundary" for this
+ * path is the chain of PyTorch calls cited per entry point below (paths relative to the reference
+ * root).  A maintainer binds this library with ctypes (INTEGRATION.md shows the stub); every symbol is
+ * plain C: raw device pointers, sizes, a hipStream_t passed as void*.
+ *
+ * Conventions
+ *   - return value: 0 = ok, <0 = argument error (WR_E_*), >0 = hipError_t of the failing HIP call.
+ *     wr_last_error() returns a thread-local, human-readable message for the last non-zero return.
+ *   - ownership: every table / index / output / workspace buffer is allocated and owned by the caller
+ *     (e.g. a PyTorch-ROCm tensor, passed as tensor.data_ptr()).  The library allocates nothing.
+ *   - asynchrony: every call only enqueues work on `stream` (hipStream_t; NULL = default stream) and
+ *     returns; no call synchronises the device.  Calls on one stream execute in order.
+ *   - tables are row-major fp32 [n_rows, D], rows contiguous (row stride = D floats), 16-byte aligned
+ *     base.  D must be a multiple of 4 and <= 1024.
+ *   - indices at the reference boundary are int64 (src/models/BaseModel.py:121); the sorted "plan"
+ *     arrays produced and consumed inside the library are int32.
+ *   - semantics are batch-synchronous: every gradient of a step is computed from the pre-step tables
+ *     (src/helpers/BaseRunner.py:197-199), duplicates inside a batch are summed, and results do not
+ *     depend on scheduling (no float atomics: bitwise reproducible run to run).
+ */
+#ifndef WHISPRREC_HIP_H
+#define WHISPRREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WR_ABI_VERSION 1
+
+#define WR_OK 0
+#define WR_E_NULL (-1)     /* required pointer is NULL            */
+#define WR_E_SHAPE (-2)    /* bad size / D / batch                */
+#define WR_E_WORKSPACE (-3)/* workspace too small                 */
+#define WR_E_ALIGN (-4)    /* pointer not 16-byte aligned         */
+#define WR_E_RANGE (-5)    /* value out of supported range        */
+
+int32_t wr_abi_version(void);
+const char *wr_last_error(void);
+/* number of CUs, wavefront size and gcnArchName of the current device (sanity: expects gfx950) */
+int32_t wr_device_info(int32_t *n_cu, int32_t *wave_size, char *arch, int32_t arch_len);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1-K3  BPRMF.predict forward  — src/models/general/BPRMF.py:69-80, src/utils/loss.py:37-39
+ *   pos[b] = <U[u_b], I[p_b]>, neg[b] = <U[u_b], I[n_b]>, loss = -mean(log(1e-10 + sigmoid(pos-neg)))
+ *   coef[b] = dloss/dpos[b]  (what loss.backward(), BaseRunner.py:198, feeds the three gathers)
+ * pos_score / neg_score / coef may be NULL.  loss: 1 float on device.
+ * workspace: >= wr_bpr_fwd_workspace_bytes(B) bytes.
+ * Also serves LightGCN.predict (LightGCN.py:156-163) and SASRec.predict (SASRec.py:105-111) on
+ * propagated / encoded rows: `user_tab` is then any [n_users, D] fp32 matrix.
+ * --------------------------------------------------------------------------------------------------- */
+int64_t wr_bpr_fwd_workspace_bytes(int64_t B);
+int32_t wr_bpr_fwd(const float *user_tab, int64_t n_users, const float *item_tab, int64_t n_items, int32_t D,
+                   const int64_t *u, const int64_t *p, const int64_t *n, int64_t B, float *pos_score, float *neg_score,
+                   float *coef, float *loss, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Batch plan — the on-device counterpart of DataLoader batching (BaseRunner.py:188-193) +
+ * collate_batch (BaseModel.py:96-127) for the fused step: for each consecutive batch of `batch_size`
+ * triplets (last one may be short, no drop_last — BaseRunner.py:201), triplets are stably sorted by
+ * user and the 2*B (item, source) occurrences are stably sorted by item, so that each table row of a
+ * step has exactly one owner.
+ *   tu,tp,tn [n]  : triplets of batch k at [k*batch_size, ...), sorted by user
+ *   torig    [n]  : original position (0..n) of each sorted triplet (may be NULL)
+ *   oc_item  [2n] : occurrences of batch k at [2*k*batch_size, ...), sorted by item row
+ *   oc_src   [2n] : (local sorted triplet index << 1) | (1 if the occurrence is the NEGATIVE item)
+ * Index inputs are int64 (reference layout) or int32.  Every index is range-checked on device against
+ * n_users / n_items; *err_flag (int32 on device, caller-zeroed) is set to 1 on violation.
+ * --------------------------------------------------------------------------------------------------- */
+int64_t wr_bprmf_plan_workspace_bytes(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items);
+int32_t wr_bprmf_plan_build_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                void *workspace, int64_t workspace_bytes, void *stream);
+int32_t wr_bprmf_plan_build_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1-K5 fused  One BaseRunner.fit iteration for BPRMF with torch.optim.SGD —
+ *   zero_grad -> predict -> backward -> step  (BaseRunner.py:196-199, optimizer per :120-124)
+ * Two kernels: (A) one 16-lane team per user row: gathers U[u], I[p], I[n], BPR loss + coefficient,
+ * user-row gradient reduced over the user's triplets, U[u] updated in place, c_b*U[u] stashed;
+ * (B) one team per item row: sums the stashed contributions of its occurrences, I[r] updated in place.
+ *   w <- w - lr * (g + l2*w)  for rows in the batch.  Rows NOT in the batch are not touched here: with
+ *   l2 != 0 call wr_sgd_decay_untouched afterwards (dense torch.optim.SGD weight_decay semantics).
+ * stamp_u / stamp_i (int32 [n_rows], may be NULL when l2 == 0): set to step_id for rows in the batch.
+ * loss_out: 1 float on device (may be NULL).  workspace >= wr_bprmf_step_workspace_bytes(B, D).
+ * --------------------------------------------------------------------------------------------------- */
+int64_t wr_bprmf_step_workspace_bytes(int64_t B, int32_t D);
+int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                          const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                          const int32_t *oc_src, int64_t B, float lr, float l2, int32_t *stamp_u, int32_t *stamp_i,
+                          int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Runs consecutive steps over batches [first_batch, first_batch + n_batches) of a plan built with
+ * `batch_size` over `n_triplets` triplets (the native inner loop of BaseRunner.fit, BaseRunner.py:194-200).
+ * loss_out[k] receives the loss of batch first_batch + k (may be NULL).  l2 must be 0 here. */
+int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                         const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                         const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                         int64_t n_batches, float lr, float *loss_out, void *workspace, int64_t workspace_bytes,
+                         void *stream);
+
+/* Same two kernels in gradient-emitting mode: instead of updating the tables, writes the reduced
+ * gradient rows (embedding_dense_backward of BaseRunner.py:198) to grad_u[r,:] / grad_i[r,:] for rows in
+ * the batch and sets stamp[r] = step_id.  Rows not in the batch are not written: a consumer treats
+ * stamp[r] != step_id as a zero gradient row (wr_adam_dense / wr_sgd_dense below). */
+int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item_tab, int64_t n_items, int32_t D,
+                       const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                       const int32_t *oc_src, int64_t B, float *grad_u, float *grad_i, int32_t *stamp_u,
+                       int32_t *stamp_i, int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K5  optimizers over a whole table — torch.optim.{SGD,Adam}.step as built at BaseRunner.py:120-124.
+ * grad rows are valid where stamp[r] == step_id and are zero elsewhere (stamp == NULL: all rows valid).
+ * --------------------------------------------------------------------------------------------------- */
+/* w <- w - lr*l2*w for rows with stamp[r] != step_id (completes weight decay after wr_bprmf_step_sgd) */
+int32_t wr_sgd_decay_untouched(float *tab, int64_t n_rows, int32_t D, const int32_t *stamp, int32_t step_id, float lr,
+                               float l2, void *stream);
+/* g' = g + l2*w ; w <- w - lr*g' */
+int32_t wr_sgd_dense(float *tab, int64_t n_rows, int32_t D, const float *grad, const int32_t *stamp, int32_t step_id,
+                     float lr, float l2, void *stream);
+/* Adam (amsgrad off): g' = g + l2*w; m = lerp(m,g',1-b1); v = b2 v + (1-b2) g'^2;
+ * w <- w - lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);  t = adam_step (1-based) */
+int32_t wr_adam_dense(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_rows, int32_t D, const float *grad,
+                      const int32_t *stamp, int32_t step_id, int64_t adam_step, float lr, float l2, float beta1,
+                      float beta2, float eps, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K9  nn.Embedding forward / embedding_dense_backward with padding_idx —
+ *     src/models/sequential/SASRec.py:60,84,105-106; also the row-exchange primitive of the
+ *     row-sharded multi-GPU step.
+ * out[k,:] = tab[idx[k],:]                                        (gather; padding rows are read as stored)
+ * grad[idx[k],:] += src[k,:] for idx[k] != padding_idx            (deterministic: sorted segmented sum)
+ * --------------------------------------------------------------------------------------------------- */
+int32_t wr_gather_rows(const float *tab, int64_t n_rows, int32_t D, const int64_t *idx, int64_t n, float *out,
+                       void *stream);
+int64_t wr_scatter_add_workspace_bytes(int64_t n, int64_t n_rows);
+int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_t *idx, const float *src, int64_t n,
+                            int64_t padding_idx, float alpha, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K6-K7  LightGCN propagation — src/models/general/LightGCN.py:134-148
+ *   Y = A X for the CSR form of the normalised bipartite adjacency (the reference multiplies the dense
+ *   form of the same matrix, LightGCN.py:120,139).  If acc != NULL: acc += Y fused (running layer sum
+ *   for the mean over layers, LightGCN.py:142-143).  row_ptr int64 [n_rows+1], col int32, val fp32.
+ * --------------------------------------------------------------------------------------------------- */
+int32_t wr_spmm_csr(int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const float *val, const float *X,
+                    int32_t D, float *Y, float *acc, void *stream);
+/* out = alpha * x  /  y += alpha * x  over numel floats (layer-mean scaling, gradient accumulation) */
+int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream);
+/* EmbLoss pieces (src/utils/loss.py:94-98): sq[0..2] = sum of squares of the gathered U[u], I[p], I[n] blocks */
+int32_t wr_embloss_sumsq(const float *user_tab, const float *item_tab, int32_t D, const int64_t *u, const int64_t *p,
+                         const int64_t *n, int64_t B, float *sq3, void *workspace, int64_t workspace_bytes,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPRREC_HIP_H */

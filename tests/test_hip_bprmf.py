@@ -1,0 +1,293 @@
+"""GPU parity tests of the BPRMF hot path: HIP kernels (through the C-ABI) vs the golden vectors produced by the
+reference and vs the CPU oracle on seeded inputs.
+
+Bar (BASELINE.json north_star): indices bit-exact; fp32 embeddings / loss within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from whisprrec_amd import hip_ops
+    info = hip_ops.device_info()
+    assert info["wave_size"] == 64
+    return hip_ops
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------ forward
+def test_fwd_matches_reference_golden(ops, dev, g1):
+    out = ops.bpr_fwd(T(g1["U0"], dev), T(g1["I0"], dev), T(g1["u0"], dev), T(g1["p0"], dev), T(g1["n0"], dev), coef=True)
+    assert rel_err(out["pos_score"].cpu().numpy(), g1["pos_score"]) < TOL
+    assert rel_err(out["neg_score"].cpu().numpy(), g1["neg_score"]) < TOL
+    assert abs(float(out["loss"]) - float(g1["loss0"][0])) / float(g1["loss0"][0]) < TOL
+    _, _, coef, _ = oracle.bpr_fwd(g1["U0"], g1["I0"], g1["u0"], g1["p0"], g1["n0"])
+    assert rel_err(out["coef"].cpu().numpy(), coef) < TOL
+
+
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 100, 128, 200, 256, 512])
+def test_fwd_embedding_sizes(ops, dev, D):
+    rng = np.random.RandomState(D)
+    nU, nI, B = 301, 411, 1000
+    U = (rng.standard_normal((nU, D)) / np.sqrt(D) * 2).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) / np.sqrt(D) * 2).astype(np.float32)
+    u, p, n = rng.randint(0, nU, B), rng.randint(0, nI, B), rng.randint(0, nI, B)
+    out = ops.bpr_fwd(T(U, dev), T(I, dev), T(u, dev), T(p, dev), T(n, dev))
+    pos, neg, _, loss = oracle.bpr_fwd(U, I, u, p, n)
+    assert rel_err(out["pos_score"].cpu().numpy(), pos) < TOL
+    assert rel_err(out["neg_score"].cpu().numpy(), neg) < TOL
+    assert abs(float(out["loss"]) - loss) / loss < TOL
+
+
+def test_fwd_saturated_scores(ops, dev):
+    """sigmoid saturation on both sides: loss -> -log(1e-10) for x << 0 (loss.py:38), coef -> 0 for |x| large."""
+    D = 64
+    U = np.zeros((2, D), np.float32); I = np.zeros((3, D), np.float32)
+    U[0, 0] = 10.0; I[1, 0] = 10.0; I[2, 0] = -10.0
+    u = np.array([0, 0, 1]); p = np.array([1, 2, 1]); n = np.array([2, 1, 2])
+    out = ops.bpr_fwd(T(U, dev), T(I, dev), T(u, dev), T(p, dev), T(n, dev), coef=True)
+    _, _, coef, loss = oracle.bpr_fwd(U, I, u, p, n)
+    assert abs(float(out["loss"]) - loss) / loss < TOL
+    assert np.allclose(out["coef"].cpu().numpy(), coef, rtol=1e-5, atol=1e-12)
+    assert np.isfinite(float(out["loss"]))
+
+
+# ------------------------------------------------------------------------------------------------ plan
+def _check_plan(plan, u, p, n, B):
+    N = len(u)
+    tu, tp, tn = plan.tu.cpu().numpy(), plan.tp.cpu().numpy(), plan.tn.cpu().numpy()
+    torig = plan.torig.cpu().numpy()
+    oi, osrc = plan.oc_item.cpu().numpy(), plan.oc_src.cpu().numpy()
+    for k in range(plan.n_batches):
+        lo, hi = k * B, min(N, (k + 1) * B)
+        order = lo + np.argsort(u[lo:hi], kind="stable")         # stable sort by user inside the batch
+        assert np.array_equal(torig[lo:hi], order)                # bit-exact permutation
+        assert np.array_equal(tu[lo:hi], u[order]) and np.array_equal(tp[lo:hi], p[order]) and np.array_equal(tn[lo:hi], n[order])
+        Bk = hi - lo
+        items = np.concatenate([tp[lo:hi], tn[lo:hi]])
+        src = np.concatenate([np.arange(Bk) << 1, (np.arange(Bk) << 1) | 1])
+        o2 = np.argsort(items, kind="stable")
+        assert np.array_equal(oi[2 * lo:2 * lo + 2 * Bk], items[o2])
+        assert np.array_equal(osrc[2 * lo:2 * lo + 2 * Bk], src[o2])
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_plan_is_a_stable_sort(ops, dev, dtype):
+    rng = np.random.RandomState(7)
+    nU, nI, N, B = 50, 70, 1000, 128  # 8 batches, last one short (104)
+    u = rng.randint(0, nU, N).astype(dtype); p = rng.randint(0, nI, N).astype(dtype); n = rng.randint(0, nI, N).astype(dtype)
+    plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, keep_orig=True)
+    assert plan.n_batches == 8 and plan.batch_len(7) == 104
+    _check_plan(plan, u, p, n, B)
+
+
+def test_plan_wide_keys(ops, dev):
+    """composite (batch,row) keys beyond 32 bits take the 64-bit path"""
+    rng = np.random.RandomState(8)
+    nU, nI, N, B = (1 << 30) + 5, (1 << 29) + 3, 4096, 4   # 1024 batches x 31 bits
+    u = rng.randint(0, nU, N); p = rng.randint(0, nI, N); n = rng.randint(0, nI, N)
+    plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, keep_orig=True)
+    _check_plan(plan, u, p, n, B)
+
+
+def test_plan_rejects_out_of_range(ops, dev):
+    u = np.array([0, 1, 5]); p = np.array([0, 1, 2]); n = np.array([1, 1, 1])
+    with pytest.raises(IndexError):
+        ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), 4, 5, 3)
+    with pytest.raises(IndexError):
+        ops.BatchPlan(T(p, dev), T(u, dev), T(n, dev), 4, 5, 3)
+
+
+# ------------------------------------------------------------------------------------------------ step
+def test_sgd_trajectory_matches_reference_golden(ops, dev, g1):
+    lr, l2 = g1["sgd_hp"]
+    tabs = ops.BprmfTables(T(g1["U0"], dev), T(g1["I0"], dev))
+    for k in range(5):
+        plan = ops.BatchPlan(T(g1[f"u{k}"], dev), T(g1[f"p{k}"], dev), T(g1[f"n{k}"], dev), 512, 97, 131)
+        loss = tabs.step_sgd(plan, 0, float(lr), float(l2))
+        assert abs(float(loss) - g1["sgd_loss"][k]) / g1["sgd_loss"][k] < TOL
+        assert rel_err(tabs.U.cpu().numpy(), g1[f"sgd_U{k + 1}"]) < TOL
+        assert rel_err(tabs.I.cpu().numpy(), g1[f"sgd_I{k + 1}"]) < TOL
+
+
+def test_sgd_weight_decay_matches_reference_golden(ops, dev, g1):
+    lr, l2 = g1["sgdl2_hp"]
+    tabs = ops.BprmfTables(T(g1["U0"], dev), T(g1["I0"], dev))
+    for k in range(3):
+        plan = ops.BatchPlan(T(g1[f"u{k}"], dev), T(g1[f"p{k}"], dev), T(g1[f"n{k}"], dev), 512, 97, 131)
+        loss = tabs.step_sgd(plan, 0, float(lr), float(l2))
+        assert abs(float(loss) - g1["sgdl2_loss"][k]) / g1["sgdl2_loss"][k] < TOL
+        assert rel_err(tabs.U.cpu().numpy(), g1[f"sgdl2_U{k + 1}"]) < TOL
+        assert rel_err(tabs.I.cpu().numpy(), g1[f"sgdl2_I{k + 1}"]) < TOL
+
+
+def test_dense_grads_match_reference_golden(ops, dev, g1):
+    tabs = ops.BprmfTables(T(g1["U0"], dev), T(g1["I0"], dev))
+    plan = ops.BatchPlan(T(g1["u0"], dev), T(g1["p0"], dev), T(g1["n0"], dev), 512, 97, 131)
+    gU = torch.zeros_like(tabs.U); gI = torch.zeros_like(tabs.I)
+    loss, sid = tabs.grads(plan, 0, gU, gI)
+    assert abs(float(loss) - float(g1["loss0"][0])) / float(g1["loss0"][0]) < TOL
+    assert rel_err(gU.cpu().numpy(), g1["gU"]) < TOL
+    assert rel_err(gI.cpu().numpy(), g1["gI"]) < TOL
+    # stamps mark exactly the rows of the batch
+    su = tabs.stamp_u.cpu().numpy() == sid
+    assert np.array_equal(np.nonzero(su)[0], np.unique(g1["u0"]))
+    si = tabs.stamp_i.cpu().numpy() == sid
+    assert np.array_equal(np.nonzero(si)[0], np.unique(np.concatenate([g1["p0"], g1["n0"]])))
+    # tables untouched in gradient mode
+    assert np.array_equal(tabs.U.cpu().numpy(), g1["U0"]) and np.array_equal(tabs.I.cpu().numpy(), g1["I0"])
+
+
+@pytest.mark.parametrize("tag", ["adam", "adaml2"])
+def test_adam_trajectory_matches_reference_golden(ops, dev, g1, tag):
+    lr, l2 = g1[tag + "_hp"]
+    tabs = ops.BprmfTables(T(g1["U0"], dev), T(g1["I0"], dev))
+    gU = torch.zeros_like(tabs.U); gI = torch.zeros_like(tabs.I)
+    mU, vU, mI, vI = (torch.zeros_like(tabs.U), torch.zeros_like(tabs.U), torch.zeros_like(tabs.I), torch.zeros_like(tabs.I))
+    for k in range(3):
+        plan = ops.BatchPlan(T(g1[f"u{k}"], dev), T(g1[f"p{k}"], dev), T(g1[f"n{k}"], dev), 512, 97, 131)
+        loss, sid = tabs.grads(plan, 0, gU, gI)
+        ops.adam_dense(tabs.U, mU, vU, gU, k + 1, float(lr), float(l2), stamp=tabs.stamp_u, step_id=sid)
+        ops.adam_dense(tabs.I, mI, vI, gI, k + 1, float(lr), float(l2), stamp=tabs.stamp_i, step_id=sid)
+        assert abs(float(loss) - g1[tag + "_loss"][k]) / g1[tag + "_loss"][k] < TOL
+        assert rel_err(tabs.U.cpu().numpy(), g1[f"{tag}_U{k + 1}"]) < TOL
+        assert rel_err(tabs.I.cpu().numpy(), g1[f"{tag}_I{k + 1}"]) < TOL
+
+
+def test_ml100k_sgd_curve_matches_reference_golden(ops, dev, g2):
+    """BaseRunner.fit over ml-100k, 2 epochs x 33 batches (last batch 480 rows), via the native multi-step loop."""
+    lr, _ = g2["sgd_hp"]
+    nU, nI = int(g2["n_users"][0]), int(g2["n_items"][0])
+    tabs = ops.BprmfTables(T(g2["sgd_U0"], dev), T(g2["sgd_I0"], dev))
+    n_ep = len(g2["train_user"])
+    losses = []
+    for ep in range(2):
+        sl = slice(ep * n_ep, (ep + 1) * n_ep)
+        plan = ops.BatchPlan(T(g2["sgd_bu"][sl], dev), T(g2["sgd_bp"][sl], dev), T(g2["sgd_bn"][sl], dev), 2048, nU, nI)
+        assert plan.n_batches == 33 and plan.batch_len(32) == 480
+        losses.append(tabs.run_sgd(plan, 0, plan.n_batches, float(lr)).cpu().numpy())
+    losses = np.concatenate(losses)
+    assert rel_err(losses, g2["sgd_loss"]) < TOL
+    assert rel_err(tabs.U.cpu().numpy(), g2["sgd_Uend"]) < TOL
+    assert rel_err(tabs.I.cpu().numpy(), g2["sgd_Iend"]) < TOL
+    assert abs(float(np.mean(losses[:33])) - g2["sgd_epoch_mean"][0]) < 1e-6  # fit() return value (BaseRunner.py:201)
+
+
+def test_ml100k_adam_curve_matches_reference_golden(ops, dev, g2):
+    lr, l2 = g2["adam_hp"]
+    nU, nI = int(g2["n_users"][0]), int(g2["n_items"][0])
+    tabs = ops.BprmfTables(T(g2["adam_U0"], dev), T(g2["adam_I0"], dev))
+    plan = ops.BatchPlan(T(g2["adam_bu"], dev), T(g2["adam_bp"], dev), T(g2["adam_bn"], dev), 2048, nU, nI)
+    gU = torch.zeros_like(tabs.U); gI = torch.zeros_like(tabs.I)
+    mU, vU, mI, vI = (torch.zeros_like(tabs.U), torch.zeros_like(tabs.U), torch.zeros_like(tabs.I), torch.zeros_like(tabs.I))
+    losses = []
+    for k in range(plan.n_batches):
+        loss, sid = tabs.grads(plan, k, gU, gI)
+        ops.adam_dense(tabs.U, mU, vU, gU, k + 1, float(lr), float(l2), stamp=tabs.stamp_u, step_id=sid)
+        ops.adam_dense(tabs.I, mI, vI, gI, k + 1, float(lr), float(l2), stamp=tabs.stamp_i, step_id=sid)
+        losses.append(loss)
+    losses = torch.stack(losses).cpu().numpy()
+    assert rel_err(losses, g2["adam_loss"]) < TOL
+    assert rel_err(tabs.U.cpu().numpy(), g2["adam_Uend"]) < 1e-4  # same bar as the oracle test (v ~ 1e-12 under the sqrt)
+    assert rel_err(tabs.I.cpu().numpy(), g2["adam_Iend"]) < 1e-4
+
+
+@pytest.mark.parametrize("D", [8, 32, 64, 96, 128, 256])
+def test_step_vs_oracle_embedding_sizes(ops, dev, D):
+    rng = np.random.RandomState(100 + D)
+    nU, nI, B = 203, 157, 2048   # heavy duplication: every row appears ~10x
+    U = (rng.standard_normal((nU, D)) / np.sqrt(D) * 3).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) / np.sqrt(D) * 3).astype(np.float32)
+    tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+    Uo, Io = U.copy(), I.copy()
+    for k in range(3):
+        u, p, n = rng.randint(0, nU, B), rng.randint(0, nI, B), rng.randint(0, nI, B)
+        plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI)
+        loss = tabs.step_sgd(plan, 0, 0.2)
+        lo = oracle.bprmf_step_sgd(Uo, Io, u, p, n, 0.2, 0.0)
+        assert abs(float(loss) - lo) / lo < TOL
+    assert rel_err(tabs.U.cpu().numpy(), Uo) < TOL
+    assert rel_err(tabs.I.cpu().numpy(), Io) < TOL
+
+
+def test_single_hot_row_and_untouched_rows(ops, dev):
+    """One user and one item take every occurrence (longest possible runs); every other row must stay bit-identical
+    under SGD with l2 = 0 (the only exactly-sparse case)."""
+    rng = np.random.RandomState(5)
+    nU, nI, D, B = 64, 64, 64, 4096
+    U = rng.standard_normal((nU, D)).astype(np.float32) * 0.2
+    I = rng.standard_normal((nI, D)).astype(np.float32) * 0.2
+    u = np.full(B, 3); p = np.full(B, 9); n = rng.randint(10, 20, B)
+    tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+    plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI)
+    loss = tabs.step_sgd(plan, 0, 0.5)
+    Uo, Io = U.copy(), I.copy()
+    lo = oracle.bprmf_step_sgd(Uo, Io, u, p, n, 0.5, 0.0)
+    assert abs(float(loss) - lo) / lo < TOL
+    Ug, Ig = tabs.U.cpu().numpy(), tabs.I.cpu().numpy()
+    assert rel_err(Ug, Uo) < TOL and rel_err(Ig, Io) < TOL
+    keep_u = np.setdiff1d(np.arange(nU), [3]); keep_i = np.setdiff1d(np.arange(nI), np.concatenate([[9], np.arange(10, 20)]))
+    assert np.array_equal(Ug[keep_u], U[keep_u]) and np.array_equal(Ig[keep_i], I[keep_i])
+
+
+def test_step_is_bitwise_reproducible(ops, dev):
+    rng = np.random.RandomState(77)
+    nU, nI, D, B = 5000, 3000, 64, 16384
+    U = rng.standard_normal((nU, D)).astype(np.float32) * 0.1
+    I = rng.standard_normal((nI, D)).astype(np.float32) * 0.1
+    u, p, n = rng.randint(0, nU, B), rng.randint(0, nI, B), rng.randint(0, nI, B)
+    res = []
+    for _ in range(2):
+        tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+        plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI)
+        loss = tabs.step_sgd(plan, 0, 0.3)
+        res.append((tabs.U.cpu().numpy().copy(), tabs.I.cpu().numpy().copy(), float(loss)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
+def test_full_size_step_c2(ops, dev):
+    """BASELINE.json configs[1] shapes: 1M x 1M tables, D=64, B=65,536 uniform ids.  One step against the oracle's
+    sparse restatement, plus size-independent properties: untouched rows bit-identical, loss equals the forward-only
+    kernel's loss, second run bitwise identical."""
+    nU = nI = 1_000_000
+    D, B = 64, 65536
+    g = torch.Generator(device="cpu").manual_seed(3407)
+    U = torch.randn(nU, D, generator=g) * 0.05
+    I = torch.randn(nI, D, generator=g) * 0.05
+    rng = np.random.RandomState(3407)
+    u, p, n = rng.randint(0, nU, B), rng.randint(0, nI, B), rng.randint(1, nI, B)
+    Ud, Id = U.to(dev), I.to(dev)
+    fwd = ops.bpr_fwd(Ud, Id, T(u, dev), T(p, dev), T(n, dev), scores=False)
+    tabs = ops.BprmfTables(Ud.clone(), Id.clone())
+    plan = ops.BatchPlan(T(u.astype(np.int32), dev), T(p.astype(np.int32), dev), T(n.astype(np.int32), dev), B, nU, nI)
+    loss = tabs.step_sgd(plan, 0, 0.05)
+    assert abs(float(loss) - float(fwd["loss"])) / float(fwd["loss"]) < 1e-6
+    Uo, Io = U.numpy().copy(), I.numpy().copy()
+    bl = oracle.SparseSgdBaseline(Uo, Io, B)
+    lo = bl.step(u, p, n, 0.05)
+    assert abs(float(loss) - lo) / lo < TOL
+    Ug, Ig = tabs.U.cpu().numpy(), tabs.I.cpu().numpy()
+    assert rel_err(Ug, Uo) < TOL and rel_err(Ig, Io) < TOL
+    mask_u = np.ones(nU, bool); mask_u[u] = False
+    mask_i = np.ones(nI, bool); mask_i[p] = False; mask_i[n] = False
+    assert np.array_equal(Ug[mask_u], U.numpy()[mask_u]) and np.array_equal(Ig[mask_i], I.numpy()[mask_i])
+    tabs2 = ops.BprmfTables(Ud.clone(), Id.clone())
+    tabs2.step_sgd(plan, 0, 0.05)
+    assert torch.equal(tabs2.U, tabs.U) and torch.equal(tabs2.I, tabs.I)

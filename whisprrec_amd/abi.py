@@ -1,0 +1,85 @@
+"""ctypes binding of libwhisprrec_hip.so (the C-ABI declared in include/whisprrec_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwhisprrec_hip.so")
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/whisprrec_hip.h one to one (tests/test_abi.py checks the
+# header against this table).  Pointers are passed as integers (tensor.data_ptr()).
+SIGNATURES = {
+    "wr_abi_version": (c_i32, []),
+    "wr_last_error": (ctypes.c_char_p, []),
+    "wr_device_info": (c_i32, [c_vp, c_vp, c_vp, c_i32]),
+    "wr_bpr_fwd_workspace_bytes": (c_i64, [c_i64]),
+    "wr_bpr_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                           c_vp]),
+    "wr_bprmf_plan_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    "wr_bprmf_plan_build_i64": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_plan_build_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_step_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "wr_bprmf_step_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32,
+                                  c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_run_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
+                                 c_i64, c_f32, c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_grads": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
+                               c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "wr_sgd_decay_untouched": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_f32, c_f32, c_vp]),
+    "wr_sgd_dense": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_f32, c_f32, c_vp]),
+    "wr_adam_dense": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32,
+                              c_f32, c_vp]),
+    "wr_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    "wr_scatter_add_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "wr_scatter_add_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_i64, c_vp]),
+    "wr_spmm_csr": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "wr_axpy": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_i32, c_vp]),
+    "wr_embloss_sumsq": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+}
+
+_lib = None
+
+
+class WhisprRecHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WhisprRecHipError(
+                "libwhisprrec_hip.so is missing at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C whisprrec_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.wr_abi_version() != 1:
+            raise WhisprRecHipError("ABI version mismatch: library %d, binding 1" % handle.wr_abi_version())
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    return lib().wr_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    """0 ok; <0 argument error; >0 hipError_t — both raise with the library's message."""
+    if rc != 0:
+        raise WhisprRecHipError("%s failed (rc=%d): %s" % (what, rc, last_error()))
+
+
+def check_size(nbytes, what):
+    if nbytes < 0:
+        raise WhisprRecHipError("%s failed (rc=%d): %s" % (what, nbytes, last_error()))
+    return int(nbytes)

@@ -1,0 +1,367 @@
+// wr_bpr.hip — BPRMF forward and the fused batch-synchronous SGD step for gfx950 (MI355X).
+//
+// Reference path restated (paths relative to the reference root):
+//   BPRMF.predict            src/models/general/BPRMF.py:69-80     3 row gathers, 2 row dots
+//   BPRLoss.forward          src/utils/loss.py:37-39               -mean(log(1e-10 + sigmoid(pos-neg)))
+//   loss.backward()          src/helpers/BaseRunner.py:198         3 scatter-adds of c_b-scaled rows
+//   torch.optim.SGD.step()   src/helpers/BaseRunner.py:199         w -= lr (g + l2 w)
+//
+// Data layout in HBM: tables row-major fp32 [n_rows, D]; a team of T lanes holds one row as float4 per
+// lane (D=64: 16 lanes x 16 B = one 256-B row; a wave-instruction moves four rows = 1 KiB).
+//
+// Step = two kernels over a sorted batch plan (wr_plan.hip):
+//   user phase: position t of the user-sorted triplets; the first position of a run of equal users
+//     ("head") owns U[u]: it reads U[u] once, loops over the run reading I[p], I[n], reduces the two dots
+//     with DPP adds inside the 16-lane row, forms the loss term and coefficient c, accumulates
+//     g_u += c (I[p]-I[n]), stashes z_t = c U[u] (what the item side needs of the OLD user row), and
+//     finally rewrites U[u] in place.  Nobody else reads U[u] in this step, so in-place is
+//     batch-synchronous.
+//   item phase: position q of the item-sorted occurrences; the head of a run owns I[r]: it sums +-z of
+//     its occurrences and rewrites I[r] in place (all reads of I by the user phase are complete at the
+//     kernel boundary).  Block 0 also folds the user phase's per-block loss partials into the loss.
+// No float atomics anywhere: each row has one writer and a fixed summation order.
+#include "wr_common.h"
+
+namespace wr {
+
+// ----------------------------------------------------------------------------------------------- forward only
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
+                                                          const int64_t *__restrict__ u, const int64_t *__restrict__ p,
+                                                          const int64_t *__restrict__ n, int B, float *__restrict__ pos_out,
+                                                          float *__restrict__ neg_out, float *__restrict__ coef_out,
+                                                          float *__restrict__ partials) {
+    __shared__ float scratch[kBlock / 64];
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int b = blockIdx.x * TEAMS + threadIdx.x / T;
+    float term_acc = 0.f;
+    if (b < B) {
+        const Row<NV> ur = load_row<T, NV, FULL>(U, u[b], D, lane);
+        const Row<NV> pr = load_row<T, NV, FULL>(I, p[b], D, lane);
+        const Row<NV> nr = load_row<T, NV, FULL>(I, n[b], D, lane);
+        const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
+        const float sn = team_sum<T>(dot_partial<NV>(ur, nr));
+        float term, coef;
+        bpr_terms(sp, sn, (float)B, term, coef);
+        if (lane == 0) {
+            term_acc = term;
+            if (pos_out) pos_out[b] = sp;
+            if (neg_out) neg_out[b] = sn;
+            if (coef_out) coef_out[b] = coef;
+        }
+    }
+    const float s = block_sum(term_acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// Sums `n` partials in a fixed order and writes out[0] = sum / denom.  One block.
+__global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__restrict__ partials, int n, float denom,
+                                                              float *__restrict__ out) {
+    __shared__ float scratch[kBlock / 64];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += kBlock) a += partials[i];
+    const float s = block_sum(a, scratch);
+    if (threadIdx.x == 0) out[0] = s / denom;
+}
+
+// ----------------------------------------------------------------------------------------------- user phase
+// MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.
+template <int T, int NV, bool FULL, int MODE>
+__global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U, const float *__restrict__ I, int D,
+                                                            const int *__restrict__ tu, const int *__restrict__ tp,
+                                                            const int *__restrict__ tn, int B, float lr, float l2,
+                                                            float *__restrict__ Z, float *__restrict__ partials,
+                                                            float *__restrict__ gradU, int *__restrict__ stampU,
+                                                            int step_id) {
+    __shared__ float scratch[kBlock / 64];
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int t0 = blockIdx.x * TEAMS + threadIdx.x / T;
+    float term_acc = 0.f;
+    if (t0 < B) {
+        const int u = tu[t0];
+        const bool head = (t0 == 0) || (tu[t0 - 1] != u);
+        if (head) {
+            const Row<NV> ur = load_row<T, NV, FULL>(U, u, D, lane);
+            Row<NV> g;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int t = t0;
+            int p = tp[t], n = tn[t];
+            bool more;
+            do {
+                const Row<NV> pr = load_row<T, NV, FULL>(I, p, D, lane);
+                const Row<NV> nr = load_row<T, NV, FULL>(I, n, D, lane);
+                const int tnext = t + 1;
+                more = (tnext < B) && (tu[tnext] == u);
+                if (more) {  // indices of the next triplet of this user, issued before the dot/transcendentals
+                    p = tp[tnext];
+                    n = tn[tnext];
+                }
+                const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
+                const float sn = team_sum<T>(dot_partial<NV>(ur, nr));
+                float term, c;
+                bpr_terms(sp, sn, (float)B, term, c);
+                term_acc += term;
+                Row<NV> z;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    g.v[k].x = fmaf(c, pr.v[k].x - nr.v[k].x, g.v[k].x);
+                    g.v[k].y = fmaf(c, pr.v[k].y - nr.v[k].y, g.v[k].y);
+                    g.v[k].z = fmaf(c, pr.v[k].z - nr.v[k].z, g.v[k].z);
+                    g.v[k].w = fmaf(c, pr.v[k].w - nr.v[k].w, g.v[k].w);
+                    z.v[k] = make_float4(c * ur.v[k].x, c * ur.v[k].y, c * ur.v[k].z, c * ur.v[k].w);
+                }
+                store_row<T, NV, FULL>(Z, t, D, lane, z);
+                t = tnext;
+            } while (more);
+            if (MODE == 0) {
+                Row<NV> w;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {  // torch.optim.SGD: g' = g + l2 w ; w -= lr g'
+                    w.v[k].x = ur.v[k].x - lr * fmaf(l2, ur.v[k].x, g.v[k].x);
+                    w.v[k].y = ur.v[k].y - lr * fmaf(l2, ur.v[k].y, g.v[k].y);
+                    w.v[k].z = ur.v[k].z - lr * fmaf(l2, ur.v[k].z, g.v[k].z);
+                    w.v[k].w = ur.v[k].w - lr * fmaf(l2, ur.v[k].w, g.v[k].w);
+                }
+                store_row<T, NV, FULL>(U, u, D, lane, w);
+            } else {
+                store_row<T, NV, FULL>(gradU, u, D, lane, g);
+            }
+            if (stampU != nullptr && lane == 0) stampU[u] = step_id;
+            if (lane != 0) term_acc = 0.f;  // every lane of the team holds the same terms: count them once
+        }
+    }
+    const float s = block_sum(term_acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// ----------------------------------------------------------------------------------------------- item phase
+template <int T, int NV, bool FULL, int MODE>
+__global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I, int D, const int *__restrict__ oc_item,
+                                                            const int *__restrict__ oc_src, int B2,
+                                                            const float *__restrict__ Z, float lr, float l2,
+                                                            float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
+                                                            const float *__restrict__ partials, int n_partials,
+                                                            float loss_denom, float *__restrict__ loss_out) {
+    __shared__ float scratch[kBlock / 64];
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int q0 = blockIdx.x * TEAMS + threadIdx.x / T;
+    if (q0 < B2) {
+        const int r = oc_item[q0];
+        const bool head = (q0 == 0) || (oc_item[q0 - 1] != r);
+        if (head) {
+            const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
+            Row<NV> g;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int q = q0;
+            int src = oc_src[q];
+            bool more;
+            do {
+                const Row<NV> z = load_row<T, NV, FULL>(Z, src >> 1, D, lane);
+                const float sgn = (src & 1) ? -1.0f : 1.0f;  // d/dI[p] = +c U[u], d/dI[n] = -c U[u]
+                const int qnext = q + 1;
+                more = (qnext < B2) && (oc_item[qnext] == r);
+                if (more) src = oc_src[qnext];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    g.v[k].x = fmaf(sgn, z.v[k].x, g.v[k].x);
+                    g.v[k].y = fmaf(sgn, z.v[k].y, g.v[k].y);
+                    g.v[k].z = fmaf(sgn, z.v[k].z, g.v[k].z);
+                    g.v[k].w = fmaf(sgn, z.v[k].w, g.v[k].w);
+                }
+                q = qnext;
+            } while (more);
+            if (MODE == 0) {
+                Row<NV> w;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    w.v[k].x = ir.v[k].x - lr * fmaf(l2, ir.v[k].x, g.v[k].x);
+                    w.v[k].y = ir.v[k].y - lr * fmaf(l2, ir.v[k].y, g.v[k].y);
+                    w.v[k].z = ir.v[k].z - lr * fmaf(l2, ir.v[k].z, g.v[k].z);
+                    w.v[k].w = ir.v[k].w - lr * fmaf(l2, ir.v[k].w, g.v[k].w);
+                }
+                store_row<T, NV, FULL>(I, r, D, lane, w);
+            } else {
+                store_row<T, NV, FULL>(gradI, r, D, lane, g);
+            }
+            if (stampI != nullptr && lane == 0) stampI[r] = step_id;
+        }
+    }
+    if (blockIdx.x == 0 && loss_out != nullptr) {  // uniform per block: fold the user phase's partials
+        float a = 0.f;
+        for (int i = threadIdx.x; i < n_partials; i += kBlock) a += partials[i];
+        const float s = block_sum(a, scratch);
+        if (threadIdx.x == 0) loss_out[0] = s / loss_denom;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- host side
+static inline int teams_per_block(int D) {
+    if (D >= 64) return kBlock / 16;
+    if (D == 32) return kBlock / 8;
+    if (D == 16) return kBlock / 4;
+    if (D == 8) return kBlock / 2;
+    if (D == 4) return kBlock / 1;
+    return kBlock / 16;
+}
+static inline int64_t n_blocks_for(int64_t n_teams, int D) {
+    const int tpb = teams_per_block(D);
+    return (n_teams + tpb - 1) / tpb;
+}
+
+struct StepWs {
+    float *Z;
+    float *partials;
+    int64_t n_partials;
+};
+
+static inline int64_t step_ws_bytes(int64_t B, int32_t D) {
+    // Z stash [B, D] + loss partials (one per user-phase block; bounded by B for the smallest team count)
+    return align_up(B * (int64_t)D * 4, 256) + align_up(n_blocks_for(B, D) * 4, 256);
+}
+
+static inline StepWs carve_step_ws(void *workspace, int64_t B, int32_t D) {
+    StepWs w;
+    w.Z = reinterpret_cast<float *>(workspace);
+    w.partials = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + align_up(B * (int64_t)D * 4, 256));
+    w.n_partials = n_blocks_for(B, D);
+    return w;
+}
+
+template <int MODE>
+static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
+                           const int32_t *oc_item, const int32_t *oc_src, int64_t B, float lr, float l2, float *gradU,
+                           float *gradI, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id, float *loss_out,
+                           void *workspace, hipStream_t stream) {
+    const StepWs w = carve_step_ws(workspace, B, D);
+    const dim3 block(kBlock);
+    const dim3 gridA((unsigned)n_blocks_for(B, D));
+    const dim3 gridB((unsigned)n_blocks_for(2 * B, D));
+#define WR_CALL_USER(T_, NV_, FULL_)                                                                                  \
+    hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE>), gridA, block, 0, stream, U, I, D, tu, tp, tn, (int)B, \
+                       lr, l2, w.Z, w.partials, gradU, stamp_u, step_id)
+    WR_DISPATCH_D(D, WR_CALL_USER);
+#undef WR_CALL_USER
+    WR_LAUNCH_CHECK("bprmf_user_phase");
+#define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
+    hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
+                       (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)w.n_partials, (float)B, \
+                       loss_out)
+    WR_DISPATCH_D(D, WR_CALL_ITEM);
+#undef WR_CALL_ITEM
+    WR_LAUNCH_CHECK("bprmf_item_phase");
+    return WR_OK;
+}
+
+static int32_t check_plan_args(const void *tu, const void *tp, const void *tn, const void *oc_item, const void *oc_src,
+                               int64_t B) {
+    WR_REQUIRE(tu && tp && tn && oc_item && oc_src, WR_E_NULL, "plan arrays must not be NULL");
+    WR_REQUIRE(B > 0 && B <= (int64_t(1) << 29), WR_E_SHAPE, "batch size %lld out of range (1..2^29)", (long long)B);
+    return WR_OK;
+}
+
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" {
+
+int64_t wr_bpr_fwd_workspace_bytes(int64_t B) { return align_up(((B + 15) / 16 + 1) * 4, 256); }
+
+int32_t wr_bpr_fwd(const float *user_tab, int64_t n_users, const float *item_tab, int64_t n_items, int32_t D,
+                   const int64_t *u, const int64_t *p, const int64_t *n, int64_t B, float *pos_score, float *neg_score,
+                   float *coef, float *loss, void *workspace, int64_t workspace_bytes, void *stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    WR_REQUIRE(u && p && n, WR_E_NULL, "index arrays must not be NULL");
+    WR_REQUIRE(B > 0 && B <= (int64_t(1) << 29), WR_E_SHAPE, "B=%lld out of range", (long long)B);
+    WR_REQUIRE(loss != nullptr || pos_score || neg_score || coef, WR_E_NULL, "no output requested");
+    const int64_t nblk = n_blocks_for(B, D);
+    WR_REQUIRE(workspace != nullptr && workspace_bytes >= nblk * 4, WR_E_WORKSPACE,
+               "wr_bpr_fwd: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)(nblk * 4));
+    float *partials = reinterpret_cast<float *>(workspace);
+#define WR_CALL_FWD(T_, NV_, FULL_)                                                                               \
+    hipLaunchKernelGGL((bpr_fwd_kernel<T_, NV_, FULL_>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, user_tab,  \
+                       item_tab, D, u, p, n, (int)B, pos_score, neg_score, coef, partials)
+    WR_DISPATCH_D(D, WR_CALL_FWD);
+#undef WR_CALL_FWD
+    WR_LAUNCH_CHECK("bpr_fwd_kernel");
+    if (loss != nullptr) {
+        hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partials, (int)nblk, (float)B, loss);
+        WR_LAUNCH_CHECK("finish_loss_kernel");
+    }
+    return WR_OK;
+}
+
+int64_t wr_bprmf_step_workspace_bytes(int64_t B, int32_t D) { return step_ws_bytes(B, D); }
+
+int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                          const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                          const int32_t *oc_src, int64_t B, float lr, float l2, int32_t *stamp_u, int32_t *stamp_i,
+                          int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, B)) != WR_OK) return rc;
+    WR_REQUIRE(l2 == 0.0f || (stamp_u && stamp_i), WR_E_NULL, "l2 != 0 needs stamp_u/stamp_i for the dense decay pass");
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
+               "wr_bprmf_step_sgd: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
+    return launch_step<0>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, B, lr, l2, nullptr, nullptr, stamp_u,
+                          stamp_i, step_id, loss_out, workspace, reinterpret_cast<hipStream_t>(stream_));
+}
+
+int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                         const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                         const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                         int64_t n_batches, float lr, float *loss_out, void *workspace, int64_t workspace_bytes,
+                         void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, batch_size)) != WR_OK) return rc;
+    WR_REQUIRE(n_triplets > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(batch_size, D), WR_E_WORKSPACE,
+               "wr_bprmf_run_sgd: workspace %lld B < %lld B", (long long)workspace_bytes,
+               (long long)step_ws_bytes(batch_size, D));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t b = first_batch + k;
+        const int64_t off = b * batch_size;
+        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
+        rc = launch_step<0>(user_tab, item_tab, D, tu + off, tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk,
+                            lr, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, loss_out ? loss_out + k : nullptr,
+                            workspace, stream);
+        if (rc != WR_OK) return rc;
+    }
+    return WR_OK;
+}
+
+int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item_tab, int64_t n_items, int32_t D,
+                       const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                       const int32_t *oc_src, int64_t B, float *grad_u, float *grad_i, int32_t *stamp_u,
+                       int32_t *stamp_i, int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes,
+                       void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_table(grad_u, n_users, D, "grad_u")) != WR_OK) return rc;
+    if ((rc = check_table(grad_i, n_items, D, "grad_i")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, B)) != WR_OK) return rc;
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
+               "wr_bprmf_grads: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
+    // MODE 1 never writes the tables; the const_cast only serves the shared kernel signature.
+    return launch_step<1>(const_cast<float *>(user_tab), const_cast<float *>(item_tab), D, tu, tp, tn, oc_item, oc_src, B,
+                          0.f, 0.f, grad_u, grad_i, stamp_u, stamp_i, step_id, loss_out, workspace,
+                          reinterpret_cast<hipStream_t>(stream_));
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+// wr_common.h — shared device helpers and host-side error plumbing for libwhisprrec_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "whisprrec_hip.h"
+
+namespace wr {
+
+// ------------------------------------------------------------------------------------------------ errors
+void set_error(const char *fmt, ...);
+int32_t fail_hip(hipError_t e, const char *what);
+
+#define WR_REQUIRE(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::wr::set_error(__VA_ARGS__);    \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+#define WR_HIP(call)                                              \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) return ::wr::fail_hip(e__, #call); \
+    } while (0)
+
+#define WR_LAUNCH_CHECK(name)                                          \
+    do {                                                               \
+        hipError_t e__ = hipGetLastError();                            \
+        if (e__ != hipSuccess) return ::wr::fail_hip(e__, "launch " name); \
+    } while (0)
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+constexpr float kGamma = 1e-10f;  // BPRLoss(gamma=1e-10), reference src/utils/loss.py:33
+constexpr int kBlock = 256;       // 4 waves per workgroup
+
+// ------------------------------------------------------------------------------------------------ teams
+// A "team" is T consecutive lanes (T in {1,2,4,8,16}) of one 16-lane DPP row that together hold one
+// embedding row: lane l of the team holds float4 chunks l, l+T, ... (NV chunks).  D = 4*T*NV when the row
+// is full; a row with D < 4*T*NV masks the tail chunks.  D=64 -> T=16, NV=1: one wave-instruction moves
+// four 256-B rows (1 KiB, 16 B per lane).
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    // row_mask/bank_mask = 0xF (all), bound_ctrl = true: lanes outside EXEC read as 0 (never happens inside a team)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the T lanes of a team; every lane of the team gets the total.  DPP only (no LDS traffic):
+// quad_perm [1,0,3,2] (0xB1), quad_perm [2,3,0,1] (0x4E), row_half_mirror (0x141), row_mirror (0x140).
+template <int T>
+__device__ __forceinline__ float team_sum(float v) {
+    if constexpr (T >= 2) v += dpp_f<0xB1>(v);
+    if constexpr (T >= 4) v += dpp_f<0x4E>(v);
+    if constexpr (T >= 8) v += dpp_f<0x141>(v);
+    if constexpr (T >= 16) v += dpp_f<0x140>(v);
+    return v;
+}
+
+// Sum over the 64 lanes of a wave (result valid in every lane): team_sum<16> then two cross-row steps.
+__device__ __forceinline__ float wave_sum(float v) {
+    v = team_sum<16>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Deterministic block sum for kBlock threads; result valid in thread 0.  `scratch` >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float *scratch) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) r += scratch[w];
+    }
+    return r;
+}
+
+template <int NV>
+struct Row {
+    float4 v[NV];
+};
+
+// chunk index of this lane's k-th float4, and whether it is inside the row
+template <int T>
+__device__ __forceinline__ int chunk_of(int lane, int k) { return lane + k * T; }
+
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ Row<NV> load_row(const float *__restrict__ base, int64_t row, int D, int lane) {
+    Row<NV> r;
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * (int64_t)D);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = chunk_of<T>(lane, k);
+        if (FULL || c * 4 < D) r.v[k] = p[c];
+        else r.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return r;
+}
+
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ void store_row(float *__restrict__ base, int64_t row, int D, int lane, const Row<NV> &r) {
+    float4 *p = reinterpret_cast<float4 *>(base + row * (int64_t)D);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = chunk_of<T>(lane, k);
+        if (FULL || c * 4 < D) p[c] = r.v[k];
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ float dot_partial(const Row<NV> &a, const Row<NV> &b) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        s = fmaf(a.v[k].x, b.v[k].x, s);
+        s = fmaf(a.v[k].y, b.v[k].y, s);
+        s = fmaf(a.v[k].z, b.v[k].z, s);
+        s = fmaf(a.v[k].w, b.v[k].w, s);
+    }
+    return s;
+}
+
+// BPR per-triplet loss term and coefficient from the two scores (reference src/utils/loss.py:38 and its
+// autograd): term = -log(gamma + s), coef = -(s(1-s)/(gamma+s)) / B, s = sigmoid(pos-neg).
+__device__ __forceinline__ void bpr_terms(float pos, float neg, float batch_f, float &term, float &coef) {
+    const float x = pos - neg;
+    const float s = 1.0f / (1.0f + expf(-x));
+    term = -logf(kGamma + s);
+    coef = -(s * (1.0f - s) / (kGamma + s)) / batch_f;
+}
+
+// Shape dispatch: picks <T, NV, FULL> for an embedding size D (multiple of 4, <= 1024).
+//   D = 4,8,16,32 -> T = D/4, NV = 1;  D >= 64 -> T = 16, NV = ceil(D/64);  FULL iff D == 4*T*NV.
+#define WR_DISPATCH_D(D, CALL)                                                      \
+    do {                                                                            \
+        if ((D) == 64) { CALL(16, 1, true); }                                       \
+        else if ((D) == 128) { CALL(16, 2, true); }                                 \
+        else if ((D) == 32) { CALL(8, 1, true); }                                   \
+        else if ((D) == 256) { CALL(16, 4, true); }                                 \
+        else if ((D) == 16) { CALL(4, 1, true); }                                   \
+        else if ((D) == 8) { CALL(2, 1, true); }                                    \
+        else if ((D) == 4) { CALL(1, 1, true); }                                    \
+        else if ((D) < 64) { CALL(16, 1, false); }                                  \
+        else if ((D) <= 128) { CALL(16, 2, false); }                                \
+        else if ((D) <= 256) { CALL(16, 4, false); }                                \
+        else if ((D) <= 512) { CALL(16, 8, false); }                                \
+        else { CALL(16, 16, false); }                                               \
+    } while (0)
+
+static inline int32_t check_table(const void *tab, int64_t n_rows, int32_t D, const char *name) {
+    WR_REQUIRE(tab != nullptr, WR_E_NULL, "%s is NULL", name);
+    WR_REQUIRE(n_rows > 0 && n_rows < (int64_t(1) << 31), WR_E_SHAPE, "%s: n_rows=%lld out of range", name, (long long)n_rows);
+    WR_REQUIRE(D >= 4 && D <= 1024 && D % 4 == 0, WR_E_SHAPE, "%s: D=%d must be a multiple of 4 in [4,1024]", name, D);
+    WR_REQUIRE(aligned16(tab), WR_E_ALIGN, "%s is not 16-byte aligned", name);
+    return WR_OK;
+}
+
+}  // namespace wr

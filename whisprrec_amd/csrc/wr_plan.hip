@@ -1,0 +1,205 @@
+// wr_plan.hip — on-device batch plans for the fused BPRMF step.
+//
+// Counterpart of the reference's host-side batching: DataLoader(shuffle=True) slicing the epoch into
+// consecutive batches of `batch_size` with a short last batch (src/helpers/BaseRunner.py:188-193,201) and
+// BaseModel.Dataset.collate_batch (src/models/BaseModel.py:96-127).  The reference hands each batch to
+// autograd, which resolves duplicate rows with dense scatter-adds; here every batch is sorted once so each
+// table row has a single owner in the step kernels (wr_bpr.hip):
+//   - triplets stably sorted by (batch, user)          -> tu, tp, tn, torig
+//   - the 2B (item, source) occurrences of a batch stably sorted by (batch, item) -> oc_item, oc_src
+// One device-wide LSD radix sort per table over composite keys (batch << row_bits | row), restricted to the
+// bits that are actually used.  The radix sort itself is rocPRIM's (ROCm system library, stable); key
+// construction, range checks and unpacking are the kernels below.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "wr_common.h"
+
+namespace wr {
+
+static inline unsigned bits_for(int64_t n_values) {  // bits needed to represent 0..n_values-1
+    unsigned b = 0;
+    while ((int64_t(1) << b) < n_values) ++b;
+    return b == 0 ? 1 : b;
+}
+
+template <typename Idx, typename Key>
+__global__ __launch_bounds__(kBlock) void plan_user_keys(const Idx *__restrict__ u, int64_t n, int64_t B, unsigned row_bits,
+                                                          int64_t n_users, Key *__restrict__ keys,
+                                                          uint32_t *__restrict__ vals, int *__restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int64_t uu = (int64_t)u[i];
+    if (uu < 0 || uu >= n_users) {
+        if (err) *err = 1;
+        uu = 0;
+    }
+    keys[i] = ((Key)(i / B) << row_bits) | (Key)uu;
+    vals[i] = (uint32_t)i;
+}
+
+template <typename Idx, typename Key>
+__global__ __launch_bounds__(kBlock) void plan_unpack_user(const Key *__restrict__ keys_sorted,
+                                                            const uint32_t *__restrict__ perm, const Idx *__restrict__ p,
+                                                            const Idx *__restrict__ nn, int64_t n, int64_t B,
+                                                            unsigned user_bits, unsigned item_bits, int64_t n_items,
+                                                            int *__restrict__ tu, int *__restrict__ tp, int *__restrict__ tn,
+                                                            int *__restrict__ torig, Key *__restrict__ ikeys,
+                                                            uint32_t *__restrict__ ivals, int *__restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / B;
+    const int64_t j = i - b * B;
+    const int64_t Bb = (b * B + B <= n) ? B : (n - b * B);
+    const uint32_t o = perm[i];
+    int64_t pi = (int64_t)p[o], ni = (int64_t)nn[o];
+    if (pi < 0 || pi >= n_items || ni < 0 || ni >= n_items) {
+        if (err) *err = 1;
+        pi = (pi < 0 || pi >= n_items) ? 0 : pi;
+        ni = (ni < 0 || ni >= n_items) ? 0 : ni;
+    }
+    tu[i] = (int)(keys_sorted[i] & (((Key)1 << user_bits) - 1));
+    tp[i] = (int)pi;
+    tn[i] = (int)ni;
+    if (torig) torig[i] = (int)o;
+    const int64_t base = 2 * b * B;
+    const Key hi = (Key)b << item_bits;
+    ikeys[base + j] = hi | (Key)pi;
+    ivals[base + j] = (uint32_t)(j << 1);
+    ikeys[base + Bb + j] = hi | (Key)ni;
+    ivals[base + Bb + j] = (uint32_t)((j << 1) | 1);
+}
+
+template <typename Key>
+__global__ __launch_bounds__(kBlock) void plan_unpack_item(const Key *__restrict__ keys_sorted, int64_t n2, unsigned item_bits,
+                                                            int *__restrict__ oc_item) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n2) return;
+    oc_item[i] = (int)(keys_sorted[i] & (((Key)1 << item_bits) - 1));
+}
+
+struct PlanLayout {
+    bool wide;          // 64-bit composite keys
+    unsigned user_bits, item_bits, batch_bits;
+    int64_t key_bytes;  // per key array (2n keys)
+    int64_t val_bytes;  // per value array (2n values)
+    size_t sort_temp;   // rocPRIM temporary storage
+    int64_t total;
+};
+
+template <typename Key>
+static hipError_t sort_temp_bytes(int64_t n2, unsigned end_bit, size_t &bytes) {
+    Key *k = nullptr;
+    uint32_t *v = nullptr;
+    bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n2, 0u, end_bit, (hipStream_t)0);
+}
+
+static int32_t plan_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, PlanLayout &L) {
+    WR_REQUIRE(n > 0 && n < (int64_t(1) << 31), WR_E_SHAPE, "n_triplets=%lld out of range (1..2^31)", (long long)n);
+    WR_REQUIRE(B > 0 && B <= (int64_t(1) << 29), WR_E_SHAPE, "batch_size=%lld out of range (1..2^29)", (long long)B);
+    WR_REQUIRE(n_users > 0 && n_users < (int64_t(1) << 31) && n_items > 0 && n_items < (int64_t(1) << 31), WR_E_SHAPE,
+               "table sizes out of range");
+    const int64_t nb = (n + B - 1) / B;
+    L.user_bits = bits_for(n_users);
+    L.item_bits = bits_for(n_items);
+    L.batch_bits = bits_for(nb);
+    const unsigned need = (L.user_bits > L.item_bits ? L.user_bits : L.item_bits) + L.batch_bits;
+    L.wide = need > 32;
+    const int64_t n2 = 2 * n;
+    L.key_bytes = align_up(n2 * (L.wide ? 8 : 4), 256);
+    L.val_bytes = align_up(n2 * 4, 256);
+    size_t t = 0;
+    hipError_t e = L.wide ? sort_temp_bytes<uint64_t>(n2, L.item_bits + L.batch_bits, t)
+                          : sort_temp_bytes<uint32_t>(n2, L.item_bits + L.batch_bits, t);
+    if (e != hipSuccess) return fail_hip(e, "rocprim::radix_sort_pairs (size query)");
+    size_t t2 = 0;
+    e = L.wide ? sort_temp_bytes<uint64_t>(n, L.user_bits + L.batch_bits, t2)
+               : sort_temp_bytes<uint32_t>(n, L.user_bits + L.batch_bits, t2);
+    if (e != hipSuccess) return fail_hip(e, "rocprim::radix_sort_pairs (size query)");
+    L.sort_temp = (size_t)align_up((int64_t)(t > t2 ? t : t2), 256);
+    L.total = 2 * L.key_bytes + 2 * L.val_bytes + (int64_t)L.sort_temp;
+    return WR_OK;
+}
+
+template <typename Idx, typename Key>
+static int32_t plan_build_impl(const Idx *u, const Idx *p, const Idx *nn, int64_t n, int64_t B, int64_t n_users,
+                               int64_t n_items, int32_t *tu, int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item,
+                               int32_t *oc_src, int32_t *err_flag, void *workspace, const PlanLayout &L,
+                               hipStream_t stream) {
+    char *ws = reinterpret_cast<char *>(workspace);
+    Key *keyA = reinterpret_cast<Key *>(ws);
+    Key *keyB = reinterpret_cast<Key *>(ws + L.key_bytes);
+    uint32_t *valA = reinterpret_cast<uint32_t *>(ws + 2 * L.key_bytes);
+    uint32_t *valB = reinterpret_cast<uint32_t *>(ws + 2 * L.key_bytes + L.val_bytes);
+    void *temp = ws + 2 * L.key_bytes + 2 * L.val_bytes;
+    size_t temp_bytes = L.sort_temp;
+    const int64_t n2 = 2 * n;
+    const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock), g2 = (unsigned)((n2 + kBlock - 1) / kBlock);
+
+    hipLaunchKernelGGL((plan_user_keys<Idx, Key>), dim3(g1), dim3(kBlock), 0, stream, u, n, B, L.user_bits, n_users, keyA,
+                       valA, err_flag);
+    WR_LAUNCH_CHECK("plan_user_keys");
+    WR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keyA, keyB, valA, valB, (size_t)n, 0u, L.user_bits + L.batch_bits,
+                                     stream));
+    // keyB/valB hold the user-sorted order; item keys/values go to keyA/valA (2n entries)
+    hipLaunchKernelGGL((plan_unpack_user<Idx, Key>), dim3(g1), dim3(kBlock), 0, stream, keyB, valB, p, nn, n, B, L.user_bits,
+                       L.item_bits, n_items, tu, tp, tn, torig, keyA, valA, err_flag);
+    WR_LAUNCH_CHECK("plan_unpack_user");
+    temp_bytes = L.sort_temp;
+    WR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keyA, keyB, valA, reinterpret_cast<uint32_t *>(oc_src), (size_t)n2,
+                                     0u, L.item_bits + L.batch_bits, stream));
+    hipLaunchKernelGGL((plan_unpack_item<Key>), dim3(g2), dim3(kBlock), 0, stream, keyB, n2, L.item_bits, oc_item);
+    WR_LAUNCH_CHECK("plan_unpack_item");
+    return WR_OK;
+}
+
+template <typename Idx>
+static int32_t plan_build(const Idx *u, const Idx *p, const Idx *nn, int64_t n, int64_t B, int64_t n_users,
+                          int64_t n_items, int32_t *tu, int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item,
+                          int32_t *oc_src, int32_t *err_flag, void *workspace, int64_t workspace_bytes, void *stream_) {
+    WR_REQUIRE(u && p && nn, WR_E_NULL, "index arrays must not be NULL");
+    WR_REQUIRE(tu && tp && tn && oc_item && oc_src, WR_E_NULL, "plan output arrays must not be NULL");
+    PlanLayout L;
+    int32_t rc = plan_layout(n, B, n_users, n_items, L);
+    if (rc != WR_OK) return rc;
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= L.total, WR_E_WORKSPACE,
+               "plan workspace %lld B < %lld B", (long long)workspace_bytes, (long long)L.total);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (L.wide)
+        return plan_build_impl<Idx, uint64_t>(u, p, nn, n, B, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src, err_flag,
+                                              workspace, L, stream);
+    return plan_build_impl<Idx, uint32_t>(u, p, nn, n, B, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src, err_flag,
+                                          workspace, L, stream);
+}
+
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" {
+
+int64_t wr_bprmf_plan_workspace_bytes(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items) {
+    PlanLayout L;
+    const int32_t rc = plan_layout(n_triplets, batch_size, n_users, n_items, L);
+    if (rc != WR_OK) return rc < 0 ? rc : -(int64_t)rc;
+    return L.total;
+}
+
+int32_t wr_bprmf_plan_build_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                void *workspace, int64_t workspace_bytes, void *stream) {
+    return plan_build<int64_t>(u, p, n, n_triplets, batch_size, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src,
+                               err_flag, workspace, workspace_bytes, stream);
+}
+
+int32_t wr_bprmf_plan_build_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                void *workspace, int64_t workspace_bytes, void *stream) {
+    return plan_build<int32_t>(u, p, n, n_triplets, batch_size, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src,
+                               err_flag, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,431 @@
+// wr_rows.hip — row gather / deterministic scatter-add, whole-table optimizers, CSR SpMM, small reductions.
+//
+// Reference call sites restated (paths relative to the reference root):
+//   nn.Embedding forward / embedding_dense_backward with padding_idx   src/models/sequential/SASRec.py:60,84,105-106
+//   torch.optim.SGD / Adam .step() over full tables                      src/helpers/BaseRunner.py:120-124,199
+//   torch.sparse.mm(norm_adj, E) + layer mean                            src/models/general/LightGCN.py:139,142-143
+//   EmbLoss (un-squared Frobenius norms)                                  src/utils/loss.py:94-98
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "wr_common.h"
+
+namespace wr {
+
+// ------------------------------------------------------------------------------------------------ gather
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float *__restrict__ tab, int D, int64_t n_rows,
+                                                              const int64_t *__restrict__ idx, int64_t n,
+                                                              float *__restrict__ out) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int64_t k = (int64_t)blockIdx.x * TEAMS + threadIdx.x / T;
+    if (k >= n) return;
+    int64_t r = idx[k];
+    if (r < 0 || r >= n_rows) r = 0;  // callers validate; never read out of bounds
+    const Row<NV> v = load_row<T, NV, FULL>(tab, r, D, lane);
+    store_row<T, NV, FULL>(out, k, D, lane, v);
+}
+
+// ------------------------------------------------------------------------------------------------ scatter-add
+__global__ __launch_bounds__(kBlock) void scatter_keys_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t n_rows,
+                                                               int64_t padding_idx, uint32_t *__restrict__ keys,
+                                                               uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int64_t r = idx[i];
+    // padding (and out-of-range) entries sort to the end under key n_rows and are skipped
+    keys[i] = (r == padding_idx || r < 0 || r >= n_rows) ? (uint32_t)n_rows : (uint32_t)r;
+    vals[i] = (uint32_t)i;
+}
+
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void scatter_add_sorted_kernel(float *__restrict__ grad, int D, uint32_t n_rows,
+                                                                     const uint32_t *__restrict__ keys,
+                                                                     const uint32_t *__restrict__ perm, int64_t n,
+                                                                     const float *__restrict__ src, float alpha) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int64_t q0 = (int64_t)blockIdx.x * TEAMS + threadIdx.x / T;
+    if (q0 >= n) return;
+    const uint32_t r = keys[q0];
+    if (r >= n_rows) return;
+    if (q0 != 0 && keys[q0 - 1] == r) return;  // not the head of its run
+    Row<NV> acc;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t q = q0;
+    do {
+        const Row<NV> s = load_row<T, NV, FULL>(src, perm[q], D, lane);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            acc.v[k].x += s.v[k].x; acc.v[k].y += s.v[k].y; acc.v[k].z += s.v[k].z; acc.v[k].w += s.v[k].w;
+        }
+        ++q;
+    } while (q < n && keys[q] == r);
+    Row<NV> g = load_row<T, NV, FULL>(grad, r, D, lane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        g.v[k].x = fmaf(alpha, acc.v[k].x, g.v[k].x); g.v[k].y = fmaf(alpha, acc.v[k].y, g.v[k].y);
+        g.v[k].z = fmaf(alpha, acc.v[k].z, g.v[k].z); g.v[k].w = fmaf(alpha, acc.v[k].w, g.v[k].w);
+    }
+    store_row<T, NV, FULL>(grad, r, D, lane, g);
+}
+
+struct ScatterLayout {
+    int64_t arr_bytes;
+    size_t temp;
+    unsigned end_bit;
+    int64_t total;
+};
+
+static int32_t scatter_layout(int64_t n, int64_t n_rows, ScatterLayout &L) {
+    WR_REQUIRE(n > 0 && n < (int64_t(1) << 31), WR_E_SHAPE, "scatter: n=%lld out of range", (long long)n);
+    WR_REQUIRE(n_rows > 0 && n_rows < (int64_t(1) << 31), WR_E_SHAPE, "scatter: n_rows out of range");
+    L.arr_bytes = align_up(n * 4, 256);
+    L.end_bit = 1;
+    while ((int64_t(1) << L.end_bit) < n_rows + 1) ++L.end_bit;
+    uint32_t *k = nullptr;
+    size_t t = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, t, k, k, k, k, (size_t)n, 0u, L.end_bit, (hipStream_t)0);
+    if (e != hipSuccess) return fail_hip(e, "rocprim::radix_sort_pairs (size query)");
+    L.temp = (size_t)align_up((int64_t)t, 256);
+    L.total = 4 * L.arr_bytes + (int64_t)L.temp;
+    return WR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ optimizers
+// One thread per float4; row = (4*i)/D selects the stamp.
+__global__ __launch_bounds__(kBlock) void sgd_decay_untouched_kernel(float4 *__restrict__ w, int64_t n4, int D4,
+                                                                      const int *__restrict__ stamp, int step_id, float lr,
+                                                                      float l2) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        if (stamp[i / D4] == step_id) continue;
+        float4 v = w[i];  // g' = 0 + l2*w ; w -= lr*g'
+        v.x = v.x - lr * (l2 * v.x); v.y = v.y - lr * (l2 * v.y); v.z = v.z - lr * (l2 * v.z); v.w = v.w - lr * (l2 * v.w);
+        w[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float4 *__restrict__ w, const float4 *__restrict__ g, int64_t n4,
+                                                            int D4, const int *__restrict__ stamp, int step_id, float lr,
+                                                            float l2) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const bool live = (stamp == nullptr) || (stamp[i / D4] == step_id);
+        if (!live && l2 == 0.f) continue;
+        float4 v = w[i];
+        float4 gg = live ? g[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l2 != 0.f) { gg.x = fmaf(l2, v.x, gg.x); gg.y = fmaf(l2, v.y, gg.y); gg.z = fmaf(l2, v.z, gg.z); gg.w = fmaf(l2, v.w, gg.w); }
+        v.x -= lr * gg.x; v.y -= lr * gg.y; v.z -= lr * gg.z; v.w -= lr * gg.w;
+        w[i] = v;
+    }
+}
+
+__device__ __forceinline__ void adam_elem(float &w, float &m, float &v, float g, float l2, float b1, float b2, float eps,
+                                          float step_size, float bc2_sqrt) {
+    if (l2 != 0.f) g = fmaf(l2, w, g);
+    m = m + (1.0f - b1) * (g - m);         // exp_avg.lerp_(grad, 1-beta1)
+    v = b2 * v + (1.0f - b2) * g * g;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    w = w - step_size * (m / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ __launch_bounds__(kBlock) void adam_dense_kernel(float4 *__restrict__ w, float4 *__restrict__ m,
+                                                             float4 *__restrict__ v, const float4 *__restrict__ g, int64_t n4,
+                                                             int D4, const int *__restrict__ stamp, int step_id, float l2,
+                                                             float b1, float b2, float eps, float step_size,
+                                                             float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const bool live = (stamp == nullptr) || (stamp[i / D4] == step_id);
+        float4 ww = w[i], mm = m[i], vv = v[i];
+        const float4 gg = live ? g[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        adam_elem(ww.x, mm.x, vv.x, gg.x, l2, b1, b2, eps, step_size, bc2_sqrt);
+        adam_elem(ww.y, mm.y, vv.y, gg.y, l2, b1, b2, eps, step_size, bc2_sqrt);
+        adam_elem(ww.z, mm.z, vv.z, gg.z, l2, b1, b2, eps, step_size, bc2_sqrt);
+        adam_elem(ww.w, mm.w, vv.w, gg.w, l2, b1, b2, eps, step_size, bc2_sqrt);
+        w[i] = ww; m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void axpy_kernel(float4 *__restrict__ y, const float4 *__restrict__ x, int64_t n4,
+                                                       float alpha, int overwrite, float *__restrict__ ytail,
+                                                       const float *__restrict__ xtail, int tail) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const float4 a = x[i];
+        float4 b = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : y[i];
+        b.x = fmaf(alpha, a.x, b.x); b.y = fmaf(alpha, a.y, b.y); b.z = fmaf(alpha, a.z, b.z); b.w = fmaf(alpha, a.w, b.w);
+        y[i] = b;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) {
+        const float b = overwrite ? 0.f : ytail[threadIdx.x];
+        ytail[threadIdx.x] = fmaf(alpha, xtail[threadIdx.x], b);
+    }
+}
+
+static inline unsigned stream_grid(int64_t n4) {
+    int64_t g = (n4 + kBlock - 1) / kBlock;
+    const int64_t cap = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------------ CSR SpMM
+// One team per output row: y[i,:] = sum_k val[k] * X[col[k],:], optionally acc[i,:] += y[i,:].
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(int64_t n_rows, const int64_t *__restrict__ row_ptr,
+                                                           const int *__restrict__ col, const float *__restrict__ val,
+                                                           const float *__restrict__ X, int D, float *__restrict__ Y,
+                                                           float *__restrict__ acc) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int64_t i = (int64_t)blockIdx.x * TEAMS + threadIdx.x / T;
+    if (i >= n_rows) return;
+    Row<NV> s;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t k1 = row_ptr[i + 1];
+    for (int64_t k = row_ptr[i]; k < k1; ++k) {
+        const float a = val[k];
+        const Row<NV> x = load_row<T, NV, FULL>(X, col[k], D, lane);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            s.v[c].x = fmaf(a, x.v[c].x, s.v[c].x); s.v[c].y = fmaf(a, x.v[c].y, s.v[c].y);
+            s.v[c].z = fmaf(a, x.v[c].z, s.v[c].z); s.v[c].w = fmaf(a, x.v[c].w, s.v[c].w);
+        }
+    }
+    store_row<T, NV, FULL>(Y, i, D, lane, s);
+    if (acc != nullptr) {
+        Row<NV> a = load_row<T, NV, FULL>(acc, i, D, lane);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            a.v[c].x += s.v[c].x; a.v[c].y += s.v[c].y; a.v[c].z += s.v[c].z; a.v[c].w += s.v[c].w;
+        }
+        store_row<T, NV, FULL>(acc, i, D, lane, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ EmbLoss
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void embloss_sumsq_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
+                                                                const int64_t *__restrict__ u, const int64_t *__restrict__ p,
+                                                                const int64_t *__restrict__ n, int B,
+                                                                float *__restrict__ partials, int n_blocks) {
+    __shared__ float scratch[kBlock / 64];
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int b = blockIdx.x * TEAMS + threadIdx.x / T;
+    float su = 0.f, sp = 0.f, sn = 0.f;
+    if (b < B) {
+        const Row<NV> ur = load_row<T, NV, FULL>(U, u[b], D, lane);
+        const Row<NV> pr = load_row<T, NV, FULL>(I, p[b], D, lane);
+        const Row<NV> nr = load_row<T, NV, FULL>(I, n[b], D, lane);
+        su = dot_partial<NV>(ur, ur);
+        sp = dot_partial<NV>(pr, pr);
+        sn = dot_partial<NV>(nr, nr);
+    }
+    const float a = block_sum(su, scratch);
+    __syncthreads();
+    const float c = block_sum(sp, scratch);
+    __syncthreads();
+    const float e = block_sum(sn, scratch);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = a;
+        partials[n_blocks + blockIdx.x] = c;
+        partials[2 * n_blocks + blockIdx.x] = e;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void embloss_finish_kernel(const float *__restrict__ partials, int n_blocks,
+                                                                 float *__restrict__ sq3) {
+    __shared__ float scratch[kBlock / 64];
+    for (int j = 0; j < 3; ++j) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < n_blocks; i += kBlock) a += partials[j * n_blocks + i];
+        const float s = block_sum(a, scratch);
+        if (threadIdx.x == 0) sq3[j] = s;
+        __syncthreads();
+    }
+}
+
+static inline int teams_per_block_for(int D) {
+    if (D >= 64) return kBlock / 16;
+    if (D == 32) return kBlock / 8;
+    if (D == 16) return kBlock / 4;
+    if (D == 8) return kBlock / 2;
+    if (D == 4) return kBlock;
+    return kBlock / 16;
+}
+
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" {
+
+int32_t wr_gather_rows(const float *tab, int64_t n_rows, int32_t D, const int64_t *idx, int64_t n, float *out,
+                       void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    WR_REQUIRE(idx && out, WR_E_NULL, "idx/out must not be NULL");
+    WR_REQUIRE(aligned16(out), WR_E_ALIGN, "out is not 16-byte aligned");
+    WR_REQUIRE(n >= 0 && n < (int64_t(1) << 31), WR_E_SHAPE, "n out of range");
+    if (n == 0) return WR_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int tpb = teams_per_block_for(D);
+    const unsigned grid = (unsigned)((n + tpb - 1) / tpb);
+#define WR_CALL_G(T_, NV_, FULL_) \
+    hipLaunchKernelGGL((gather_rows_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, tab, D, n_rows, idx, n, out)
+    WR_DISPATCH_D(D, WR_CALL_G);
+#undef WR_CALL_G
+    WR_LAUNCH_CHECK("gather_rows_kernel");
+    return WR_OK;
+}
+
+int64_t wr_scatter_add_workspace_bytes(int64_t n, int64_t n_rows) {
+    ScatterLayout L;
+    const int32_t rc = scatter_layout(n, n_rows, L);
+    if (rc != WR_OK) return rc < 0 ? rc : -(int64_t)rc;
+    return L.total;
+}
+
+int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_t *idx, const float *src, int64_t n,
+                            int64_t padding_idx, float alpha, void *workspace, int64_t workspace_bytes, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(grad, n_rows, D, "grad")) != WR_OK) return rc;
+    WR_REQUIRE(idx && src, WR_E_NULL, "idx/src must not be NULL");
+    WR_REQUIRE(aligned16(src), WR_E_ALIGN, "src is not 16-byte aligned");
+    if (n == 0) return WR_OK;
+    ScatterLayout L;
+    if ((rc = scatter_layout(n, n_rows, L)) != WR_OK) return rc;
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= L.total, WR_E_WORKSPACE,
+               "scatter workspace %lld B < %lld B", (long long)workspace_bytes, (long long)L.total);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    char *ws = reinterpret_cast<char *>(workspace);
+    uint32_t *keyA = reinterpret_cast<uint32_t *>(ws), *keyB = reinterpret_cast<uint32_t *>(ws + L.arr_bytes);
+    uint32_t *valA = reinterpret_cast<uint32_t *>(ws + 2 * L.arr_bytes), *valB = reinterpret_cast<uint32_t *>(ws + 3 * L.arr_bytes);
+    void *temp = ws + 4 * L.arr_bytes;
+    size_t temp_bytes = L.temp;
+    const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(scatter_keys_kernel, dim3(g1), dim3(kBlock), 0, stream, idx, n, n_rows, padding_idx, keyA, valA);
+    WR_LAUNCH_CHECK("scatter_keys_kernel");
+    WR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keyA, keyB, valA, valB, (size_t)n, 0u, L.end_bit, stream));
+    const int tpb = teams_per_block_for(D);
+    const unsigned grid = (unsigned)((n + tpb - 1) / tpb);
+#define WR_CALL_S(T_, NV_, FULL_)                                                                                    \
+    hipLaunchKernelGGL((scatter_add_sorted_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, grad, D,     \
+                       (uint32_t)n_rows, keyB, valB, n, src, alpha)
+    WR_DISPATCH_D(D, WR_CALL_S);
+#undef WR_CALL_S
+    WR_LAUNCH_CHECK("scatter_add_sorted_kernel");
+    return WR_OK;
+}
+
+int32_t wr_sgd_decay_untouched(float *tab, int64_t n_rows, int32_t D, const int32_t *stamp, int32_t step_id, float lr,
+                               float l2, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    WR_REQUIRE(stamp, WR_E_NULL, "stamp must not be NULL");
+    if (l2 == 0.f) return WR_OK;
+    const int64_t n4 = n_rows * (D / 4);
+    hipLaunchKernelGGL(sgd_decay_untouched_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream_), reinterpret_cast<float4 *>(tab), n4, D / 4, stamp, step_id,
+                       lr, l2);
+    WR_LAUNCH_CHECK("sgd_decay_untouched_kernel");
+    return WR_OK;
+}
+
+int32_t wr_sgd_dense(float *tab, int64_t n_rows, int32_t D, const float *grad, const int32_t *stamp, int32_t step_id,
+                     float lr, float l2, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    if ((rc = check_table(grad, n_rows, D, "grad")) != WR_OK) return rc;
+    const int64_t n4 = n_rows * (D / 4);
+    hipLaunchKernelGGL(sgd_dense_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream_),
+                       reinterpret_cast<float4 *>(tab), reinterpret_cast<const float4 *>(grad), n4, D / 4, stamp, step_id,
+                       lr, l2);
+    WR_LAUNCH_CHECK("sgd_dense_kernel");
+    return WR_OK;
+}
+
+int32_t wr_adam_dense(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_rows, int32_t D, const float *grad,
+                      const int32_t *stamp, int32_t step_id, int64_t adam_step, float lr, float l2, float beta1,
+                      float beta2, float eps, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg, n_rows, D, "exp_avg")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg_sq, n_rows, D, "exp_avg_sq")) != WR_OK) return rc;
+    if ((rc = check_table(grad, n_rows, D, "grad")) != WR_OK) return rc;
+    WR_REQUIRE(adam_step >= 1, WR_E_RANGE, "adam_step must be >= 1");
+    // bias corrections in double, as torch computes them on the host for a python-number step
+    const double bc1 = 1.0 - pow((double)beta1, (double)adam_step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)adam_step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const int64_t n4 = n_rows * (D / 4);
+    hipLaunchKernelGGL(adam_dense_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream_),
+                       reinterpret_cast<float4 *>(tab), reinterpret_cast<float4 *>(exp_avg),
+                       reinterpret_cast<float4 *>(exp_avg_sq), reinterpret_cast<const float4 *>(grad), n4, D / 4, stamp,
+                       step_id, l2, beta1, beta2, eps, step_size, bc2_sqrt);
+    WR_LAUNCH_CHECK("adam_dense_kernel");
+    return WR_OK;
+}
+
+int32_t wr_spmm_csr(int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const float *val, const float *X,
+                    int32_t D, float *Y, float *acc, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(X, n_rows, D, "X")) != WR_OK) return rc;
+    if ((rc = check_table(Y, n_rows, D, "Y")) != WR_OK) return rc;
+    WR_REQUIRE(row_ptr && col && val, WR_E_NULL, "CSR arrays must not be NULL");
+    WR_REQUIRE(X != Y, WR_E_SHAPE, "spmm: X and Y must not alias");
+    WR_REQUIRE(acc == nullptr || aligned16(acc), WR_E_ALIGN, "acc is not 16-byte aligned");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int tpb = teams_per_block_for(D);
+    const unsigned grid = (unsigned)((n_rows + tpb - 1) / tpb);
+#define WR_CALL_M(T_, NV_, FULL_)                                                                                     \
+    hipLaunchKernelGGL((spmm_csr_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, n_rows, row_ptr, col, val, \
+                       X, D, Y, acc)
+    WR_DISPATCH_D(D, WR_CALL_M);
+#undef WR_CALL_M
+    WR_LAUNCH_CHECK("spmm_csr_kernel");
+    return WR_OK;
+}
+
+int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream_) {
+    WR_REQUIRE(y && x, WR_E_NULL, "x/y must not be NULL");
+    WR_REQUIRE(aligned16(y) && aligned16(x), WR_E_ALIGN, "x/y not 16-byte aligned");
+    WR_REQUIRE(numel >= 0, WR_E_SHAPE, "numel < 0");
+    if (numel == 0) return WR_OK;
+    const int64_t n4 = numel / 4;
+    const int tail = (int)(numel - n4 * 4);
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream_),
+                       reinterpret_cast<float4 *>(y), reinterpret_cast<const float4 *>(x), n4, alpha, (int)overwrite,
+                       y + n4 * 4, x + n4 * 4, tail);
+    WR_LAUNCH_CHECK("axpy_kernel");
+    return WR_OK;
+}
+
+int32_t wr_embloss_sumsq(const float *user_tab, const float *item_tab, int32_t D, const int64_t *u, const int64_t *p,
+                         const int64_t *n, int64_t B, float *sq3, void *workspace, int64_t workspace_bytes,
+                         void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, 1, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, 1, D, "item_tab")) != WR_OK) return rc;
+    WR_REQUIRE(u && p && n && sq3, WR_E_NULL, "index arrays / output must not be NULL");
+    WR_REQUIRE(B > 0 && B <= (int64_t(1) << 29), WR_E_SHAPE, "B out of range");
+    const int tpb = teams_per_block_for(D);
+    const int nblk = (int)((B + tpb - 1) / tpb);
+    WR_REQUIRE(workspace && workspace_bytes >= (int64_t)nblk * 12, WR_E_WORKSPACE, "embloss workspace %lld B < %lld B",
+               (long long)workspace_bytes, (long long)nblk * 12);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    float *partials = reinterpret_cast<float *>(workspace);
+#define WR_CALL_E(T_, NV_, FULL_)                                                                                       \
+    hipLaunchKernelGGL((embloss_sumsq_kernel<T_, NV_, FULL_>), dim3(nblk), dim3(kBlock), 0, stream, user_tab, item_tab, D, \
+                       u, p, n, (int)B, partials, nblk)
+    WR_DISPATCH_D(D, WR_CALL_E);
+#undef WR_CALL_E
+    WR_LAUNCH_CHECK("embloss_sumsq_kernel");
+    hipLaunchKernelGGL(embloss_finish_kernel, dim3(1), dim3(kBlock), 0, stream, partials, nblk, sq3);
+    WR_LAUNCH_CHECK("embloss_finish_kernel");
+    return WR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,293 @@
+"""Tensor-level wrappers over the C-ABI (whisprrec_amd.abi).
+
+PyTorch-ROCm is used here only as the owner of device memory and of the HIP stream; every computation is a
+call into libwhisprrec_hip.so on ``torch.cuda.current_stream()``.  Nothing in this module has a CPU path:
+tensors must live on a ROCm device and the library must be built.
+"""
+import torch
+
+from . import abi
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if t.device.type != "cuda":
+        raise abi.WhisprRecHipError("%s must live on a ROCm device (got %s); there is no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have %d dims (got %d)" % (name, ndim, t.dim()))
+    return t
+
+
+def _idx64(t, name):
+    """Reference batches are int64 tensors (src/models/BaseModel.py:121)."""
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    return _req(t.contiguous(), torch.int64, name)
+
+
+class Workspace:
+    """A growable byte buffer handed to the library as caller-owned scratch."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+_WS = {}
+
+
+def workspace(device, tag):
+    key = (str(device), tag)
+    if key not in _WS:
+        _WS[key] = Workspace(device)
+    return _WS[key]
+
+
+def device_info():
+    import ctypes
+    n_cu, wave = ctypes.c_int32(0), ctypes.c_int32(0)
+    arch = ctypes.create_string_buffer(64)
+    abi.check(abi.lib().wr_device_info(ctypes.addressof(n_cu), ctypes.addressof(wave), ctypes.addressof(arch), 64),
+              "wr_device_info")
+    return {"n_cu": n_cu.value, "wave_size": wave.value, "arch": arch.value.decode()}
+
+
+# ----------------------------------------------------------------------------------------------- forward
+def bpr_fwd(user_tab, item_tab, u, p, n, scores=True, coef=False):
+    """BPRMF.predict forward (reference src/models/general/BPRMF.py:69-80, src/utils/loss.py:37-39).
+
+    Returns dict(loss=0-d tensor, pos_score, neg_score, coef) — the optional entries are None when not asked."""
+    L = abi.lib()
+    _req(user_tab, torch.float32, "user_tab", 2)
+    _req(item_tab, torch.float32, "item_tab", 2)
+    u, p, n = _idx64(u, "user_id"), _idx64(p, "pos_item"), _idx64(n, "neg_items")
+    B, D = u.numel(), user_tab.shape[1]
+    if not (p.numel() == B and n.numel() == B):
+        raise ValueError("user_id/pos_item/neg_items must have the same length")
+    dev = user_tab.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    pos = torch.empty(B, dtype=torch.float32, device=dev) if scores else None
+    neg = torch.empty(B, dtype=torch.float32, device=dev) if scores else None
+    cf = torch.empty(B, dtype=torch.float32, device=dev) if coef else None
+    nbytes = abi.check_size(L.wr_bpr_fwd_workspace_bytes(B), "wr_bpr_fwd_workspace_bytes")
+    ws = workspace(dev, "fwd").get(nbytes)
+    abi.check(L.wr_bpr_fwd(_p(user_tab), user_tab.shape[0], _p(item_tab), item_tab.shape[0], D, _p(u), _p(p), _p(n), B,
+                           _p(pos), _p(neg), _p(cf), _p(loss), _p(ws), ws.numel(), _stream()), "wr_bpr_fwd")
+    return {"loss": loss, "pos_score": pos, "neg_score": neg, "coef": cf}
+
+
+# ----------------------------------------------------------------------------------------------- plan
+class BatchPlan:
+    """Sorted batches for the fused step (see include/whisprrec_hip.h, "Batch plan").
+
+    ``u, p, n`` are the epoch's triplets in batch order (int64 as in the reference, or int32); batch k is
+    ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201)."""
+
+    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True):
+        L = abi.lib()
+        if u.dtype not in (torch.int64, torch.int32):
+            raise TypeError("indices must be int64 or int32")
+        dt = u.dtype
+        u, p, n = (_req(t.contiguous(), dt, nm, 1) for t, nm in ((u, "u"), (p, "p"), (n, "n")))
+        N = u.numel()
+        if not (p.numel() == N and n.numel() == N):
+            raise ValueError("u/p/n must have the same length")
+        if N == 0:
+            raise ValueError("empty epoch")
+        dev = u.device
+        self.n_triplets, self.batch_size = N, int(batch_size)
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self.n_batches = (N + self.batch_size - 1) // self.batch_size
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.tu, self.tp, self.tn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
+        self.torig = torch.empty(N, **i32) if keep_orig else None
+        self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
+        self.err = torch.zeros(1, **i32)
+        nbytes = abi.check_size(L.wr_bprmf_plan_workspace_bytes(N, self.batch_size, self.n_users, self.n_items),
+                                "wr_bprmf_plan_workspace_bytes")
+        ws = workspace(dev, "plan").get(nbytes)
+        fn = L.wr_bprmf_plan_build_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_i32
+        abi.check(fn(_p(u), _p(p), _p(n), N, self.batch_size, self.n_users, self.n_items, _p(self.tu), _p(self.tp),
+                     _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(),
+                     _stream()), "wr_bprmf_plan_build")
+        if validate:
+            self.validate()
+
+    def validate(self):
+        """nn.Embedding raises IndexError for out-of-range ids; so does the plan (one sync)."""
+        if int(self.err.item()) != 0:
+            raise IndexError("index out of range in batch (user_id >= n_users or item id >= n_items)")
+
+    def batch_len(self, k):
+        return min(self.batch_size, self.n_triplets - k * self.batch_size)
+
+
+class BprmfTables:
+    """The two embedding tables plus the scratch the step kernels need.  Tables are plain fp32 tensors
+    (row-major [n_rows, D]) that stay valid PyTorch tensors between steps."""
+
+    def __init__(self, user_tab, item_tab):
+        self.U = _req(user_tab, torch.float32, "user_tab", 2)
+        self.I = _req(item_tab, torch.float32, "item_tab", 2)
+        if self.U.shape[1] != self.I.shape[1]:
+            raise ValueError("user and item tables must have the same embedding size")
+        self.D = self.U.shape[1]
+        self.dev = self.U.device
+        self.stamp_u = None
+        self.stamp_i = None
+        self.step_id = 0
+
+    def _stamps(self):
+        if self.stamp_u is None:
+            self.stamp_u = torch.full((self.U.shape[0],), -1, dtype=torch.int32, device=self.dev)
+            self.stamp_i = torch.full((self.I.shape[0],), -1, dtype=torch.int32, device=self.dev)
+        return self.stamp_u, self.stamp_i
+
+    def _ws(self, B):
+        nbytes = abi.check_size(abi.lib().wr_bprmf_step_workspace_bytes(B, self.D), "wr_bprmf_step_workspace_bytes")
+        return workspace(self.dev, "step").get(nbytes)
+
+    def _plan_ptrs(self, plan, k):
+        off = k * plan.batch_size
+        return (plan.tu.data_ptr() + 4 * off, plan.tp.data_ptr() + 4 * off, plan.tn.data_ptr() + 4 * off,
+                plan.oc_item.data_ptr() + 8 * off, plan.oc_src.data_ptr() + 8 * off, plan.batch_len(k))
+
+    def step_sgd(self, plan, k, lr, l2=0.0, loss_out=None):
+        """One BaseRunner.fit iteration (zero_grad/predict/backward/SGD.step, BaseRunner.py:196-199) on batch k."""
+        L = abi.lib()
+        tu, tp, tn, oi, os_, B = self._plan_ptrs(plan, k)
+        ws = self._ws(plan.batch_size)
+        if loss_out is None:
+            loss_out = torch.empty((), dtype=torch.float32, device=self.dev)
+        su = si = None
+        self.step_id += 1
+        if l2 != 0.0:
+            su, si = self._stamps()
+        abi.check(L.wr_bprmf_step_sgd(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, tu, tp, tn, oi,
+                                      os_, B, lr, l2, _p(su), _p(si), self.step_id, _p(loss_out), _p(ws), ws.numel(),
+                                      _stream()), "wr_bprmf_step_sgd")
+        if l2 != 0.0:  # dense weight decay on the rows the batch did not touch (torch.optim.SGD semantics)
+            abi.check(L.wr_sgd_decay_untouched(_p(self.U), self.U.shape[0], self.D, _p(su), self.step_id, lr, l2,
+                                               _stream()), "wr_sgd_decay_untouched")
+            abi.check(L.wr_sgd_decay_untouched(_p(self.I), self.I.shape[0], self.D, _p(si), self.step_id, lr, l2,
+                                               _stream()), "wr_sgd_decay_untouched")
+        return loss_out
+
+    def run_sgd(self, plan, first, count, lr, losses=None):
+        """`count` consecutive steps starting at batch `first` (native inner loop of BaseRunner.fit, l2 = 0)."""
+        L = abi.lib()
+        ws = self._ws(plan.batch_size)
+        if losses is None:
+            losses = torch.empty(count, dtype=torch.float32, device=self.dev)
+        abi.check(L.wr_bprmf_run_sgd(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(plan.tu),
+                                     _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets,
+                                     plan.batch_size, first, count, lr, _p(losses), _p(ws), ws.numel(), _stream()),
+                  "wr_bprmf_run_sgd")
+        self.step_id += count
+        return losses
+
+    def grads(self, plan, k, grad_u, grad_i, loss_out=None):
+        """embedding_dense_backward of BaseRunner.py:198 for batch k: writes the gradient rows of the rows in the
+        batch into grad_u / grad_i and stamps them with the returned step id (other rows are not written)."""
+        L = abi.lib()
+        tu, tp, tn, oi, os_, B = self._plan_ptrs(plan, k)
+        ws = self._ws(plan.batch_size)
+        su, si = self._stamps()
+        if loss_out is None:
+            loss_out = torch.empty((), dtype=torch.float32, device=self.dev)
+        self.step_id += 1
+        abi.check(L.wr_bprmf_grads(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, tu, tp, tn, oi, os_,
+                                   B, _p(grad_u), _p(grad_i), _p(su), _p(si), self.step_id, _p(loss_out), _p(ws),
+                                   ws.numel(), _stream()), "wr_bprmf_grads")
+        return loss_out, self.step_id
+
+
+# ----------------------------------------------------------------------------------------------- optimizers
+def sgd_dense(tab, grad, lr, l2=0.0, stamp=None, step_id=0):
+    abi.check(abi.lib().wr_sgd_dense(_p(_req(tab, torch.float32, "tab", 2)), tab.shape[0], tab.shape[1],
+                                     _p(_req(grad, torch.float32, "grad", 2)), _p(stamp), step_id, lr, l2, _stream()),
+              "wr_sgd_dense")
+
+
+def adam_dense(tab, exp_avg, exp_avg_sq, grad, adam_step, lr, l2=0.0, beta1=0.9, beta2=0.999, eps=1e-8, stamp=None,
+               step_id=0):
+    for t, nm in ((tab, "tab"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (grad, "grad")):
+        _req(t, torch.float32, nm, 2)
+    abi.check(abi.lib().wr_adam_dense(_p(tab), _p(exp_avg), _p(exp_avg_sq), tab.shape[0], tab.shape[1], _p(grad),
+                                      _p(stamp), step_id, adam_step, lr, l2, beta1, beta2, eps, _stream()),
+              "wr_adam_dense")
+
+
+# ----------------------------------------------------------------------------------------------- rows
+def gather_rows(tab, idx):
+    """nn.Embedding forward: out[..., :] = tab[idx[...], :]."""
+    _req(tab, torch.float32, "tab", 2)
+    flat = _idx64(idx.reshape(-1), "idx")
+    out = torch.empty((flat.numel(), tab.shape[1]), dtype=torch.float32, device=tab.device)
+    abi.check(abi.lib().wr_gather_rows(_p(tab), tab.shape[0], tab.shape[1], _p(flat), flat.numel(), _p(out), _stream()),
+              "wr_gather_rows")
+    return out.reshape(tuple(idx.shape) + (tab.shape[1],))
+
+
+def scatter_add_rows(grad, idx, src, padding_idx=-1, alpha=1.0):
+    """embedding_dense_backward: grad[idx[k], :] += alpha * src[k, :] for idx[k] != padding_idx (in place)."""
+    _req(grad, torch.float32, "grad", 2)
+    flat = _idx64(idx.reshape(-1), "idx")
+    src2 = _req(src.reshape(flat.numel(), grad.shape[1]).contiguous(), torch.float32, "src", 2)
+    if flat.numel() == 0:
+        return grad
+    L = abi.lib()
+    nbytes = abi.check_size(L.wr_scatter_add_workspace_bytes(flat.numel(), grad.shape[0]),
+                            "wr_scatter_add_workspace_bytes")
+    ws = workspace(grad.device, "scatter").get(nbytes)
+    abi.check(L.wr_scatter_add_rows(_p(grad), grad.shape[0], grad.shape[1], _p(flat), _p(src2), flat.numel(),
+                                    padding_idx, alpha, _p(ws), ws.numel(), _stream()), "wr_scatter_add_rows")
+    return grad
+
+
+# ----------------------------------------------------------------------------------------------- LightGCN pieces
+def spmm_csr(row_ptr, col, val, X, Y=None, acc=None):
+    _req(row_ptr, torch.int64, "row_ptr", 1)
+    _req(col, torch.int32, "col", 1)
+    _req(val, torch.float32, "val", 1)
+    _req(X, torch.float32, "X", 2)
+    if Y is None:
+        Y = torch.empty_like(X)
+    abi.check(abi.lib().wr_spmm_csr(X.shape[0], _p(row_ptr), _p(col), _p(val), _p(X), X.shape[1], _p(Y), _p(acc),
+                                    _stream()), "wr_spmm_csr")
+    return Y
+
+
+def axpy(y, x, alpha, overwrite=False):
+    abi.check(abi.lib().wr_axpy(_p(_req(y, torch.float32, "y")), _p(_req(x, torch.float32, "x")), y.numel(), alpha,
+                                1 if overwrite else 0, _stream()), "wr_axpy")
+    return y
+
+
+def embloss_sumsq(user_tab, item_tab, u, p, n):
+    u, p, n = _idx64(u, "u"), _idx64(p, "p"), _idx64(n, "n")
+    B, D = u.numel(), user_tab.shape[1]
+    out = torch.empty(3, dtype=torch.float32, device=user_tab.device)
+    ws = workspace(user_tab.device, "embloss").get(((B + 15) // 16 + 1) * 12 + 256)
+    abi.check(abi.lib().wr_embloss_sumsq(_p(user_tab), _p(item_tab), D, _p(u), _p(p), _p(n), B, _p(out), _p(ws),
+                                         ws.numel(), _stream()), "wr_embloss_sumsq")
+    return out
