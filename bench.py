@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — BPR training triplets/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N=1 workload = BASELINE.json configs[1]: BPRMF, emb_size=64, synthetic 1M users x 1M items (uniform ids from the
+100M-interaction generator, seed 3407), batch 65,536 triplets, SGD, l2=0.  A "step" is one BaseRunner.fit iteration
+(zero_grad / predict / backward / optimizer.step, reference src/helpers/BaseRunner.py:196-199) over one batch: raw
+(u, p, n) int32 triplets resident in HBM -> sorted batch plan -> user-phase kernel -> item-phase kernel -> updated
+tables + loss.  Plan building is INSIDE the timed region (done per chunk of batches).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the 8 TB/s HBM peak using
+algorithmic bytes; `cpu_baseline` times the oracle's sparse SGD restatement on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--emb", type=int, default=64)
+    ap.add_argument("--lr", type=float, default=0.05)
+    ap.add_argument("--chunk", type=int, default=64, help="batches per plan build")
+    ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent over items (0 = uniform, headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phase-events", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def synth_triplets(n, n_users, n_items, dev, seed, zipf=0.0):
+    """Synthetic interactions of configs[1]: uniform user / item ids (worst case for caches), negatives uniform in
+    [1, n_items) as in GeneralModel.Dataset.actions_before_epoch (reference src/models/BaseModel.py:168)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    u = torch.randint(0, n_users, (n,), generator=g, device=dev, dtype=torch.int32)
+    if zipf > 0.0:
+        # inverse-CDF sampling of a Zipf(alpha) over item ranks (contention variant, not the headline)
+        r = torch.rand(n, generator=g, device=dev, dtype=torch.float64)
+        if abs(zipf - 1.0) < 1e-9:
+            p = torch.exp(r * np.log(n_items)).to(torch.int64) - 1
+        else:
+            a = 1.0 - zipf
+            p = (((n_items ** a - 1.0) * r + 1.0) ** (1.0 / a)).to(torch.int64) - 1
+        p = p.clamp_(0, n_items - 1).to(torch.int32)
+    else:
+        p = torch.randint(0, n_items, (n,), generator=g, device=dev, dtype=torch.int32)
+    neg = torch.randint(1, n_items, (n,), generator=g, device=dev, dtype=torch.int32)
+    return u, p, neg
+
+
+def cpu_baseline(args, seconds):
+    """Oracle's sparse SGD restatement (oracle/wr_oracle.c:orc_bprmf_step_sgd_sparse) on ONE host core, same table
+    shapes, same batch size, same id distribution; bounded to ~`seconds` of CPU work."""
+    import oracle
+    rng = np.random.RandomState(3407)
+    U = (rng.standard_normal((args.users, args.emb)) * np.sqrt(2.0 / (args.users + args.emb))).astype(np.float32)
+    I = (rng.standard_normal((args.items, args.emb)) * np.sqrt(2.0 / (args.items + args.emb))).astype(np.float32)
+    bl = oracle.SparseSgdBaseline(U, I, args.batch)
+    batches = []
+    for _ in range(8):
+        batches.append((rng.randint(0, args.users, args.batch), rng.randint(0, args.items, args.batch),
+                        rng.randint(1, args.items, args.batch)))
+    bl.step(*batches[0], args.lr)  # warm-up (page faults of the scratch tables)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        bl.step(*batches[k % len(batches)], args.lr)
+        k += 1
+        if time.perf_counter() - t0 >= seconds and k >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": k * args.batch / dt, "unit": "triplets/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of B=%d on %dx%d tables, D=%d, SGD l2=0, %.1f s" % (k, args.batch, args.users, args.items,
+                                                                                  args.emb, dt),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" %
+                             (args.gpus, args.gpus))
+    if args.gpus > 1:
+        from whisprrec_amd import sharded
+        return sharded.bench_main(args, rank, world, local_rank)
+
+    from whisprrec_amd import hip_ops
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B, D, K, W = args.batch, args.emb, args.steps, args.warmup
+
+    # tables: N(0, 2/(rows+D)) = xavier_normal_ (reference src/models/init.py:25, BPRMF.py:40)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3407)
+    U = torch.randn(args.users, D, generator=g, device=dev) * float(np.sqrt(2.0 / (args.users + D)))
+    I = torch.randn(args.items, D, generator=g, device=dev) * float(np.sqrt(2.0 / (args.items + D)))
+    tabs = hip_ops.BprmfTables(U, I)
+    u, p, n = synth_triplets((K + W) * B, args.users, args.items, dev, 3407, args.zipf)
+    torch.cuda.synchronize()
+
+    def run_range(first_step, count, events=None):
+        """plan + steps for global steps [first_step, first_step+count), chunk by chunk"""
+        out = []
+        done = 0
+        while done < count:
+            c = min(args.chunk, count - done)
+            lo = (first_step + done) * B
+            plan = hip_ops.BatchPlan(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B, args.users, args.items,
+                                     validate=False)
+            ev = None if events is None else events[3 * done:3 * (done + c)]
+            out.append((plan, tabs.run_sgd(plan, 0, c, args.lr, phase_events=ev)))
+            done += c
+        return out
+
+    run_range(0, W)
+    torch.cuda.synchronize()
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run_range(W, K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    # per-kernel timing: HIP events recorded by the library on the launch stream around the two kernels of each
+    # step, on a second pass over the same (already planned) batches — outside the throughput measurement, so
+    # the event records do not sit in the timed region.
+    events = None
+    if not args.no_phase_events:
+        KP = min(K, 64)
+        events = [torch.cuda.Event(enable_timing=True) for _ in range(3 * KP)]
+        for e in events:
+            e.record()
+        torch.cuda.synchronize()
+        plan0 = res[0][0]
+        tabs.run_sgd(plan0, 0, min(KP, plan0.n_batches), args.lr, phase_events=events[:3 * min(KP, plan0.n_batches)])
+        KP = min(KP, plan0.n_batches)
+        torch.cuda.synchronize()
+
+    losses = torch.cat([r[1] for r in res]).cpu().numpy()
+    assert np.all(np.isfinite(losses)), "non-finite loss"
+    for plan, _ in res:
+        plan.validate()
+    value = K * B / dt
+
+    # unique rows per step (for algorithmic bytes with in-batch duplicates counted once)
+    uniq_u = uniq_i = 0
+    for plan, _ in res:
+        nb = plan.n_batches
+        tu = plan.tu.view(nb, B)
+        oi = plan.oc_item.view(nb, 2 * B)
+        uniq_u += int((tu[:, 1:] != tu[:, :-1]).sum().item()) + nb
+        uniq_i += int((oi[:, 1:] != oi[:, :-1]).sum().item()) + nb
+    uniq_u /= K
+    uniq_i /= K
+    row = D * 4
+    bytes_user = row * (2 * uniq_u + uniq_i) + 12 * B      # read U once, write U once, read each item row once, indices
+    bytes_item = row * uniq_i                               # write each item row once
+    bytes_step = bytes_user + bytes_item
+
+    roofline = None
+    if events is not None:
+        t_user = np.mean([events[3 * k].elapsed_time(events[3 * k + 1]) for k in range(KP)]) * 1e-3
+        t_item = np.mean([events[3 * k + 1].elapsed_time(events[3 * k + 2]) for k in range(KP)]) * 1e-3
+        if t_item >= t_user:
+            name, tk, bk = "bprmf_item_phase", t_item, bytes_item
+        else:
+            name, tk, bk = "bprmf_user_phase", t_user, bytes_user
+        ach = bk / tk / 1e9
+        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "kernel": name, "kernel_us": tk * 1e6, "algorithmic_bytes_per_launch": bk,
+                    "user_phase_us": t_user * 1e6, "item_phase_us": t_item * 1e6,
+                    "user_phase_GBs": bytes_user / t_user / 1e9, "item_phase_GBs": bytes_item / t_item / 1e9,
+                    "step_algorithmic_bytes": bytes_step, "step_achieved_GBs": bytes_step * K / dt / 1e9,
+                    "step_frac": bytes_step * K / dt / 1e9 / HBM_PEAK_GBS,
+                    "uniq_users_per_step": uniq_u, "uniq_items_per_step": uniq_i}
+
+    out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": 1, "steps": K,
+           "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BPRMF emb_size=%d, synthetic %d users x %d items (%s ids), batch %d, SGD l2=0, "
+                                  "plan build in timed region" % (D, args.users, args.items,
+                                                                  "uniform" if args.zipf == 0 else "zipf(%.2f) item" % args.zipf, B),
+                      "batch": B, "emb_size": D, "optimizer": "SGD", "l2": 0.0, "lr": args.lr,
+                      "plan_chunk_batches": args.chunk, "tables": "single GPU"},
+           "loss_first": float(losses[0]), "loss_last": float(losses[-1]),
+           "roofline": roofline}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

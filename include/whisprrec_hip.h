@@ -65,7 +65,8 @@ int32_t wr_bpr_fwd(const float *user_tab, int64_t n_users, const float *item_tab
  * triplets (last one may be short, no drop_last — BaseRunner.py:201), triplets are stably sorted by
  * user and the 2*B (item, source) occurrences are stably sorted by item, so that each table row of a
  * step has exactly one owner.
- *   tu,tp,tn [n]  : triplets of batch k at [k*batch_size, ...), sorted by user
+ *   tu,tp,tn [n]  : triplets of batch k at [k*batch_size, ...), sorted by user; bit 31 of tp[t] / tn[t] is
+ *                   set when that item row has more than one occurrence in the batch (row = low 31 bits)
  *   torig    [n]  : original position (0..n) of each sorted triplet (may be NULL)
  *   oc_item  [2n] : occurrences of batch k at [2*k*batch_size, ...), sorted by item row
  *   oc_src   [2n] : (local sorted triplet index << 1) | (1 if the occurrence is the NEGATIVE item)
@@ -101,12 +102,14 @@ int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int
 
 /* Runs consecutive steps over batches [first_batch, first_batch + n_batches) of a plan built with
  * `batch_size` over `n_triplets` triplets (the native inner loop of BaseRunner.fit, BaseRunner.py:194-200).
- * loss_out[k] receives the loss of batch first_batch + k (may be NULL).  l2 must be 0 here. */
+ * loss_out[k] receives the loss of batch first_batch + k (may be NULL).  l2 must be 0 here.
+ * phase_events (may be NULL): 3*n_batches hipEvent_t handles; for step k, events 3k / 3k+1 / 3k+2 are recorded
+ * on `stream` before the user phase, between the two kernels and after the item phase (per-kernel timing). */
 int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
                          const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                          const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
-                         int64_t n_batches, float lr, float *loss_out, void *workspace, int64_t workspace_bytes,
-                         void *stream);
+                         int64_t n_batches, float lr, float *loss_out, void *const *phase_events, void *workspace,
+                         int64_t workspace_bytes, void *stream);
 
 /* Same two kernels in gradient-emitting mode: instead of updating the tables, writes the reduced
  * gradient rows (embedding_dense_backward of BaseRunner.py:198) to grad_u[r,:] / grad_i[r,:] for rows in

@@ -72,7 +72,8 @@ def test_fwd_saturated_scores(ops, dev):
 # ------------------------------------------------------------------------------------------------ plan
 def _check_plan(plan, u, p, n, B):
     N = len(u)
-    tu, tp, tn = plan.tu.cpu().numpy(), plan.tp.cpu().numpy(), plan.tn.cpu().numpy()
+    tu, tp_raw, tn_raw = plan.tu.cpu().numpy(), plan.tp.cpu().numpy(), plan.tn.cpu().numpy()
+    tp, tn = tp_raw & 0x7FFFFFFF, tn_raw & 0x7FFFFFFF
     torig = plan.torig.cpu().numpy()
     oi, osrc = plan.oc_item.cpu().numpy(), plan.oc_src.cpu().numpy()
     for k in range(plan.n_batches):
@@ -86,6 +87,10 @@ def _check_plan(plan, u, p, n, B):
         o2 = np.argsort(items, kind="stable")
         assert np.array_equal(oi[2 * lo:2 * lo + 2 * Bk], items[o2])
         assert np.array_equal(osrc[2 * lo:2 * lo + 2 * Bk], src[o2])
+        # bit 31 of tp/tn: the item row has more than one occurrence in this batch
+        uniq, inv, cnt = np.unique(items, return_inverse=True, return_counts=True)
+        assert np.array_equal(tp_raw[lo:hi] < 0, cnt[inv[:Bk]] > 1)
+        assert np.array_equal(tn_raw[lo:hi] < 0, cnt[inv[Bk:]] > 1)
 
 
 @pytest.mark.parametrize("dtype", [np.int64, np.int32])

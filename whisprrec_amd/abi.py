@@ -28,7 +28,7 @@ SIGNATURES = {
     "wr_bprmf_step_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32,
                                   c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_run_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
-                                 c_i64, c_f32, c_vp, c_vp, c_i64, c_vp]),
+                                 c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_grads": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
                                c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "wr_sgd_decay_untouched": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_f32, c_f32, c_vp]),
@@ -58,6 +58,10 @@ def lib():
             raise WhisprRecHipError(
                 "libwhisprrec_hip.so is missing at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C whisprrec_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; the process must hold exactly one HIP runtime so that the
+        # device pointers and hipStream_t handles PyTorch hands out mean the same thing inside this library.
+        # Importing torch first makes the dynamic loader bind our NEEDED libamdhip64.so.7 to that copy.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol

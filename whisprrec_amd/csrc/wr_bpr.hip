@@ -13,12 +13,13 @@
 //   user phase: position t of the user-sorted triplets; the first position of a run of equal users
 //     ("head") owns U[u]: it reads U[u] once, loops over the run reading I[p], I[n], reduces the two dots
 //     with DPP adds inside the 16-lane row, forms the loss term and coefficient c, accumulates
-//     g_u += c (I[p]-I[n]), stashes z_t = c U[u] (what the item side needs of the OLD user row), and
-//     finally rewrites U[u] in place.  Nobody else reads U[u] in this step, so in-place is
-//     batch-synchronous.
-//   item phase: position q of the item-sorted occurrences; the head of a run owns I[r]: it sums +-z of
-//     its occurrences and rewrites I[r] in place (all reads of I by the user phase are complete at the
-//     kernel boundary).  Block 0 also folds the user phase's per-block loss partials into the loss.
+//     g_u += c (I[p]-I[n]) and finally rewrites U[u] in place.  Nobody else reads U[u] in this step, so
+//     in-place is batch-synchronous.  An item row that occurs ONCE in the batch (plan flag, bit 31 of
+//     tp/tn clear) is likewise read by this team only and is finished right here: I[p] -= lr*(+c U[u]),
+//     I[n] -= lr*(-c U[u]).  Only for item rows with several occurrences is z_t = c U[u] stashed.
+//   item phase: position q of the item-sorted occurrences; the head of a run of >= 2 occurrences owns
+//     I[r]: it sums +-z of its occurrences and rewrites I[r] in place (all reads of I by the user phase
+//     are complete at the kernel boundary).  Block 0 also folds the user phase's per-block loss partials into the loss.
 // No float atomics anywhere: each row has one writer and a fixed summation order.
 #include "wr_common.h"
 
@@ -68,11 +69,12 @@ __global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__rest
 // ----------------------------------------------------------------------------------------------- user phase
 // MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.
 template <int T, int NV, bool FULL, int MODE>
-__global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U, const float *__restrict__ I, int D,
+__global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
                                                             const int *__restrict__ tn, int B, float lr, float l2,
                                                             float *__restrict__ Z, float *__restrict__ partials,
                                                             float *__restrict__ gradU, int *__restrict__ stampU,
+                                                            float *__restrict__ gradI, int *__restrict__ stampI,
                                                             int step_id) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
@@ -88,16 +90,18 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
 #pragma unroll
             for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             int t = t0;
-            int p = tp[t], n = tn[t];
+            int praw = tp[t], nraw = tn[t];  // bit 31 set: the item row has other occurrences in this batch
             bool more;
             do {
+                const int p = praw & 0x7fffffff, n = nraw & 0x7fffffff;
+                const bool p_shared = praw < 0, n_shared = nraw < 0;
                 const Row<NV> pr = load_row<T, NV, FULL>(I, p, D, lane);
                 const Row<NV> nr = load_row<T, NV, FULL>(I, n, D, lane);
                 const int tnext = t + 1;
                 more = (tnext < B) && (tu[tnext] == u);
                 if (more) {  // indices of the next triplet of this user, issued before the dot/transcendentals
-                    p = tp[tnext];
-                    n = tn[tnext];
+                    praw = tp[tnext];
+                    nraw = tn[tnext];
                 }
                 const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
                 const float sn = team_sum<T>(dot_partial<NV>(ur, nr));
@@ -113,7 +117,41 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                     g.v[k].w = fmaf(c, pr.v[k].w - nr.v[k].w, g.v[k].w);
                     z.v[k] = make_float4(c * ur.v[k].x, c * ur.v[k].y, c * ur.v[k].z, c * ur.v[k].w);
                 }
-                store_row<T, NV, FULL>(Z, t, D, lane, z);
+                // An item row that occurs once in the batch is read by this team only: finish it here
+                // (gradient = +z for the positive, -z for the negative), no stash, no item-phase work.
+                if (!p_shared) {
+                    Row<NV> w;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        if (MODE == 0) {
+                            w.v[k].x = pr.v[k].x - lr * fmaf(l2, pr.v[k].x, z.v[k].x);
+                            w.v[k].y = pr.v[k].y - lr * fmaf(l2, pr.v[k].y, z.v[k].y);
+                            w.v[k].z = pr.v[k].z - lr * fmaf(l2, pr.v[k].z, z.v[k].z);
+                            w.v[k].w = pr.v[k].w - lr * fmaf(l2, pr.v[k].w, z.v[k].w);
+                        } else {
+                            w.v[k] = z.v[k];
+                        }
+                    }
+                    store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
+                    if (stampI != nullptr && lane == 0) stampI[p] = step_id;
+                }
+                if (!n_shared) {
+                    Row<NV> w;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        if (MODE == 0) {
+                            w.v[k].x = nr.v[k].x - lr * fmaf(l2, nr.v[k].x, -z.v[k].x);
+                            w.v[k].y = nr.v[k].y - lr * fmaf(l2, nr.v[k].y, -z.v[k].y);
+                            w.v[k].z = nr.v[k].z - lr * fmaf(l2, nr.v[k].z, -z.v[k].z);
+                            w.v[k].w = nr.v[k].w - lr * fmaf(l2, nr.v[k].w, -z.v[k].w);
+                        } else {
+                            w.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
+                        }
+                    }
+                    store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
+                    if (stampI != nullptr && lane == 0) stampI[n] = step_id;
+                }
+                if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
                 t = tnext;
             } while (more);
             if (MODE == 0) {
@@ -151,7 +189,8 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
     const int q0 = blockIdx.x * TEAMS + threadIdx.x / T;
     if (q0 < B2) {
         const int r = oc_item[q0];
-        const bool head = (q0 == 0) || (oc_item[q0 - 1] != r);
+        // head of a run of >= 2 occurrences; single-occurrence rows were finished by the user phase
+        const bool head = ((q0 == 0) || (oc_item[q0 - 1] != r)) && (q0 + 1 < B2) && (oc_item[q0 + 1] == r);
         if (head) {
             const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
             Row<NV> g;
@@ -236,17 +275,19 @@ template <int MODE>
 static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
                            const int32_t *oc_item, const int32_t *oc_src, int64_t B, float lr, float l2, float *gradU,
                            float *gradI, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id, float *loss_out,
-                           void *workspace, hipStream_t stream) {
+                           void *workspace, hipStream_t stream, void *const *events = nullptr) {
     const StepWs w = carve_step_ws(workspace, B, D);
     const dim3 block(kBlock);
     const dim3 gridA((unsigned)n_blocks_for(B, D));
     const dim3 gridB((unsigned)n_blocks_for(2 * B, D));
+    if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[0]), stream));
 #define WR_CALL_USER(T_, NV_, FULL_)                                                                                  \
     hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE>), gridA, block, 0, stream, U, I, D, tu, tp, tn, (int)B, \
-                       lr, l2, w.Z, w.partials, gradU, stamp_u, step_id)
+                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
     WR_LAUNCH_CHECK("bprmf_user_phase");
+    if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[1]), stream));
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
     hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
                        (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)w.n_partials, (float)B, \
@@ -254,6 +295,7 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
     WR_LAUNCH_CHECK("bprmf_item_phase");
+    if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[2]), stream));
     return WR_OK;
 }
 
@@ -319,8 +361,8 @@ int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int
 int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
                          const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                          const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
-                         int64_t n_batches, float lr, float *loss_out, void *workspace, int64_t workspace_bytes,
-                         void *stream_) {
+                         int64_t n_batches, float lr, float *loss_out, void *const *phase_events, void *workspace,
+                         int64_t workspace_bytes, void *stream_) {
     int32_t rc;
     if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
     if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
@@ -339,7 +381,7 @@ int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int6
         const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
         rc = launch_step<0>(user_tab, item_tab, D, tu + off, tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk,
                             lr, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, loss_out ? loss_out + k : nullptr,
-                            workspace, stream);
+                            workspace, stream, phase_events ? phase_events + 3 * k : nullptr);
         if (rc != WR_OK) return rc;
     }
     return WR_OK;

@@ -70,12 +70,26 @@ __global__ __launch_bounds__(kBlock) void plan_unpack_user(const Key *__restrict
     ivals[base + Bb + j] = (uint32_t)((j << 1) | 1);
 }
 
+// After the item sort: writes the item row of every sorted occurrence and flags, in tp/tn (bit 31), the
+// occurrences whose item row occurs more than once in its batch.  Composite keys carry the batch id, so
+// equal neighbouring keys are always in the same batch.
 template <typename Key>
-__global__ __launch_bounds__(kBlock) void plan_unpack_item(const Key *__restrict__ keys_sorted, int64_t n2, unsigned item_bits,
-                                                            int *__restrict__ oc_item) {
+__global__ __launch_bounds__(kBlock) void plan_unpack_item(const Key *__restrict__ keys_sorted,
+                                                            const uint32_t *__restrict__ src_sorted, int64_t n2, int64_t B,
+                                                            unsigned item_bits, int *__restrict__ oc_item,
+                                                            int *__restrict__ tp, int *__restrict__ tn) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n2) return;
-    oc_item[i] = (int)(keys_sorted[i] & (((Key)1 << item_bits) - 1));
+    const Key k = keys_sorted[i];
+    oc_item[i] = (int)(k & (((Key)1 << item_bits) - 1));
+    const bool shared = (i > 0 && keys_sorted[i - 1] == k) || (i + 1 < n2 && keys_sorted[i + 1] == k);
+    if (shared) {
+        const uint32_t s = src_sorted[i];
+        const int64_t batch = (int64_t)(k >> item_bits);
+        const int64_t t = batch * B + (int64_t)(s >> 1);
+        int *dst = (s & 1u) ? tn : tp;
+        dst[t] |= (int)0x80000000;  // one writer per (triplet, side)
+    }
 }
 
 struct PlanLayout {
@@ -149,7 +163,8 @@ static int32_t plan_build_impl(const Idx *u, const Idx *p, const Idx *nn, int64_
     temp_bytes = L.sort_temp;
     WR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keyA, keyB, valA, reinterpret_cast<uint32_t *>(oc_src), (size_t)n2,
                                      0u, L.item_bits + L.batch_bits, stream));
-    hipLaunchKernelGGL((plan_unpack_item<Key>), dim3(g2), dim3(kBlock), 0, stream, keyB, n2, L.item_bits, oc_item);
+    hipLaunchKernelGGL((plan_unpack_item<Key>), dim3(g2), dim3(kBlock), 0, stream, keyB,
+                       reinterpret_cast<const uint32_t *>(oc_src), n2, B, L.item_bits, oc_item, tp, tn);
     WR_LAUNCH_CHECK("plan_unpack_item");
     return WR_OK;
 }

@@ -4,6 +4,8 @@ PyTorch-ROCm is used here only as the owner of device memory and of the HIP stre
 call into libwhisprrec_hip.so on ``torch.cuda.current_stream()``.  Nothing in this module has a CPU path:
 tensors must live on a ROCm device and the library must be built.
 """
+import ctypes
+
 import torch
 
 from . import abi
@@ -63,7 +65,6 @@ def workspace(device, tag):
 
 
 def device_info():
-    import ctypes
     n_cu, wave = ctypes.c_int32(0), ctypes.c_int32(0)
     arch = ctypes.create_string_buffer(64)
     abi.check(abi.lib().wr_device_info(ctypes.addressof(n_cu), ctypes.addressof(wave), ctypes.addressof(arch), 64),
@@ -192,15 +193,29 @@ class BprmfTables:
                                                _stream()), "wr_sgd_decay_untouched")
         return loss_out
 
-    def run_sgd(self, plan, first, count, lr, losses=None):
-        """`count` consecutive steps starting at batch `first` (native inner loop of BaseRunner.fit, l2 = 0)."""
+    def run_sgd(self, plan, first, count, lr, losses=None, phase_events=None):
+        """`count` consecutive steps starting at batch `first` (native inner loop of BaseRunner.fit, l2 = 0).
+
+        phase_events: optional list of 3*count ``torch.cuda.Event(enable_timing=True)`` recorded around the two
+        kernels of every step (per-kernel timing for bench.py)."""
         L = abi.lib()
         ws = self._ws(plan.batch_size)
         if losses is None:
             losses = torch.empty(count, dtype=torch.float32, device=self.dev)
+        ev = None
+        if phase_events is not None:
+            if len(phase_events) != 3 * count:
+                raise ValueError("phase_events must hold 3 events per step")
+            handles = []
+            for e in phase_events:
+                if not e.cuda_event:  # torch creates the hipEvent_t lazily on first record
+                    e.record()
+                handles.append(e.cuda_event)
+            ev = (ctypes.c_void_p * len(handles))(*handles)
         abi.check(L.wr_bprmf_run_sgd(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(plan.tu),
                                      _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets,
-                                     plan.batch_size, first, count, lr, _p(losses), _p(ws), ws.numel(), _stream()),
+                                     plan.batch_size, first, count, lr, _p(losses),
+                                     ctypes.addressof(ev) if ev is not None else None, _p(ws), ws.numel(), _stream()),
                   "wr_bprmf_run_sgd")
         self.step_id += count
         return losses
