@@ -120,18 +120,37 @@ def main():
     u, p, n = synth_triplets((K + W) * B, args.users, args.items, dev, 3407, args.zipf)
     torch.cuda.synchronize()
 
-    def run_range(first_step, count, events=None):
-        """plan + steps for global steps [first_step, first_step+count), chunk by chunk"""
+    plan_stream = torch.cuda.Stream(device=dev)
+    main_stream = torch.cuda.current_stream(dev)
+
+    def build_plan(first_step, c, tag):
+        """enqueue the plan build of steps [first_step, first_step+c) on the side stream; returns (plan, ready event)"""
+        lo = first_step * B
+        with torch.cuda.stream(plan_stream):
+            plan = hip_ops.BatchPlan(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B, args.users, args.items,
+                                     validate=False, ws_tag="plan%d" % tag)
+            ready = torch.cuda.Event()
+            ready.record(plan_stream)
+        return plan, ready
+
+    def run_range(first_step, count):
+        """plan + steps for global steps [first_step, first_step+count), chunk by chunk.  The plan of chunk c+1 is built
+        on a side stream while the steps of chunk c run (it depends only on the indices, never on the tables)."""
         out = []
+        chunks = []
         done = 0
         while done < count:
             c = min(args.chunk, count - done)
-            lo = (first_step + done) * B
-            plan = hip_ops.BatchPlan(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B, args.users, args.items,
-                                     validate=False)
-            ev = None if events is None else events[3 * done:3 * (done + c)]
-            out.append((plan, tabs.run_sgd(plan, 0, c, args.lr, phase_events=ev)))
+            chunks.append((first_step + done, c))
             done += c
+        plan_stream.wait_stream(main_stream)
+        nxt = build_plan(chunks[0][0], chunks[0][1], 0)
+        for i, (fs, c) in enumerate(chunks):
+            plan, ready = nxt
+            if i + 1 < len(chunks):
+                nxt = build_plan(chunks[i + 1][0], chunks[i + 1][1], (i + 1) % 2)
+            main_stream.wait_event(ready)
+            out.append((plan, tabs.run_sgd(plan, 0, c, args.lr)))
         return out
 
     run_range(0, W)
@@ -165,18 +184,24 @@ def main():
     value = K * B / dt
 
     # unique rows per step (for algorithmic bytes with in-batch duplicates counted once)
-    uniq_u = uniq_i = 0
+    uniq_u = uniq_i = single_i = 0
     for plan, _ in res:
         nb = plan.n_batches
         tu = plan.tu.view(nb, B)
         oi = plan.oc_item.view(nb, 2 * B)
         uniq_u += int((tu[:, 1:] != tu[:, :-1]).sum().item()) + nb
         uniq_i += int((oi[:, 1:] != oi[:, :-1]).sum().item()) + nb
+        single_i += int((plan.tp >= 0).sum().item()) + int((plan.tn >= 0).sum().item())  # rows with one occurrence
     uniq_u /= K
     uniq_i /= K
+    single_i /= K
     row = D * 4
-    bytes_user = row * (2 * uniq_u + uniq_i) + 12 * B      # read U once, write U once, read each item row once, indices
-    bytes_item = row * uniq_i                               # write each item row once
+    # Algorithmic bytes: every unique row of the batch read once and written once + 12 B of indices
+    # per triplet.  Split by who does it: the user phase reads all of them, writes the user rows and the
+    # single-occurrence item rows; the item phase writes the item rows that have several occurrences (its re-read of
+    # those rows and the stash traffic are overhead, not algorithmic).
+    bytes_user = row * (2 * uniq_u + uniq_i + single_i) + 12 * B
+    bytes_item = row * (uniq_i - single_i)
     bytes_step = bytes_user + bytes_item
 
     roofline = None
@@ -184,9 +209,9 @@ def main():
         t_user = np.mean([events[3 * k].elapsed_time(events[3 * k + 1]) for k in range(KP)]) * 1e-3
         t_item = np.mean([events[3 * k + 1].elapsed_time(events[3 * k + 2]) for k in range(KP)]) * 1e-3
         if t_item >= t_user:
-            name, tk, bk = "bprmf_item_phase", t_item, bytes_item
+            name, tk, bk = "bprmf_item_phase<16,1,true,0>", t_item, bytes_item
         else:
-            name, tk, bk = "bprmf_user_phase", t_user, bytes_user
+            name, tk, bk = "bprmf_user_phase<16,1,true,0>", t_user, bytes_user
         ach = bk / tk / 1e9
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": None, "kernel": name, "kernel_us": tk * 1e6, "algorithmic_bytes_per_launch": bk,
@@ -194,7 +219,8 @@ def main():
                     "user_phase_GBs": bytes_user / t_user / 1e9, "item_phase_GBs": bytes_item / t_item / 1e9,
                     "step_algorithmic_bytes": bytes_step, "step_achieved_GBs": bytes_step * K / dt / 1e9,
                     "step_frac": bytes_step * K / dt / 1e9 / HBM_PEAK_GBS,
-                    "uniq_users_per_step": uniq_u, "uniq_items_per_step": uniq_i}
+                    "uniq_users_per_step": uniq_u, "uniq_items_per_step": uniq_i,
+                    "single_occurrence_items_per_step": single_i}
 
     out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": 1, "steps": K,
            "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

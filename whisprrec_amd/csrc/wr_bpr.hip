@@ -25,6 +25,8 @@
 
 namespace wr {
 
+static int g_variant = 0;  // tuning experiments (wr_internal_set_variant); 0 = shipped configuration
+
 // ----------------------------------------------------------------------------------------------- forward only
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
@@ -75,11 +77,12 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                                                             float *__restrict__ Z, float *__restrict__ partials,
                                                             float *__restrict__ gradU, int *__restrict__ stampU,
                                                             float *__restrict__ gradI, int *__restrict__ stampI,
-                                                            int step_id) {
+                                                            int step_id, int flags) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int t0 = blockIdx.x * TEAMS + threadIdx.x / T;
+    const bool wt = (flags & 1) != 0;
     float term_acc = 0.f;
     if (t0 < B) {
         const int u = tu[t0];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                             w.v[k] = z.v[k];
                         }
                     }
-                    store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
+                    if (wt) store_row_wt<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w); else store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
                     if (stampI != nullptr && lane == 0) stampI[p] = step_id;
                 }
                 if (!n_shared) {
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                             w.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
                         }
                     }
-                    store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
+                    if (wt) store_row_wt<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w); else store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
                     if (stampI != nullptr && lane == 0) stampI[n] = step_id;
                 }
-                if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
+                if (p_shared || n_shared) { if (wt) store_row_wt<T, NV, FULL>(Z, t, D, lane, z); else store_row<T, NV, FULL>(Z, t, D, lane, z); }
                 t = tnext;
             } while (more);
             if (MODE == 0) {
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                     w.v[k].z = ur.v[k].z - lr * fmaf(l2, ur.v[k].z, g.v[k].z);
                     w.v[k].w = ur.v[k].w - lr * fmaf(l2, ur.v[k].w, g.v[k].w);
                 }
-                store_row<T, NV, FULL>(U, u, D, lane, w);
+                if (wt) store_row_wt<T, NV, FULL>(U, u, D, lane, w); else store_row<T, NV, FULL>(U, u, D, lane, w);
             } else {
                 store_row<T, NV, FULL>(gradU, u, D, lane, g);
             }
@@ -184,27 +187,69 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             const float *__restrict__ partials, int n_partials,
                                                             float loss_denom, float *__restrict__ loss_out) {
     __shared__ float scratch[kBlock / 64];
+    __shared__ int heads[kBlock];
+    __shared__ int item_tile[kBlock + 8];  // oc_item of this tile plus up to 8 entries beyond it
+    __shared__ int src_tile[kBlock + 8];
+    __shared__ int n_heads;
     constexpr int TEAMS = kBlock / T;
+    constexpr int kAhead = 8;
     const int lane = threadIdx.x % T;
-    const int q0 = blockIdx.x * TEAMS + threadIdx.x / T;
-    if (q0 < B2) {
-        const int r = oc_item[q0];
-        // head of a run of >= 2 occurrences; single-occurrence rows were finished by the user phase
-        const bool head = ((q0 == 0) || (oc_item[q0 - 1] != r)) && (q0 + 1 < B2) && (oc_item[q0 + 1] == r);
-        if (head) {
+    const int tile0 = blockIdx.x * kBlock;
+    // 1) one THREAD per sorted occurrence: stage the tile's (item, source) pairs in LDS, find the heads of runs
+    //    of >= 2 equal item rows and compact them (single-occurrence rows were finished by the user phase; the
+    //    order of the list is irrelevant: every run is an independent row).  One global round trip.
+    if (threadIdx.x == 0) n_heads = 0;
+    {
+        const int q = tile0 + threadIdx.x;
+        item_tile[threadIdx.x] = (q < B2) ? oc_item[q] : -1;
+        src_tile[threadIdx.x] = (q < B2) ? oc_src[q] : 0;
+        if (threadIdx.x < kAhead) {
+            const int qa = tile0 + kBlock + threadIdx.x;
+            item_tile[kBlock + threadIdx.x] = (qa < B2) ? oc_item[qa] : -1;
+            src_tile[kBlock + threadIdx.x] = (qa < B2) ? oc_src[qa] : 0;
+        }
+    }
+    const int prev_item = (threadIdx.x == 0) ? ((tile0 > 0 && tile0 < B2) ? oc_item[tile0 - 1] : -1) : 0;
+    __syncthreads();
+    {
+        const int r = item_tile[threadIdx.x];
+        if (r >= 0) {
+            const int before = (threadIdx.x == 0) ? prev_item : item_tile[threadIdx.x - 1];
+            if (before != r && item_tile[threadIdx.x + 1] == r) heads[atomicAdd(&n_heads, 1)] = threadIdx.x;
+        }
+    }
+    __syncthreads();
+    const int nh = n_heads;
+    // 2) one TEAM per run: the row and the first stashed contributions are requested together (second round
+    //    trip); contributions are summed in sorted (fixed) order and the row is rewritten once.
+    for (int h = threadIdx.x / T; h < nh; h += TEAMS) {
+        const int j0 = heads[h];
+        const int r = item_tile[j0];
+        {
             const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
+            const int s0 = src_tile[j0], s1 = src_tile[j0 + 1];
+            const Row<NV> z0 = load_row<T, NV, FULL>(Z, s0 >> 1, D, lane);
+            const Row<NV> z1 = load_row<T, NV, FULL>(Z, s1 >> 1, D, lane);
             Row<NV> g;
+            const float g0 = (s0 & 1) ? -1.0f : 1.0f, g1 = (s1 & 1) ? -1.0f : 1.0f;  // d/dI[p] = +cU, d/dI[n] = -cU
 #pragma unroll
-            for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            int q = q0;
-            int src = oc_src[q];
-            bool more;
-            do {
+            for (int k = 0; k < NV; ++k) {
+                g.v[k].x = fmaf(g1, z1.v[k].x, fmaf(g0, z0.v[k].x, 0.f));
+                g.v[k].y = fmaf(g1, z1.v[k].y, fmaf(g0, z0.v[k].y, 0.f));
+                g.v[k].z = fmaf(g1, z1.v[k].z, fmaf(g0, z0.v[k].z, 0.f));
+                g.v[k].w = fmaf(g1, z1.v[k].w, fmaf(g0, z0.v[k].w, 0.f));
+            }
+            // third and later occurrences (rare): walk on, from LDS while inside the staged window
+            int j = j0 + 2;
+            for (;;) {
+                const int q = tile0 + j;
+                if (q >= B2) break;
+                const bool in_lds = j < kBlock + kAhead;
+                const int it = in_lds ? item_tile[j] : oc_item[q];
+                if (it != r) break;
+                const int src = in_lds ? src_tile[j] : oc_src[q];
                 const Row<NV> z = load_row<T, NV, FULL>(Z, src >> 1, D, lane);
-                const float sgn = (src & 1) ? -1.0f : 1.0f;  // d/dI[p] = +c U[u], d/dI[n] = -c U[u]
-                const int qnext = q + 1;
-                more = (qnext < B2) && (oc_item[qnext] == r);
-                if (more) src = oc_src[qnext];
+                const float sgn = (src & 1) ? -1.0f : 1.0f;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     g.v[k].x = fmaf(sgn, z.v[k].x, g.v[k].x);
@@ -212,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                     g.v[k].z = fmaf(sgn, z.v[k].z, g.v[k].z);
                     g.v[k].w = fmaf(sgn, z.v[k].w, g.v[k].w);
                 }
-                q = qnext;
-            } while (more);
+                ++j;
+            }
             if (MODE == 0) {
                 Row<NV> w;
 #pragma unroll
@@ -279,11 +324,11 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     const StepWs w = carve_step_ws(workspace, B, D);
     const dim3 block(kBlock);
     const dim3 gridA((unsigned)n_blocks_for(B, D));
-    const dim3 gridB((unsigned)n_blocks_for(2 * B, D));
+    const dim3 gridB((unsigned)((2 * B + kBlock - 1) / kBlock));  // item phase: one thread per occurrence
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[0]), stream));
 #define WR_CALL_USER(T_, NV_, FULL_)                                                                                  \
     hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE>), gridA, block, 0, stream, U, I, D, tu, tp, tn, (int)B, \
-                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id)
+                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, g_variant)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
     WR_LAUNCH_CHECK("bprmf_user_phase");
@@ -311,6 +356,9 @@ static int32_t check_plan_args(const void *tu, const void *tp, const void *tn, c
 using namespace wr;
 
 extern "C" {
+
+// Not part of the public ABI (absent from include/whisprrec_hip.h): selects experimental kernel variants.
+void wr_internal_set_variant(int v) { g_variant = v; }
 
 int64_t wr_bpr_fwd_workspace_bytes(int64_t B) { return align_up(((B + 15) / 16 + 1) * 4, 256); }
 

@@ -103,7 +103,7 @@ class BatchPlan:
     ``u, p, n`` are the epoch's triplets in batch order (int64 as in the reference, or int32); batch k is
     ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201)."""
 
-    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True):
+    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan"):
         L = abi.lib()
         if u.dtype not in (torch.int64, torch.int32):
             raise TypeError("indices must be int64 or int32")
@@ -125,7 +125,7 @@ class BatchPlan:
         self.err = torch.zeros(1, **i32)
         nbytes = abi.check_size(L.wr_bprmf_plan_workspace_bytes(N, self.batch_size, self.n_users, self.n_items),
                                 "wr_bprmf_plan_workspace_bytes")
-        ws = workspace(dev, "plan").get(nbytes)
+        ws = workspace(dev, ws_tag).get(nbytes)  # distinct tags allow plan builds in flight on different streams
         fn = L.wr_bprmf_plan_build_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_i32
         abi.check(fn(_p(u), _p(p), _p(n), N, self.batch_size, self.n_users, self.n_items, _p(self.tu), _p(self.tp),
                      _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(),
