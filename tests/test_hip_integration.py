@@ -1,0 +1,129 @@
+"""GPU integration tests: the BPRMF drop-in model driven (a) by the reference runner loop restated in
+whisprrec_amd.runner.BaseRunner.fit (predict / backward / optimizer.step per batch) and (b) by HipRunner.fit (device epoch),
+both starting from the reference's seed only — sampler, shuffle, initial tables, loss curve and final tables must
+reproduce what the reference produced on ml-100k (tests/golden/g2_ml100k_curve.npz) within 1e-5 relative."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from test_host_contract import ml100k_corpus, seed_all
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _args(**kw):
+    base = dict(device=torch.device("cuda:0"), model_path="/tmp/wr_test_model_gpu.pt", buffer=1, num_neg=1, test_all=1,
+                embedding_size=64, fused=1, epoch=2, check_epoch=1, test_epoch=-1, early_stop=10, lr=0.5, l2=0.0,
+                batch_size=2048, eval_batch_size=2048, optimizer="SGD", num_workers=0, pin_memory=0, topk="10,20",
+                metric="NDCG, HR")
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def _setup(g2, **kw):
+    from whisprrec_amd.bprmf import BPRMF
+    args = _args(**kw)
+    seed_all(3407)
+    corpus = ml100k_corpus(g2)
+    model = BPRMF(args, corpus).to(args.device)     # main.py:66
+    return args, corpus, model, BPRMF.Dataset(model, corpus, "train")
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_reference_runner_loop_sgd(g2, fused):
+    from whisprrec_amd import runner
+    args, corpus, model, ds = _setup(g2, fused=fused)
+    r = runner.BaseRunner(args)
+    means = [r.fit(ds, epoch=1), r.fit(ds, epoch=2)]
+    assert abs(means[0] - g2["sgd_epoch_mean"][0]) / g2["sgd_epoch_mean"][0] < TOL
+    assert abs(means[1] - g2["sgd_epoch_mean"][1]) / g2["sgd_epoch_mean"][1] < TOL
+    assert rel_err(model.user_embeddings.weight.detach().cpu().numpy(), g2["sgd_Uend"]) < TOL
+    assert rel_err(model.item_embeddings.weight.detach().cpu().numpy(), g2["sgd_Iend"]) < TOL
+
+
+def test_hip_runner_sgd(g2):
+    from whisprrec_amd import runner
+    args, corpus, model, ds = _setup(g2)
+    r = runner.HipRunner(args)
+    means = [r.fit(ds, epoch=1), r.fit(ds, epoch=2)]
+    assert abs(means[0] - g2["sgd_epoch_mean"][0]) / g2["sgd_epoch_mean"][0] < TOL
+    assert abs(means[1] - g2["sgd_epoch_mean"][1]) / g2["sgd_epoch_mean"][1] < TOL
+    assert rel_err(model.user_embeddings.weight.detach().cpu().numpy(), g2["sgd_Uend"]) < TOL
+    assert rel_err(model.item_embeddings.weight.detach().cpu().numpy(), g2["sgd_Iend"]) < TOL
+
+
+def test_hip_runner_adam_default_optimizer(g2):
+    """reference default optimizer (BaseRunner.py:36), README learning rate"""
+    from whisprrec_amd import runner
+    args, corpus, model, ds = _setup(g2, optimizer="Adam", lr=1e-3, epoch=1)
+    r = runner.HipRunner(args)
+    mean = r.fit(ds, epoch=1)
+    assert abs(mean - g2["adam_epoch_mean"][0]) / g2["adam_epoch_mean"][0] < TOL
+    assert rel_err(model.user_embeddings.weight.detach().cpu().numpy(), g2["adam_Uend"]) < 1e-4
+    assert rel_err(model.item_embeddings.weight.detach().cpu().numpy(), g2["adam_Iend"]) < 1e-4
+
+
+def test_reference_runner_loop_adam(g2):
+    from whisprrec_amd import runner
+    args, corpus, model, ds = _setup(g2, optimizer="Adam", lr=1e-3, epoch=1)
+    r = runner.BaseRunner(args)
+    mean = r.fit(ds, epoch=1)
+    assert abs(mean - g2["adam_epoch_mean"][0]) / g2["adam_epoch_mean"][0] < TOL
+    assert rel_err(model.user_embeddings.weight.detach().cpu().numpy(), g2["adam_Uend"]) < 1e-4
+
+
+def test_torch_optimizer_on_dense_grads(g1):
+    """--optimizer Adagrad (BaseRunner.py:36 lists it): torch.optim on the dense gradients our backward emits must equal
+    torch.optim on autograd's dense gradients, which we hold as golden gU/gI."""
+    from whisprrec_amd.bprmf import BPRMF
+    from whisprrec_amd import host
+    args = _args(optimizer="Adagrad", lr=0.05)
+    corpus = host.Corpus(97, 131, {"train": {"user_id": g1["u0"], "item_id": g1["p0"]},
+                                   "dev": {"user_id": [], "item_id": []}, "test": {"user_id": [], "item_id": []}})
+    model = BPRMF(args, corpus).to(args.device)
+    assert model.optimizer is None
+    with torch.no_grad():
+        model.user_embeddings.weight.copy_(torch.from_numpy(g1["U0"]))
+        model.item_embeddings.weight.copy_(torch.from_numpy(g1["I0"]))
+    model.train()
+    dev = args.device
+    batch = {"user_id": torch.from_numpy(g1["u0"]).to(dev), "pos_item": torch.from_numpy(g1["p0"]).to(dev),
+             "neg_items": torch.from_numpy(g1["n0"]).to(dev)}
+    loss = model.predict(batch)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g1["loss0"][0])) / float(g1["loss0"][0]) < TOL
+    assert rel_err(model.user_embeddings.weight.grad.cpu().numpy(), g1["gU"]) < TOL
+    assert rel_err(model.item_embeddings.weight.grad.cpu().numpy(), g1["gI"]) < TOL
+
+
+def test_full_predict_and_eval(g2):
+    from whisprrec_amd import runner, host
+    args, corpus, model, ds = _setup(g2)
+    model.eval()
+    users = torch.tensor([0, 5, 942], device=args.device)
+    s = model.full_predict({"user_id": users})
+    ref = model.user_embeddings.weight.detach()[users] @ model.item_embeddings.weight.detach().t()
+    assert s.shape == (3, 1574) and torch.allclose(s, ref, rtol=1e-5, atol=1e-7)
+    # evaluation pipeline end to end on a small dev frame
+    corpus.data_df["dev"] = {"user_id": np.array([0, 1, 2]), "item_id": np.array([10, 20, 30])}
+    for u, i in ((0, 10), (1, 20), (2, 30)):
+        corpus.residual_clicked_set[u].add(i)
+    dev_ds = type(ds)(model, corpus, "dev")
+    r = runner.HipRunner(args)
+    res = r.evaluate(dev_ds, [10], ["NDCG", "HR"])
+    assert set(res) == {"NDCG@10", "HR@10"} and 0.0 <= res["HR@10"] <= 1.0
+
+
+def test_save_load_roundtrip(g2, tmp_path):
+    args, corpus, model, ds = _setup(g2, model_path=str(tmp_path / "m" / "bprmf.pt"))
+    model.save_model()
+    sd = torch.load(args.model_path)
+    assert list(sd.keys()) == ["user_embeddings.weight", "item_embeddings.weight"]   # reference checkpoint layout
+    with torch.no_grad():
+        model.user_embeddings.weight.zero_()
+    model.load_model()
+    assert np.array_equal(model.user_embeddings.weight.detach().cpu().numpy(), g2["sgd_U0"])

@@ -1,0 +1,129 @@
+"""CPU tests of the host-side mirror of the reference contract (whisprrec_amd/host.py, bprmf.py, runner.py): model
+construction, state_dict keys, sampler and shuffle streams (bit-exact against what the reference recorded in
+tests/golden/g2_ml100k_curve.npz), collate, ranking metrics.  No kernel is launched here."""
+import argparse
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from whisprrec_amd import host, runner as wr_runner
+from whisprrec_amd.bprmf import BPRMF
+
+
+def seed_all(seed):
+    """reference utils.init_seed (src/utils/utils.py:13-20)"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def ml100k_corpus(g2):
+    ptr, idx = g2["clicked_ptr"], g2["clicked_idx"]
+    nU, nI = int(g2["n_users"][0]), int(g2["n_items"][0])
+    tcs = {u: set(idx[ptr[u]:ptr[u + 1]].tolist()) for u in range(nU)}
+    data = {"train": {"user_id": g2["train_user"].astype(np.int64), "item_id": g2["train_item"].astype(np.int64)},
+            "dev": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)},
+            "test": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)}}
+    return host.Corpus(nU, nI, data, tcs, {u: set() for u in range(nU)})
+
+
+def model_args(**kw):
+    base = dict(device=torch.device("cpu"), model_path="/tmp/wr_test_model.pt", buffer=1, num_neg=1, test_all=1,
+                embedding_size=64, fused=1)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_flags_match_reference_names():
+    p = argparse.ArgumentParser()
+    BPRMF.parse_model_args(p)
+    wr_runner.HipRunner.parse_runner_args(p)
+    a = p.parse_args([])
+    assert a.embedding_size == 64 and a.num_neg == 1 and a.test_all == 1 and a.buffer == 1 and a.model_path == ""
+    assert (a.epoch, a.lr, a.l2, a.batch_size, a.eval_batch_size, a.optimizer, a.num_workers, a.topk, a.early_stop) == \
+        (200, 5e-4, 0, 2048, 2048, "Adam", 5, "10,20", 10)
+    assert BPRMF.reader == "BaseReader" and BPRMF.runner == "BaseRunner" and BPRMF.extra_log_args == ["embedding_size"]
+
+
+def test_initial_tables_bit_identical_to_reference(g2):
+    seed_all(3407)
+    m = BPRMF(model_args(), ml100k_corpus(g2))
+    assert list(m.state_dict().keys()) == ["user_embeddings.weight", "item_embeddings.weight"]
+    assert np.array_equal(m.user_embeddings.weight.detach().numpy(), g2["sgd_U0"])
+    assert np.array_equal(m.item_embeddings.weight.detach().numpy(), g2["sgd_I0"])
+    assert m.count_variables() == (943 + 1574) * 64
+    assert m.optimizer is None  # no lr/optimizer in args -> the runner builds one, as in the reference
+
+
+def test_sampler_and_shuffle_streams_bit_exact(g2):
+    """Two epochs of (negative sampling -> DataLoader shuffle) reproduce the reference's batches index for index."""
+    seed_all(3407)
+    corpus = ml100k_corpus(g2)
+    m = BPRMF(model_args(), corpus)
+    ds = BPRMF.Dataset(m, corpus, "train")
+    n = len(ds)
+    assert n == 66016
+    for ep in range(2):
+        ds.actions_before_epoch()
+        order = wr_runner.epoch_order(n, 2048).numpy()
+        sl = slice(ep * n, (ep + 1) * n)
+        assert np.array_equal(ds.data["user_id"][order], g2["sgd_bu"][sl])
+        assert np.array_equal(ds.data["item_id"][order], g2["sgd_bp"][sl])
+        assert np.array_equal(np.asarray(ds.data["neg_items"])[order], g2["sgd_bn"][sl])
+
+
+def test_g3_sampler_bit_exact(g3):
+    ptr, idx = g3["clicked_ptr"], g3["clicked_idx"]
+    sets = {u: set(idx[ptr[u]:ptr[u + 1]].tolist()) for u in range(len(ptr) - 1)}
+    np.random.seed(int(g3["seed"][0]))
+    n1 = host.sample_negatives(g3["users"], int(g3["n_items"][0]), sets)
+    n2 = host.sample_negatives(g3["users"], int(g3["n_items"][0]), sets)
+    assert np.array_equal(n1, g3["neg_epoch1"]) and np.array_equal(n2, g3["neg_epoch2"])
+
+
+def test_collate_batch_layout(g2):
+    corpus = ml100k_corpus(g2)
+    m = BPRMF(model_args(), corpus)
+    ds = BPRMF.Dataset(m, corpus, "train")
+    ds.data["neg_items"] = np.arange(len(ds)) % 7 + 1
+    batch = ds.collate_batch([ds[i] for i in (5, 6, 7)])
+    assert set(batch) == {"user_id", "pos_item", "neg_items", "batch_size", "phase"}
+    for k in ("user_id", "pos_item", "neg_items"):
+        assert batch[k].dtype == torch.int64 and batch[k].shape == (3,)
+    assert batch["batch_size"] == 3 and batch["phase"] == "train"
+    assert batch["user_id"].tolist() == g2["train_user"][5:8].tolist()
+    # ragged values are right-padded with zeros (sequential models)
+    ragged = ds.collate_batch([{"h": np.array([1, 2, 3])}, {"h": np.array([4])}])
+    assert ragged["h"].tolist() == [[1, 2, 3], [4, 0, 0]]
+
+
+def test_evaluate_method_matches_reference(g6):
+    res = wr_runner.BaseRunner.evaluate_method(g6["predictions"], [5, 10, 20], ["NDCG", "HR", "RECALL", "PRECISION"])
+    for k, v in zip(g6["keys"], g6["values"]):
+        assert abs(res[str(k)] - v) < 1e-12
+    line = wr_runner.format_metric({"NDCG@10": np.float64(0.10851), "HR@10": 0.2254, "HR@20": np.float32(0.3), "NDCG@20": 0.125})
+    assert line == "HR@10:0.2254,NDCG@10:0.1085,HR@20:0.3000,NDCG@20:0.1250"
+
+
+def test_early_stop_rule():
+    a = argparse.Namespace(epoch=1, check_epoch=1, test_epoch=-1, early_stop=3, lr=1e-3, l2=0, batch_size=4,
+                           eval_batch_size=4, optimizer="SGD", num_workers=0, pin_memory=0, topk="10,20", metric="NDCG, HR")
+    r = wr_runner.HipRunner(a)
+    assert r.main_metric == "NDCG@10" and r.metrics == ["NDCG", "HR"]
+    assert not r.eval_termination([0.1, 0.2, 0.3])
+    assert r.eval_termination([0.5, 0.4, 0.3, 0.2])        # non-increasing over the last 3 (BaseRunner.py:203-206)
+    assert r.eval_termination([0.5, 0.1, 0.2, 0.3, 0.4])   # 4 epochs since the best (BaseRunner.py:207-208)
+
+
+def test_model_refuses_cpu_execution(g2):
+    from whisprrec_amd import abi
+    m = BPRMF(model_args(lr=0.1, l2=0.0, optimizer="SGD"), ml100k_corpus(g2))
+    batch = {"user_id": torch.zeros(4, dtype=torch.int64), "pos_item": torch.ones(4, dtype=torch.int64),
+             "neg_items": torch.ones(4, dtype=torch.int64) * 2}
+    m.train()
+    loss = m.predict(batch)
+    loss.backward()
+    with pytest.raises(abi.WhisprRecHipError):
+        m.optimizer.step()

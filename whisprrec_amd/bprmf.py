@@ -1,0 +1,221 @@
+"""BPRMF on MI355X behind the reference's model contract (reference src/models/general/BPRMF.py).
+
+Same surface as the reference class — ``reader``/``runner``/``extra_log_args``, ``parse_model_args`` (flag
+``--embedding_size``, BPRMF.py:24), ``__init__(args, corpus)``, ``predict(batch) -> loss``, ``full_predict(batch) ->
+[B, n_items]``, ``state_dict`` keys ``user_embeddings.weight`` / ``item_embeddings.weight`` — but the arithmetic of
+``predict`` + ``loss.backward()`` + ``optimizer.step()`` (reference src/helpers/BaseRunner.py:196-199) runs in the
+hand-written HIP kernels of libwhisprrec_hip.so.  There is no CPU path: using the model on a CPU device raises.
+
+Two ways to drive it:
+  * unchanged ``BaseRunner.fit``: the model pre-installs ``self.optimizer`` (the runner only builds one while it is
+    ``None``, BaseRunner.py:182-183).  ``predict`` records the batch, ``loss.backward()`` is a marker, and
+    ``optimizer.step()`` launches the fused step, which also writes the loss value into the tensor ``predict`` returned —
+    it is read by the runner only after ``step()`` (``loss.detach().cpu()``, BaseRunner.py:200).  ``--fused 0`` computes
+    the loss eagerly in ``predict`` instead (one extra gather pass).
+  * ``HipRunner`` (runner.py): plans a whole epoch on the device and runs the steps from native code.
+Other ``--optimizer`` names (Adagrad, Adadelta, ...) work through ``torch.optim`` on the dense gradients the backward
+kernels emit.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip_ops, host
+
+
+class FusedOptimizer:
+    """Duck-types what BaseRunner.fit needs from ``model.optimizer`` (``zero_grad``/``step``) and applies
+    torch.optim.SGD / torch.optim.Adam semantics (reference BaseRunner.py:120-124) inside the HIP step."""
+
+    def __init__(self, model, name, lr, l2):
+        if name not in ("SGD", "Adam"):
+            raise ValueError("FusedOptimizer supports SGD and Adam, got %r" % name)
+        self.model, self.name, self.lr, self.l2 = model, name, float(lr), float(l2)
+        self.betas, self.eps = (0.9, 0.999), 1e-8
+        self.adam_step = 0
+        self.state = None
+
+    def zero_grad(self, set_to_none=True):
+        self.model._pending = None
+
+    def _adam_state(self):
+        if self.state is None:
+            m = self.model
+            z = torch.zeros_like
+            self.state = {"gU": z(m.user_embeddings.weight), "gI": z(m.item_embeddings.weight),
+                          "mU": z(m.user_embeddings.weight), "vU": z(m.user_embeddings.weight),
+                          "mI": z(m.item_embeddings.weight), "vI": z(m.item_embeddings.weight)}
+        return self.state
+
+    @torch.no_grad()
+    def step(self):
+        m = self.model
+        if m._pending is None:
+            raise RuntimeError("optimizer.step() without a preceding predict()/backward()")
+        u, p, n, loss_buf = m._pending
+        m._pending = None
+        tabs = m._tables()
+        plan = hip_ops.BatchPlan(u, p, n, u.numel(), m.user_num, m.item_num)
+        if self.name == "SGD":
+            tabs.step_sgd(plan, 0, self.lr, self.l2, loss_out=loss_buf)
+        else:
+            st = self._adam_state()
+            self.adam_step += 1
+            _, sid = tabs.grads(plan, 0, st["gU"], st["gI"], loss_out=loss_buf)
+            hip_ops.adam_dense(tabs.U, st["mU"], st["vU"], st["gU"], self.adam_step, self.lr, self.l2, self.betas[0],
+                               self.betas[1], self.eps, stamp=tabs.stamp_u, step_id=sid)
+            hip_ops.adam_dense(tabs.I, st["mI"], st["vI"], st["gI"], self.adam_step, self.lr, self.l2, self.betas[0],
+                               self.betas[1], self.eps, stamp=tabs.stamp_i, step_id=sid)
+
+
+class _DeferredBprLoss(torch.autograd.Function):
+    """The loss tensor handed back by ``predict`` when the fused optimizer owns the update: backward only records
+    that it ran (the gradient never materialises; the step kernels consume the batch directly)."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, model, loss_buf):
+        ctx.model = model
+        return loss_buf
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._backward_seen = True
+        return None, None, None, None
+
+
+class _DenseGradBprLoss(torch.autograd.Function):
+    """Loss with real (dense) gradients for arbitrary torch optimizers: forward = wr_bpr_fwd, backward = the two step
+    kernels in gradient-emitting mode (embedding_dense_backward of BaseRunner.py:198)."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, model, u, p, n):
+        out = hip_ops.bpr_fwd(user_w.detach(), item_w.detach(), u, p, n, scores=False)
+        ctx.model, ctx.idx = model, (u, p, n)
+        return out["loss"]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        m = ctx.model
+        u, p, n = ctx.idx
+        tabs = m._tables()
+        plan = hip_ops.BatchPlan(u, p, n, u.numel(), m.user_num, m.item_num)
+        gU = torch.zeros_like(tabs.U)
+        gI = torch.zeros_like(tabs.I)
+        tabs.grads(plan, 0, gU, gI)
+        return gU * grad_out, gI * grad_out, None, None, None, None
+
+
+def make_bprmf(general_model_cls):
+    """Builds the BPRMF class on top of a GeneralModel base: ``host.GeneralModel`` stand-alone, or the reference's own
+    ``models.BaseModel.GeneralModel`` when dropped into its tree (so its Dataset / reader plumbing is reused)."""
+
+    class BPRMF(general_model_cls):
+        reader = "BaseReader"
+        runner = "BaseRunner"
+        extra_log_args = ["embedding_size"]
+
+        @staticmethod
+        def parse_model_args(parser):
+            parser.add_argument("--embedding_size", type=int, default=64, help="Size of embedding vectors.")
+            parser.add_argument("--fused", type=int, default=1,
+                                help="1: loss value is produced by the fused step at optimizer.step(); 0: eagerly in predict().")
+            return general_model_cls.parse_model_args(parser)
+
+        def __init__(self, args, corpus):
+            super().__init__(args, corpus)
+            self.emb_size = args.embedding_size
+            if self.emb_size % 4 != 0:
+                raise ValueError("embedding_size must be a multiple of 4 for the HIP kernels (got %d)" % self.emb_size)
+            # same construction order and initialiser as the reference (BPRMF.py:35-40, init.py:13-29), so the same
+            # torch seed gives bit-identical initial tables
+            self.user_embeddings = nn.Embedding(self.user_num, self.emb_size)
+            self.item_embeddings = nn.Embedding(self.item_num, self.emb_size)
+            nn.init.xavier_normal_(self.user_embeddings.weight.data)
+            nn.init.xavier_normal_(self.item_embeddings.weight.data)
+            self.fused = int(getattr(args, "fused", 1))
+            self._pending = None
+            self._backward_seen = False
+            self._tabs = None
+            name = getattr(args, "optimizer", None)
+            if name in ("SGD", "Adam") and hasattr(args, "lr"):
+                self.optimizer = FusedOptimizer(self, name, args.lr, getattr(args, "l2", 0.0))
+
+        # ------------------------------------------------------------------ plumbing
+        def _tables(self):
+            U, I = self.user_embeddings.weight.data, self.item_embeddings.weight.data
+            if self._tabs is None or self._tabs.U.data_ptr() != U.data_ptr() or self._tabs.I.data_ptr() != I.data_ptr():
+                self._tabs = hip_ops.BprmfTables(U, I)  # raises on CPU tensors: there is no CPU path
+            return self._tabs
+
+        def _batch(self, feed_dict):
+            dev = self.user_embeddings.weight.device
+            return tuple(feed_dict[k].to(dev).reshape(-1) for k in ("user_id", "pos_item", "neg_items"))
+
+        # ------------------------------------------------------------------ reference surface
+        def forward(self, user, item):
+            return (hip_ops.gather_rows(self.user_embeddings.weight.data, user),
+                    hip_ops.gather_rows(self.item_embeddings.weight.data, item))
+
+        def predict(self, feed_dict):
+            u, p, n = self._batch(feed_dict)
+            if self.training and isinstance(self.optimizer, FusedOptimizer):
+                loss_buf = torch.zeros((), dtype=torch.float32, device=u.device)
+                if not self.fused:
+                    loss_buf = hip_ops.bpr_fwd(self.user_embeddings.weight.data, self.item_embeddings.weight.data, u, p, n,
+                                               scores=False)["loss"]
+                self._pending = (u, p, n, loss_buf if self.fused else None)
+                return _DeferredBprLoss.apply(self.user_embeddings.weight, self.item_embeddings.weight, self, loss_buf)
+            return _DenseGradBprLoss.apply(self.user_embeddings.weight, self.item_embeddings.weight, self, u, p, n)
+
+        def full_predict(self, feed_dict):
+            """scores[B, n_items] = U[user] @ I^T (BPRMF.py:82-91).  Evaluation only: a plain GEMM, left to rocBLAS."""
+            dev = self.user_embeddings.weight.device
+            user_e = hip_ops.gather_rows(self.user_embeddings.weight.data, feed_dict["user_id"].to(dev))
+            return torch.matmul(user_e, self.item_embeddings.weight.data.t())
+
+        # ------------------------------------------------------------------ native epoch (used by HipRunner)
+        @torch.no_grad()
+        def train_epoch(self, u, p, n, batch_size, lr, l2=0.0, optimizer="SGD", chunk=64):
+            """Runs one epoch over triplets already in batch order on the device; returns the per-batch losses
+            (device tensor), i.e. the list BaseRunner.fit averages (BaseRunner.py:200-201)."""
+            tabs = self._tables()
+            N = u.numel()
+            nb = (N + batch_size - 1) // batch_size
+            losses = torch.empty(nb, dtype=torch.float32, device=u.device)
+            opt = self.optimizer if isinstance(self.optimizer, FusedOptimizer) else None
+            done = 0
+            while done < nb:
+                c = min(chunk, nb - done)
+                lo, hi = done * batch_size, min(N, (done + c) * batch_size)
+                plan = hip_ops.BatchPlan(u[lo:hi], p[lo:hi], n[lo:hi], batch_size, self.user_num, self.item_num)
+                if optimizer == "SGD" and l2 == 0.0:
+                    tabs.run_sgd(plan, 0, c, lr, losses=losses[done:done + c])
+                elif optimizer == "SGD":
+                    for k in range(c):
+                        tabs.step_sgd(plan, k, lr, l2, loss_out=losses[done + k])
+                elif optimizer == "Adam":
+                    if opt is None or opt.name != "Adam":
+                        opt = self.optimizer = FusedOptimizer(self, "Adam", lr, l2)
+                    st = opt._adam_state()
+                    for k in range(c):
+                        opt.adam_step += 1
+                        _, sid = tabs.grads(plan, k, st["gU"], st["gI"], loss_out=losses[done + k])
+                        hip_ops.adam_dense(tabs.U, st["mU"], st["vU"], st["gU"], opt.adam_step, lr, l2, stamp=tabs.stamp_u,
+                                           step_id=sid)
+                        hip_ops.adam_dense(tabs.I, st["mI"], st["vI"], st["gI"], opt.adam_step, lr, l2, stamp=tabs.stamp_i,
+                                           step_id=sid)
+                else:
+                    raise ValueError("train_epoch supports SGD and Adam; use BaseRunner.fit for %r" % optimizer)
+                done += c
+            return losses
+
+    BPRMF.__qualname__ = "BPRMF"
+    return BPRMF
+
+
+BPRMF = make_bprmf(host.GeneralModel)
+
+
+def bind(reference_general_model_cls):
+    """``BPRMFHip = bind(GeneralModel)`` inside the reference tree."""
+    return make_bprmf(reference_general_model_cls)

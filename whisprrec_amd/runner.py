@@ -1,0 +1,221 @@
+"""Runner for the HIP models behind the reference's runner contract (reference src/helpers/BaseRunner.py).
+
+``BaseRunner`` restates the reference runner's surface (flags, ``train``/``fit``/``evaluate``/``print_res``,
+``evaluate_method``) so the package runs stand-alone; ``HipRunner`` replaces the inner loop of ``fit``
+(BaseRunner.py:180-201) by device-side epoch preparation plus the native multi-step driver, keeping:
+  * negative sampling = the dataset's own ``actions_before_epoch`` (bit-exact NumPy stream);
+  * batch composition = exactly what ``DataLoader(shuffle=True)`` would yield (same torch RNG draws);
+  * return value = unweighted mean of per-batch mean losses, short last batch included (BaseRunner.py:200-201).
+Inside the reference tree use ``bind_runner(BaseRunner)`` to inherit everything else from it.
+"""
+import gc
+import logging
+import os
+from time import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+
+def format_metric(result_dict):
+    """'NDCG@10:0.1085,HR@10:0.2254'-style line (reference src/utils/utils.py:58-71, without its NumPy-2 breakage)."""
+    names = sorted({k.split("@")[0] for k in result_dict})
+    topks = sorted({int(k.split("@")[1]) for k in result_dict})
+    parts = []
+    for k in topks:
+        for m in names:
+            key = "{}@{}".format(m, k)
+            v = result_dict[key]
+            parts.append("{}:{:<.4f}".format(key, v) if isinstance(v, (float, np.floating)) else "{}:{}".format(key, v))
+    return ",".join(parts)
+
+
+def epoch_order(n, batch_size, num_workers=0):
+    """The row order DataLoader(dataset, batch_size, shuffle=True) visits (reference BaseRunner.py:188-193), obtained
+    from the very same sampler machinery so that the global torch RNG is consumed identically."""
+    dl = DataLoader(torch.arange(n), batch_size=batch_size, shuffle=True, num_workers=0)
+    return torch.cat([b for b in dl])
+
+
+class BaseRunner(object):
+    @staticmethod
+    def parse_runner_args(parser):
+        parser.add_argument("--epoch", type=int, default=200, help="Number of epochs.")
+        parser.add_argument("--check_epoch", type=int, default=1, help="Check some tensors every check_epoch.")
+        parser.add_argument("--test_epoch", type=int, default=-1, help="Print test results every test_epoch (-1: never).")
+        parser.add_argument("--early_stop", type=int, default=10, help="Epochs of non-improving dev results before stopping.")
+        parser.add_argument("--lr", type=float, default=5e-4, help="Learning rate.")
+        parser.add_argument("--l2", type=float, default=0, help="Weight decay in optimizer.")
+        parser.add_argument("--batch_size", type=int, default=2048, help="Batch size during training.")
+        parser.add_argument("--eval_batch_size", type=int, default=2048, help="Batch size during testing.")
+        parser.add_argument("--optimizer", type=str, default="Adam", help="optimizer: SGD, Adam, Adagrad, Adadelta")
+        parser.add_argument("--num_workers", type=int, default=5, help="DataLoader workers (unused by HipRunner.fit).")
+        parser.add_argument("--pin_memory", type=int, default=0, help="pin_memory in DataLoader")
+        parser.add_argument("--topk", type=str, default="10,20", help="The number of items recommended to each user.")
+        parser.add_argument("--metric", type=str, default="NDCG, HR", help="metrics: NDCG, HR, RECALL, PRECISION")
+        return parser
+
+    @staticmethod
+    def evaluate_method(predictions, topk, metrics):
+        """predictions[:, 0] is the ground-truth score; rank = its position in the descending order of the row
+        (reference BaseRunner.py:50-92)."""
+        order = (-predictions).argsort(axis=1)
+        gt_rank = np.argwhere(order == 0)[:, 1] + 1
+        return BaseRunner.metrics_from_ranks(gt_rank, topk, metrics)
+
+    @staticmethod
+    def metrics_from_ranks(gt_rank, topk, metrics):
+        out = {}
+        for k in topk:
+            hit = gt_rank <= k
+            for m in metrics:
+                key = "{}@{}".format(m, k)
+                name = m.lower()
+                if name in ("hr", "recall"):
+                    out[key] = hit.mean()
+                elif name == "ndcg":
+                    out[key] = np.mean(hit / np.log2(gt_rank + 1))
+                elif name == "precision":
+                    out[key] = hit.sum() / (hit.shape[0] * k)
+                else:
+                    raise ValueError("Undefined evaluation metric: {}.".format(m))
+        return out
+
+    def __init__(self, args):
+        self.epoch = args.epoch
+        self.check_epoch = args.check_epoch
+        self.test_epoch = args.test_epoch
+        self.early_stop = args.early_stop
+        self.learning_rate = float(args.lr)
+        self.batch_size = args.batch_size
+        self.eval_batch_size = args.eval_batch_size
+        self.l2 = args.l2
+        self.optimizer_name = args.optimizer
+        self.num_workers = args.num_workers
+        self.pin_memory = args.pin_memory
+        self.topk = [int(x) for x in args.topk.split(",")]
+        self.metrics = [m.strip().upper() for m in args.metric.split(",")]
+        self.main_metric = "{}@{}".format(self.metrics[0], self.topk[0])
+        self.time = None
+
+    def _check_time(self, start=False):
+        if self.time is None or start:
+            self.time = [time()] * 2
+            return self.time[0]
+        last = self.time[1]
+        self.time[1] = time()
+        return self.time[1] - last
+
+    def _build_optimizer(self, model):
+        logging.info("Optimizer: " + self.optimizer_name)
+        return getattr(torch.optim, self.optimizer_name)(model.parameters(), lr=self.learning_rate, weight_decay=self.l2)
+
+    def eval_termination(self, criterion):
+        recent = criterion[-self.early_stop:]
+        if len(criterion) > self.early_stop and all(a >= b for a, b in zip(recent, recent[1:])):
+            return True
+        return len(criterion) - criterion.index(max(criterion)) > self.early_stop
+
+    def train(self, data_dict):
+        model = data_dict["train"].model
+        main_results, dev_results = [], []
+        self._check_time(start=True)
+        for epoch in range(self.epoch):
+            self._check_time()
+            gc.collect()
+            loss = self.fit(data_dict["train"], epoch=epoch + 1)
+            train_t = self._check_time()
+            dev = self.evaluate(data_dict["dev"], self.topk[:1], self.metrics)
+            dev_results.append(dev)
+            main_results.append(dev[self.main_metric])
+            line = "Epoch {:<5} loss={:<.4f} [{:<3.1f} s]    dev=({})".format(epoch + 1, loss, train_t, format_metric(dev))
+            if self.test_epoch > 0 and epoch % self.test_epoch == 0:
+                line += " test=({})".format(format_metric(self.evaluate(data_dict["test"], self.topk[:1], self.metrics)))
+            line += " [{:<.1f} s]".format(self._check_time())
+            if max(main_results) == main_results[-1]:
+                model.save_model()
+                line += " *"
+            logging.info(line)
+            if self.early_stop > 0 and self.eval_termination(main_results):
+                logging.info("Early stop at %d based on dev result." % (epoch + 1))
+                break
+        best = main_results.index(max(main_results))
+        logging.info(os.linesep + "Best Iter(dev)={:>5}\t dev=({}) [{:<.1f} s] ".format(
+            best + 1, format_metric(dev_results[best]), self.time[1] - self.time[0]))
+        model.load_model()
+
+    def fit(self, dataset, epoch=-1):
+        """The reference loop (BaseRunner.py:180-201): DataLoader batches -> predict/backward/step."""
+        model = dataset.model
+        if model.optimizer is None:
+            model.optimizer = self._build_optimizer(model)
+        dataset.actions_before_epoch()
+        model.train()
+        losses = []
+        dl = DataLoader(dataset, batch_size=self.batch_size, shuffle=True, num_workers=0, collate_fn=dataset.collate_batch)
+        for batch in dl:
+            batch = {k: (v.to(model.device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            model.optimizer.zero_grad()
+            loss = model.predict(batch)
+            loss.backward()
+            model.optimizer.step()
+            losses.append(loss.detach().cpu().data.numpy())
+        return np.mean(losses).item()
+
+    def evaluate(self, dataset, topks, metrics):
+        return self.evaluate_method(self.interface(dataset), topks, metrics)
+
+    def interface(self, dataset):
+        """[n_eval, 1 + n_items] matrix: column 0 = score of the ground-truth item, then all item scores with the
+        user's train/dev/test items masked to -inf (reference BaseRunner.py:218-258)."""
+        model = dataset.model
+        model.eval()
+        users = np.asarray(dataset.data["user_id"])
+        items = np.asarray(dataset.data["item_id"])
+        scores, targets = [], []
+        with torch.no_grad():
+            for lo in range(0, len(users), self.eval_batch_size):
+                ub = torch.from_numpy(users[lo:lo + self.eval_batch_size]).to(model.device)
+                pb = torch.from_numpy(items[lo:lo + self.eval_batch_size]).to(model.device)
+                s = model.full_predict({"user_id": ub, "pos_item": pb})
+                targets.append(s[torch.arange(len(pb), device=s.device), pb])
+                scores.append(s)
+        target = torch.cat(targets).cpu().numpy()
+        score = torch.cat(scores).cpu().numpy()
+        if model.test_all:
+            corpus = dataset.corpus
+            for row, uid in enumerate(users):
+                clicked = corpus.train_clicked_set[uid] | corpus.residual_clicked_set[uid]
+                score[row, list(clicked)] = -np.inf
+        return np.concatenate([target[:, None], score], axis=1)
+
+    def print_res(self, dataset):
+        return "(" + format_metric(self.evaluate(dataset, self.topk, self.metrics)) + ")"
+
+
+def make_hip_runner(base_runner_cls):
+    class HipRunner(base_runner_cls):
+        def fit(self, dataset, epoch=-1):
+            model = dataset.model
+            if not hasattr(model, "train_epoch") or self.optimizer_name not in ("SGD", "Adam"):
+                return base_runner_cls.fit(self, dataset, epoch)
+            dataset.actions_before_epoch()          # must happen before the shuffle draws, as in the reference
+            model.train()
+            order = epoch_order(len(dataset), self.batch_size)
+            dev = model.user_embeddings.weight.device
+            cols = [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64)[order].to(dev)
+                    for k in ("user_id", "item_id", "neg_items")]
+            losses = model.train_epoch(cols[0], cols[1], cols[2], self.batch_size, self.learning_rate, float(self.l2),
+                                       self.optimizer_name)
+            return float(np.mean(losses.cpu().numpy()))  # one sync per epoch instead of one per batch (:200)
+
+    HipRunner.__qualname__ = "HipRunner"
+    return HipRunner
+
+
+HipRunner = make_hip_runner(BaseRunner)
+
+
+def bind_runner(reference_base_runner_cls):
+    return make_hip_runner(reference_base_runner_cls)
