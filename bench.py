@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-events", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -102,7 +103,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" %
                              (args.gpus, args.gpus))
-    if args.gpus > 1:
+    if args.gpus > 1 or args.force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         from whisprrec_amd import sharded
         return sharded.bench_main(args, rank, world, local_rank)
 

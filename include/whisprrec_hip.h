@@ -150,6 +150,24 @@ int64_t wr_scatter_add_workspace_bytes(int64_t n, int64_t n_rows);
 int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_t *idx, const float *src, int64_t n,
                             int64_t padding_idx, float alpha, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* tab[sorted_rows[q], :] += alpha * sum of src[perm[q'], :] over the run of equal sorted_rows (rows ascending; the
+ * order was fixed when the exchange was planned, so the sum is reproducible).  Entries >= n_rows are skipped.
+ * Owner-side application of gradient rows received from other shards (alpha = -lr for SGD). */
+int32_t wr_apply_rows_sorted(float *tab, int64_t n_rows, int32_t D, const int32_t *sorted_rows, const int32_t *perm,
+                             const float *src, int64_t n, float alpha, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Row-sharded step (multi-GPU): the same two kernels with the user rows of this shard updated in place
+ * (SGD, l2 = 0) and the item side exchanged: `item_rows` [n_slots, D] are the item rows this rank received
+ * from their owners for this step (tp/tn/oc_item hold SLOT ids into it), `grad_slots` [n_slots, D] receives
+ * the reduced gradient row of every slot (to be returned to the owners).  The loss term and coefficient are
+ * scaled by 1/global_batch (the mean runs over all shards' triplets); loss_partial = this shard's share.
+ * --------------------------------------------------------------------------------------------------- */
+int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,
+                            const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                            const int32_t *oc_src, int64_t B, int64_t global_batch, float lr, float *grad_slots,
+                            float *loss_partial, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K6-K7  LightGCN propagation — src/models/general/LightGCN.py:134-148
  *   Y = A X for the CSR form of the normalised bipartite adjacency (the reference multiplies the dense

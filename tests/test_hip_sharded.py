@@ -1,0 +1,66 @@
+"""GPU test of the row-sharded step through RCCL with a single rank (the only multi-process-free configuration a 1-GPU
+box allows): exercises HipBackend — wr_gather_rows, wr_bprmf_shard_step (MODE 2), wr_apply_rows_sorted — and
+torch.distributed's nccl(=RCCL) all_to_all_single, against the oracle.  The multi-rank exchange logic itself is covered on
+CPU/gloo by tests/test_sharded_gloo.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+import oracle
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    yield dev
+    dist.destroy_process_group()
+
+
+def test_sharded_world1_matches_oracle(pg):
+    from whisprrec_amd.sharded import ShardedBprmf
+    dev = pg
+    rng = np.random.RandomState(11)
+    nU, nI, D, B, steps, lr = 3000, 2000, 64, 4096, 4, 0.3
+    U = (rng.standard_normal((nU, D)) * 0.3).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) * 0.3).astype(np.float32)
+    u = rng.randint(0, nU, steps * B); p = rng.randint(0, nI, steps * B); n = rng.randint(1, nI, steps * B)
+    m = ShardedBprmf(nU, nI, D, dev)
+    m.load_full(torch.from_numpy(U), torch.from_numpy(I))
+    cp = m.plan_chunk(torch.from_numpy(u).to(dev), torch.from_numpy(p).to(dev), torch.from_numpy(n).to(dev), B)
+    losses = m.global_losses(m.run_chunk(cp, lr)).cpu().numpy()
+    Uf, If = m.gather_full()
+    Uo, Io = U.copy(), I.copy()
+    ref = [oracle.bprmf_step_sgd(Uo, Io, u[k * B:(k + 1) * B], p[k * B:(k + 1) * B], n[k * B:(k + 1) * B], lr, 0.0)
+           for k in range(steps)]
+    assert rel_err(losses, np.asarray(ref)) < 1e-5
+    assert rel_err(Uf.cpu().numpy(), Uo) < 1e-5
+    assert rel_err(If.cpu().numpy(), Io) < 1e-5
+
+
+def test_shard_step_global_batch_scaling(pg):
+    """coefficients and loss share are scaled by 1/global_batch, not 1/local batch"""
+    from whisprrec_amd.sharded import ShardedBprmf
+    dev = pg
+    rng = np.random.RandomState(12)
+    nU, nI, D, B = 500, 400, 32, 1024
+    U = (rng.standard_normal((nU, D)) * 0.3).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) * 0.3).astype(np.float32)
+    u = rng.randint(0, nU, B); p = rng.randint(0, nI, B); n = rng.randint(1, nI, B)
+    m = ShardedBprmf(nU, nI, D, dev)
+    m.load_full(torch.from_numpy(U), torch.from_numpy(I))
+    cp = m.plan_chunk(torch.from_numpy(u).to(dev), torch.from_numpy(p).to(dev), torch.from_numpy(n).to(dev), B)
+    losses = m.run_chunk(cp, 0.4, global_batch=4 * B).cpu().numpy()
+    Uo, Io = U.copy(), I.copy()
+    lo = oracle.bprmf_step_sgd(Uo, Io, u, p, n, 0.4 / 4, 0.0)   # grads scale by 1/4 <=> lr/4
+    assert abs(losses[0] - lo / 4) / (lo / 4) < 1e-5
+    Uf, If = m.gather_full()
+    assert rel_err(Uf.cpu().numpy(), Uo) < 1e-5 and rel_err(If.cpu().numpy(), Io) < 1e-5

@@ -38,6 +38,9 @@ SIGNATURES = {
     "wr_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "wr_scatter_add_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "wr_scatter_add_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_i64, c_vp]),
+    "wr_apply_rows_sorted": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "wr_bprmf_shard_step": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32,
+                                    c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_spmm_csr": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "wr_axpy": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_i32, c_vp]),
     "wr_embloss_sumsq": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),

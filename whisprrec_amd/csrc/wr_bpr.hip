@@ -70,6 +70,8 @@ __global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__rest
 
 // ----------------------------------------------------------------------------------------------- user phase
 // MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.
+// MODE 2 (row-sharded step): user rows applied in place, item gradients emitted (the item "table" is the buffer of
+// rows received from their owners and gradI the buffer of gradient rows sent back).
 template <int T, int NV, bool FULL, int MODE>
 __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                                                             float *__restrict__ Z, float *__restrict__ partials,
                                                             float *__restrict__ gradU, int *__restrict__ stampU,
                                                             float *__restrict__ gradI, int *__restrict__ stampI,
-                                                            int step_id, int flags) {
+                                                            int step_id, int flags, float denom) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                 const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
                 const float sn = team_sum<T>(dot_partial<NV>(ur, nr));
                 float term, c;
-                bpr_terms(sp, sn, (float)B, term, c);
+                bpr_terms(sp, sn, denom, term, c);
                 term_acc += term;
                 Row<NV> z;
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
                 if (p_shared || n_shared) { if (wt) store_row_wt<T, NV, FULL>(Z, t, D, lane, z); else store_row<T, NV, FULL>(Z, t, D, lane, z); }
                 t = tnext;
             } while (more);
-            if (MODE == 0) {
+            if (MODE != 1) {
                 Row<NV> w;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {  // torch.optim.SGD: g' = g + l2 w ; w -= lr g'
@@ -320,7 +322,8 @@ template <int MODE>
 static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
                            const int32_t *oc_item, const int32_t *oc_src, int64_t B, float lr, float l2, float *gradU,
                            float *gradI, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id, float *loss_out,
-                           void *workspace, hipStream_t stream, void *const *events = nullptr) {
+                           void *workspace, hipStream_t stream, void *const *events = nullptr, float denom = 0.f) {
+    if (denom <= 0.f) denom = (float)B;  // single-device step: mean over this batch
     const StepWs w = carve_step_ws(workspace, B, D);
     const dim3 block(kBlock);
     const dim3 gridA((unsigned)n_blocks_for(B, D));
@@ -328,14 +331,14 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[0]), stream));
 #define WR_CALL_USER(T_, NV_, FULL_)                                                                                  \
     hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE>), gridA, block, 0, stream, U, I, D, tu, tp, tn, (int)B, \
-                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, g_variant)
+                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, g_variant, denom)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
     WR_LAUNCH_CHECK("bprmf_user_phase");
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[1]), stream));
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
     hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
-                       (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)w.n_partials, (float)B, \
+                       (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)w.n_partials, denom,    \
                        loss_out)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
@@ -452,6 +455,24 @@ int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item
     return launch_step<1>(const_cast<float *>(user_tab), const_cast<float *>(item_tab), D, tu, tp, tn, oc_item, oc_src, B,
                           0.f, 0.f, grad_u, grad_i, stamp_u, stamp_i, step_id, loss_out, workspace,
                           reinterpret_cast<hipStream_t>(stream_));
+}
+
+int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,
+                            const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                            const int32_t *oc_src, int64_t B, int64_t global_batch, float lr, float *grad_slots,
+                            float *loss_partial, void *workspace, int64_t workspace_bytes, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_shard, n_user_rows, D, "user_shard")) != WR_OK) return rc;
+    if ((rc = check_table(item_rows, n_slots, D, "item_rows")) != WR_OK) return rc;
+    if ((rc = check_table(grad_slots, n_slots, D, "grad_slots")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, B)) != WR_OK) return rc;
+    WR_REQUIRE(global_batch >= B, WR_E_SHAPE, "global_batch %lld < local batch %lld", (long long)global_batch, (long long)B);
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
+               "wr_bprmf_shard_step: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
+    // MODE 2 never writes item_rows; the const_cast only serves the shared kernel signature.
+    return launch_step<2>(user_shard, const_cast<float *>(item_rows), D, tu, tp, tn, oc_item, oc_src, B, lr, 0.f, nullptr,
+                          grad_slots, nullptr, nullptr, 0, loss_partial, workspace, reinterpret_cast<hipStream_t>(stream_),
+                          nullptr, (float)global_batch);
 }
 
 }  // extern "C"

@@ -319,6 +319,27 @@ int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_
     return WR_OK;
 }
 
+int32_t wr_apply_rows_sorted(float *tab, int64_t n_rows, int32_t D, const int32_t *sorted_rows, const int32_t *perm,
+                             const float *src, int64_t n, float alpha, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    WR_REQUIRE(n >= 0 && n < (int64_t(1) << 31), WR_E_SHAPE, "n out of range");
+    if (n == 0) return WR_OK;
+    WR_REQUIRE(sorted_rows && perm && src, WR_E_NULL, "sorted_rows/perm/src must not be NULL");
+    WR_REQUIRE(aligned16(src), WR_E_ALIGN, "src is not 16-byte aligned");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int tpb = teams_per_block_for(D);
+    const unsigned grid = (unsigned)((n + tpb - 1) / tpb);
+#define WR_CALL_AS(T_, NV_, FULL_)                                                                                   \
+    hipLaunchKernelGGL((scatter_add_sorted_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, tab, D,      \
+                       (uint32_t)n_rows, reinterpret_cast<const uint32_t *>(sorted_rows),                            \
+                       reinterpret_cast<const uint32_t *>(perm), n, src, alpha)
+    WR_DISPATCH_D(D, WR_CALL_AS);
+#undef WR_CALL_AS
+    WR_LAUNCH_CHECK("scatter_add_sorted_kernel");
+    return WR_OK;
+}
+
 int32_t wr_sgd_decay_untouched(float *tab, int64_t n_rows, int32_t D, const int32_t *stamp, int32_t step_id, float lr,
                                float l2, void *stream_) {
     int32_t rc;
