@@ -7,6 +7,7 @@ Layout:
   host.py      host-side mirror of the reference's BaseModel / GeneralModel / Dataset contract
   bprmf.py     BPRMF drop-in model (reference src/models/general/BPRMF.py)
   lightgcn.py  LightGCN drop-in model (reference src/models/general/LightGCN.py)
+  sasrec.py    SASRec with its item-embedding gather/scatter on the HIP kernels (reference src/models/sequential/SASRec.py)
   runner.py    HipRunner: BaseRunner-compatible runner that drives the fused step
   sharded.py   row-sharded multi-GPU step (RCCL all-to-all over xGMI)
 """

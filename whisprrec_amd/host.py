@@ -165,3 +165,34 @@ class GeneralModel(BaseModel):
         def actions_before_epoch(self):
             self.data["neg_items"] = sample_negatives(self.data["user_id"], self.corpus.n_items,
                                                       self.corpus.train_clicked_set, self.model.num_neg)
+
+
+class SequentialModel(GeneralModel):
+    """History-aware variant (reference src/models/BaseModel.py:181-213): ``--history_max``; samples with an empty
+    history are dropped; each feed dict carries the user's last ``history_max`` (item, time) pairs before the target."""
+    reader = "SeqReader"
+
+    @staticmethod
+    def parse_model_args(parser):
+        parser.add_argument("--history_max", type=int, default=20, help="Maximum length of history.")
+        return GeneralModel.parse_model_args(parser)
+
+    def __init__(self, args, corpus):
+        super().__init__(args, corpus)
+        self.history_max = args.history_max
+
+    class Dataset(GeneralModel.Dataset):
+        def __init__(self, model, corpus, phase):
+            super().__init__(model, corpus, phase)
+            keep = np.asarray(self.data["position"]) > 0
+            self.data = {k: np.asarray(v)[keep] for k, v in self.data.items()}
+
+        def _get_feed_dict(self, index):
+            fd = super()._get_feed_dict(index)
+            seq = self.corpus.user_his[fd["user_id"]][:self.data["position"][index]]
+            if self.model.history_max > 0:
+                seq = seq[-self.model.history_max:]
+            fd["history_items"] = np.array([x[0] for x in seq])
+            fd["history_times"] = np.array([x[1] for x in seq])
+            fd["lengths"] = len(fd["history_items"])
+            return fd

@@ -1,0 +1,212 @@
+"""LightGCN on MI355X behind the reference's model contract (reference src/models/general/LightGCN.py).
+
+Same surface as the reference class: flags ``--embedding_size --gcn_layers --reg_weight`` (LightGCN.py:27-32),
+``state_dict`` keys ``user_embedding.weight`` / ``item_embedding.weight``, xavier-uniform init (:52),
+``predict(batch) -> loss`` of shape (1,) (:175), ``full_predict`` (:177-187).
+
+What changes underneath:
+  * the normalised adjacency D^-1/2 A D^-1/2 (:54-121) is kept in CSR on the device (the reference multiplies its
+    DENSE N x N form at run time, :120,139) and built with vectorised NumPy instead of DOK/LIL loops;
+  * propagation E_{l+1} = A E_l and the layer mean (:138-143) are ``wr_spmm_csr`` calls with the running sum fused;
+  * BPR on the propagated rows uses the same forward / gradient kernels as BPRMF; the backward of the propagation is the
+    same SpMM again (A is symmetric);
+  * EmbLoss (src/utils/loss.py:94-98, un-squared Frobenius norms) = ``wr_embloss_sumsq`` + row gather / sorted scatter.
+Gradients come out dense (like autograd's), so any ``torch.optim`` works; SGD and Adam (the default) run in the HIP
+dense optimizers.  No CPU path.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip_ops, host
+
+
+def build_norm_adj_csr(n_users, n_items, train_clicked_set):
+    """CSR of the symmetric normalised bipartite adjacency over N = n_users + n_items nodes.
+
+    Restates build_adjmat + csr2tensor (LightGCN.py:54-76, 79-121): A[u, n_users+i] = A[n_users+i, u] = 1 for every
+    train pair, d = rowsum + 1e-10 (:89), value = d_r^-1/2 * 1 * d_c^-1/2 in float64, rounded to fp32 (:109).
+    Columns ascend inside each row.  Returns (row_ptr int64 [N+1], col int32 [nnz], val float32 [nnz])."""
+    N = n_users + n_items
+    us, its = [], []
+    for uu, items in train_clicked_set.items():
+        if len(items):
+            arr = np.fromiter(items, dtype=np.int64, count=len(items))
+            us.append(np.full(arr.shape, uu, dtype=np.int64))
+            its.append(arr)
+    if us:
+        uu = np.concatenate(us)
+        ii = np.concatenate(its) + n_users
+    else:
+        uu = ii = np.zeros(0, np.int64)
+    rows = np.concatenate([uu, ii])
+    cols = np.concatenate([ii, uu])
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    deg = np.bincount(rows, minlength=N).astype(np.float64)
+    dis = np.power(deg + 1e-10, -0.5)
+    val = (dis[rows] * 1.0 * dis[cols]).astype(np.float32)
+    row_ptr = np.zeros(N + 1, np.int64)
+    np.cumsum(np.bincount(rows, minlength=N), out=row_ptr[1:])
+    return row_ptr, cols.astype(np.int32), val
+
+
+class DenseHipOptimizer:
+    """zero_grad/step over dense ``.grad`` tensors with the HIP dense optimizers (torch.optim.SGD / Adam semantics,
+    reference BaseRunner.py:120-124)."""
+
+    def __init__(self, params, name, lr, l2):
+        if name not in ("SGD", "Adam"):
+            raise ValueError(name)
+        self.params, self.name, self.lr, self.l2 = list(params), name, float(lr), float(l2)
+        self.t = 0
+        self.state = {}
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        for p in self.params:
+            if p.grad is None:
+                continue
+            g = p.grad.contiguous()
+            if self.name == "SGD":
+                hip_ops.sgd_dense(p.data, g, self.lr, self.l2)
+            else:
+                if p not in self.state:
+                    self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+                m, v = self.state[p]
+                hip_ops.adam_dense(p.data, m, v, g, self.t, self.lr, self.l2)
+
+
+class _LightGcnLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, user_w, item_w, model, u, p, n):
+        ctx.model, ctx.idx = model, (u, p, n)
+        loss, ctx.saved = model._forward_loss(u, p, n)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gE = ctx.model._backward(ctx.idx, ctx.saved)
+        nU = ctx.model.n_users
+        s = grad_out.reshape(-1)[0]
+        return gE[:nU] * s, gE[nU:] * s, None, None, None, None
+
+
+def make_lightgcn(general_model_cls):
+    class LightGCN(general_model_cls):
+        reader = "BaseReader"
+        runner = "BaseRunner"
+        extra_log_args = ["embedding_size", "gcn_layers", "reg_weight"]
+
+        @staticmethod
+        def parse_model_args(parser):
+            parser.add_argument("--embedding_size", type=int, default=64, help="Size of embedding vectors.")
+            parser.add_argument("--gcn_layers", type=int, default=2, help="Number of LightGCN layers.")
+            parser.add_argument("--reg_weight", type=float, default=1e-05, help="The L2 regularization weight.")
+            return general_model_cls.parse_model_args(parser)
+
+        def __init__(self, args, corpus):
+            super().__init__(args, corpus)
+            self.emb_size = args.embedding_size
+            if self.emb_size % 4 != 0:
+                raise ValueError("embedding_size must be a multiple of 4 for the HIP kernels (got %d)" % self.emb_size)
+            self.gcn_layers = args.gcn_layers
+            self.n_users, self.n_items = int(corpus.n_users), int(corpus.n_items)
+            self.reg_weight = float(args.reg_weight)
+            self.user_embedding = nn.Embedding(self.n_users, self.emb_size)
+            self.item_embedding = nn.Embedding(self.n_items, self.emb_size)
+            rp, col, val = build_norm_adj_csr(self.n_users, self.n_items, corpus.train_clicked_set)
+            # plain attributes like the reference's norm_adj (not buffers: absent from state_dict, LightGCN.py:49-51)
+            self._csr_host = (torch.from_numpy(rp), torch.from_numpy(col), torch.from_numpy(val))
+            self._csr_dev = None
+            nn.init.xavier_uniform_(self.user_embedding.weight.data)   # LightGCN.py:52, init.py:32-48
+            nn.init.xavier_uniform_(self.item_embedding.weight.data)
+            name = getattr(args, "optimizer", None)
+            if name in ("SGD", "Adam") and hasattr(args, "lr"):
+                self.optimizer = DenseHipOptimizer([self.user_embedding.weight, self.item_embedding.weight], name, args.lr,
+                                                   getattr(args, "l2", 0.0))
+
+        # ------------------------------------------------------------------ device state
+        def _csr(self):
+            dev = self.user_embedding.weight.device
+            if self._csr_dev is None or self._csr_dev[0].device != dev:
+                self._csr_dev = tuple(t.to(dev) for t in self._csr_host)
+            return self._csr_dev
+
+        def _propagate(self, E0):
+            """mean over layers of A^l E0, l = 0..L (LightGCN.py:134-143)."""
+            rp, col, val = self._csr()
+            acc = E0.clone()
+            cur = E0
+            for _ in range(self.gcn_layers):
+                cur = hip_ops.spmm_csr(rp, col, val, cur, acc=acc)
+            out = torch.empty_like(acc)
+            hip_ops.axpy(out, acc, 1.0 / (self.gcn_layers + 1), overwrite=True)
+            return out
+
+        def forward(self):
+            E0 = torch.cat([self.user_embedding.weight.data, self.item_embedding.weight.data], dim=0)
+            allE = self._propagate(E0)
+            return allE[:self.n_users], allE[self.n_users:]
+
+        # ------------------------------------------------------------------ loss / gradients
+        def _forward_loss(self, u, p, n):
+            U0, I0 = self.user_embedding.weight.data, self.item_embedding.weight.data
+            E0 = torch.cat([U0, I0], dim=0)
+            allE = self._propagate(E0)
+            Ua, Ia = allE[:self.n_users], allE[self.n_users:]
+            mf = hip_ops.bpr_fwd(Ua, Ia, u, p, n, scores=False)["loss"]
+            sq = hip_ops.embloss_sumsq(U0, I0, u, p, n)
+            norms = torch.sqrt(sq)                                     # ||U[u]||_F, ||I[p]||_F, ||I[n]||_F
+            reg = norms.sum() / u.numel()
+            loss = (mf + self.reg_weight * reg).reshape(1)             # the reference returns shape (1,) (loss.py:94)
+            return loss, (allE, norms)
+
+        def _backward(self, idx, saved):
+            u, p, n = idx
+            allE, norms = saved
+            nU, D, B = self.n_users, self.emb_size, u.numel()
+            Ua, Ia = allE[:nU].contiguous(), allE[nU:].contiguous()
+            # gradient w.r.t. the propagated tables: BPRMF gradient kernels on (Ua, Ia)
+            tabs = hip_ops.BprmfTables(Ua, Ia)
+            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items)
+            gOut = torch.zeros(nU + self.n_items, D, device=allE.device)
+            tabs.grads(plan, 0, gOut[:nU], gOut[nU:])
+            # back through the propagation: A is symmetric, d(mean_l A^l E0) = mean_l A^l gOut
+            gE = self._propagate(gOut)
+            # EmbLoss: d/dx ||X||_F = x/||X||_F per gathered row, duplicates add up (loss.py:94-98)
+            U0, I0 = self.user_embedding.weight.data, self.item_embedding.weight.data
+            nv = norms.tolist()
+            for tab, g, ix, nrm in ((U0, gE[:nU], u, nv[0]), (I0, gE[nU:], p, nv[1]), (I0, gE[nU:], n, nv[2])):
+                if nrm > 0.0:
+                    hip_ops.scatter_add_rows(g, ix, hip_ops.gather_rows(tab, ix), alpha=self.reg_weight / (B * nrm))
+            return gE
+
+        def _batch(self, feed_dict):
+            dev = self.user_embedding.weight.device
+            return tuple(feed_dict[k].to(dev).reshape(-1) for k in ("user_id", "pos_item", "neg_items"))
+
+        def predict(self, feed_dict):
+            u, p, n = self._batch(feed_dict)
+            return _LightGcnLoss.apply(self.user_embedding.weight, self.item_embedding.weight, self, u, p, n)
+
+        def full_predict(self, feed_dict):
+            dev = self.user_embedding.weight.device
+            Ua, Ia = self.forward()
+            user_e = hip_ops.gather_rows(Ua.contiguous(), feed_dict["user_id"].to(dev))
+            return torch.matmul(user_e, Ia.t())
+
+    LightGCN.__qualname__ = "LightGCN"
+    return LightGCN
+
+
+LightGCN = make_lightgcn(host.GeneralModel)
+
+
+def bind(reference_general_model_cls):
+    return make_lightgcn(reference_general_model_cls)
