@@ -152,10 +152,10 @@ def main():
         nxt = build_plan(chunks[0][0], chunks[0][1], 0)
         for i, (fs, c) in enumerate(chunks):
             plan, ready = nxt
-            if i + 1 < len(chunks):
-                nxt = build_plan(chunks[i + 1][0], chunks[i + 1][1], (i + 1) % 2)
             main_stream.wait_event(ready)
-            out.append((plan, tabs.run_sgd(plan, 0, c, args.lr)))
+            out.append((plan, tabs.run_sgd(plan, 0, c, args.lr)))      # enqueue this chunk's steps first ...
+            if i + 1 < len(chunks):                                     # ... then build the next plan beside them
+                nxt = build_plan(chunks[i + 1][0], chunks[i + 1][1], (i + 1) % 2)
         return out
 
     run_range(0, W)

@@ -103,6 +103,41 @@ def test_plan_is_a_stable_sort(ops, dev, dtype):
     _check_plan(plan, u, p, n, B)
 
 
+@pytest.mark.parametrize("shape", [(50, 70, 1000, 128), (1000, 3000, 20000, 4096), (1 << 20, 1 << 20, 3 * 65536 + 777, 65536),
+                                   (943, 1574, 66016, 2048), (5, 7, 300, 64)])
+def test_fast_and_generic_builders_agree_bitwise(ops, dev, shape):
+    """the hand-written bucket/LDS-sort builder must emit exactly the generic radix-sort builder's arrays"""
+    nU, nI, N, B = shape
+    rng = np.random.RandomState(N)
+    u = rng.randint(0, nU, N).astype(np.int32); p = rng.randint(0, nI, N).astype(np.int32); n = rng.randint(0, nI, N).astype(np.int32)
+    a = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, keep_orig=True, builder="generic")
+    try:
+        b = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, keep_orig=True, builder="fast")
+    except Exception as e:  # overflow is legal for tiny id ranges: then "auto" must fall back
+        assert "overflow" in str(e)
+        b = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, keep_orig=True, builder="auto")
+        assert b.builder == "generic"
+        return
+    assert a.builder == "generic" and b.builder == "fast"
+    for name in ("tu", "tp", "tn", "torig", "oc_item", "oc_src"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_fast_builder_overflow_falls_back(ops, dev):
+    """all triplets on one user / one item: every pair lands in one bucket -> overflow -> generic builder"""
+    N, B = 8192, 4096
+    u = np.zeros(N, np.int32); p = np.full(N, 3, np.int32); n = np.full(N, 5, np.int32)
+    plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, 100000, 100000, keep_orig=True, builder="auto")
+    assert plan.builder == "generic"
+    _check_plan(plan, u, p, n, B)
+
+
+def test_fast_builder_rejects_out_of_range(ops, dev):
+    u = np.array([0, 1, 5] * 100, np.int32); p = np.array([0, 1, 2] * 100, np.int32); n = np.array([1, 1, 1] * 100, np.int32)
+    with pytest.raises(IndexError):
+        ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), 64, 5, 3, builder="auto")
+
+
 def test_plan_wide_keys(ops, dev):
     """composite (batch,row) keys beyond 32 bits take the 64-bit path"""
     rng = np.random.RandomState(8)

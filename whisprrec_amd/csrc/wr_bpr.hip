@@ -62,8 +62,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict
 __global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__restrict__ partials, int n, float denom,
                                                               float *__restrict__ out) {
     __shared__ float scratch[kBlock / 64];
-    float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += kBlock) a += partials[i];
+    const float a = strided_partial_sum(partials, n);
     const float s = block_sum(a, scratch);
     if (threadIdx.x == 0) out[0] = s / denom;
 }
@@ -187,9 +186,10 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             const float *__restrict__ Z, float lr, float l2,
                                                             float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
                                                             const float *__restrict__ partials, int n_partials,
-                                                            float loss_denom, float *__restrict__ loss_out) {
+                                                            float loss_denom, float *__restrict__ loss_out, int flags) {
     __shared__ float scratch[kBlock / 64];
     __shared__ int heads[kBlock];
+    if (flags & 4) return;  // experiment: fixed cost of the launch alone
     __shared__ int item_tile[kBlock + 8];  // oc_item of this tile plus up to 8 entries beyond it
     __shared__ int src_tile[kBlock + 8];
     __shared__ int n_heads;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
         }
     }
     __syncthreads();
-    const int nh = n_heads;
+    const int nh = (flags & 2) ? 0 : n_heads;  // experiment: scan only
     // 2) one TEAM per run: the row and the first stashed contributions are requested together (second round
     //    trip); contributions are summed in sorted (fixed) order and the row is rewritten once.
     for (int h = threadIdx.x / T; h < nh; h += TEAMS) {
@@ -278,8 +278,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
         }
     }
     if (blockIdx.x == 0 && loss_out != nullptr) {  // uniform per block: fold the user phase's partials
-        float a = 0.f;
-        for (int i = threadIdx.x; i < n_partials; i += kBlock) a += partials[i];
+        const float a = strided_partial_sum(partials, n_partials);
         const float s = block_sum(a, scratch);
         if (threadIdx.x == 0) loss_out[0] = s / loss_denom;
     }
@@ -339,7 +338,7 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
     hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
                        (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)w.n_partials, denom,    \
-                       loss_out)
+                       loss_out, g_variant)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
     WR_LAUNCH_CHECK("bprmf_item_phase");

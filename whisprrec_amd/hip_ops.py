@@ -103,7 +103,9 @@ class BatchPlan:
     ``u, p, n`` are the epoch's triplets in batch order (int64 as in the reference, or int32); batch k is
     ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201)."""
 
-    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan"):
+    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="generic"):
+        """builder: "generic" = radix-sort builder (default); "auto" = hand-written bucket/LDS-sort builder when applicable,
+        generic otherwise or when a bucket overflowed (skewed ids); "fast" forces the hand-written one (tests)."""
         L = abi.lib()
         if u.dtype not in (torch.int64, torch.int32):
             raise TypeError("indices must be int64 or int32")
@@ -122,14 +124,34 @@ class BatchPlan:
         self.tu, self.tp, self.tn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
         self.torig = torch.empty(N, **i32) if keep_orig else None
         self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
-        self.err = torch.zeros(1, **i32)
-        nbytes = abi.check_size(L.wr_bprmf_plan_workspace_bytes(N, self.batch_size, self.n_users, self.n_items),
-                                "wr_bprmf_plan_workspace_bytes")
-        ws = workspace(dev, ws_tag).get(nbytes)  # distinct tags allow plan builds in flight on different streams
-        fn = L.wr_bprmf_plan_build_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_i32
-        abi.check(fn(_p(u), _p(p), _p(n), N, self.batch_size, self.n_users, self.n_items, _p(self.tu), _p(self.tp),
-                     _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(),
-                     _stream()), "wr_bprmf_plan_build")
+        self.flags = torch.zeros(2, **i32)      # [0] index out of range, [1] fast-builder bucket overflow
+        self.err = self.flags[:1]
+        self.builder = None
+        args = (N, self.batch_size, self.n_users, self.n_items)
+        if builder in ("auto", "fast"):
+            nbytes = abi.check_size(L.wr_bprmf_plan_fast_workspace_bytes(*args), "wr_bprmf_plan_fast_workspace_bytes")
+            if nbytes > 0:
+                ws = workspace(dev, ws_tag + "_fast").get(nbytes)
+                fn = L.wr_bprmf_plan_build_fast_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_i32
+                abi.check(fn(_p(u), _p(p), _p(n), *args, _p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig),
+                             _p(self.oc_item), _p(self.oc_src), _p(self.flags), _p(ws), ws.numel(), _stream()),
+                          "wr_bprmf_plan_build_fast")
+                if int(self.flags[1].item()) == 0:   # one sync of the building stream per chunk of batches
+                    self.builder = "fast"
+                elif builder == "fast":
+                    raise abi.WhisprRecHipError("fast plan builder: bucket overflow (skewed ids)")
+                else:
+                    self.flags.zero_()
+            elif builder == "fast":
+                raise abi.WhisprRecHipError("fast plan builder not applicable to this batch size")
+        if self.builder is None:
+            nbytes = abi.check_size(L.wr_bprmf_plan_workspace_bytes(*args), "wr_bprmf_plan_workspace_bytes")
+            ws = workspace(dev, ws_tag).get(nbytes)  # distinct tags allow plan builds in flight on different streams
+            fn = L.wr_bprmf_plan_build_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_i32
+            abi.check(fn(_p(u), _p(p), _p(n), *args, _p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig),
+                         _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(), _stream()),
+                      "wr_bprmf_plan_build")
+            self.builder = "generic"
         if validate:
             self.validate()
 
