@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--items", type=int, default=1_000_000)
@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-events", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--plan-builder", default="auto", choices=["auto", "generic", "fast"])
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even with one rank (testing)")
     return ap.parse_args()
 
@@ -133,7 +134,7 @@ def main():
         lo = first_step * B
         with torch.cuda.stream(plan_stream):
             plan = hip_ops.BatchPlan(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B, args.users, args.items,
-                                     validate=False, ws_tag="plan%d" % tag)
+                                     validate=False, ws_tag="plan%d" % tag, builder=args.plan_builder)
             ready = torch.cuda.Event()
             ready.record(plan_stream)
         return plan, ready
@@ -227,6 +228,15 @@ def main():
                     "uniq_users_per_step": uniq_u, "uniq_items_per_step": uniq_i,
                     "single_occurrence_items_per_step": single_i}
 
+    if roofline is not None:
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, separate passes: scripts/pmc_passes.sh); only valid for the configuration it was collected on.
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_configs1.json")
+        if os.path.exists(pmc) and (B, D, args.users, args.items, args.zipf) == (65536, 64, 1_000_000, 1_000_000, 0.0):
+            for k, v in json.load(open(pmc)).items():
+                if roofline["kernel"].split("<")[0] in k:
+                    roofline["traffic"] = v["hbm_bytes"]
+                    roofline["traffic_source"] = "profiles/r01_pmc_traffic_configs1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": 1, "steps": K,
            "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",

@@ -132,6 +132,22 @@ def test_fast_builder_overflow_falls_back(ops, dev):
     _check_plan(plan, u, p, n, B)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_auto_builder_on_skewed_ids(ops, dev, seed):
+    """power-law users and items, a short last batch, hot rows: whichever builder "auto" ends up with, the plan must be
+    the stable sort (memory safety of the fast builder after a bucket overflow is part of what this exercises)"""
+    rng = np.random.RandomState(seed)
+    nU, nI, B = [(50000, 80000, 4096), (1 << 20, 1 << 20, 16384), (3000, 100, 2048), (200000, 200000, 8192)][seed]
+    N = 5 * B + 123
+    u = np.minimum((rng.pareto(1.1, N) * 20).astype(np.int64), nU - 1).astype(np.int32)
+    p = np.minimum((rng.pareto(0.9, N) * 5).astype(np.int64), nI - 1).astype(np.int32)
+    n = rng.randint(1, nI, N).astype(np.int32)
+    n[::7] = 1
+    plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, keep_orig=True, builder="auto")
+    assert plan.builder in ("fast", "generic")
+    _check_plan(plan, u, p, n, B)
+
+
 def test_fast_builder_rejects_out_of_range(ops, dev):
     u = np.array([0, 1, 5] * 100, np.int32); p = np.array([0, 1, 2] * 100, np.int32); n = np.array([1, 1, 1] * 100, np.int32)
     with pytest.raises(IndexError):

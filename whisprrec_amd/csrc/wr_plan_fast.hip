@@ -1,4 +1,4 @@
-// wr_plan_fast.hip — hand-written batch-plan builder: bucket scatter + per-bucket LDS bitonic sort.
+// wr_plan_fast.hip — hand-written batch-plan builder: bucket scatter + per-bucket LDS counting sort.
 //
 // Produces EXACTLY the arrays of the generic builder (wr_plan.hip, radix sort over composite keys): triplets of each
 // batch stably sorted by user, item occurrences sorted by (item, positive-before-negative, sorted triplet index), bit
@@ -8,10 +8,13 @@
 //
 // Why: the generic radix sort moves every (key,value) pair 4x through HBM at ~2 TB/s; here every pair is written
 // once into a (batch, row-range) bucket and sorted inside LDS.
-//   F1 user scatter : (user<<32 | original index) appended to bucket (batch, user >> shift_u)   [atomic slot counter]
-//   F2 user sort    : one workgroup per bucket: LDS bitonic sort, writes tu/tp/tn/torig at the bucket's prefix, and
-//                     appends the two item occurrences (item<<32 | side<<31 | sorted index) to the item buckets
-//   F3 item sort    : one workgroup per bucket: LDS bitonic sort, writes oc_item/oc_src, flags shared rows in tp/tn
+//   F1 user scatter : tiles of 4096 triplets; (user<<32 | original index) appended to bucket (batch, user >> shift_u);
+//                     ranks inside a tile from LDS atomics, ONE global atomic per (tile, bucket) reserves the range
+//   F2 user sort    : one workgroup per bucket: LDS counting sort on the low row bits + insertion sort of the (short)
+//                     runs of equal rows; writes tu/tp/tn/torig at the bucket's prefix
+//   F3 item scatter : same tiling over the batch's [positives | negatives] occurrences:
+//                     (item<<32 | side<<31 | sorted index) appended to bucket (batch, item >> shift_i)
+//   F4 item sort    : like F2; writes oc_item/oc_src, flags rows with several occurrences in tp/tn
 // Buckets have a fixed capacity (2x the mean + 64); if any bucket overflows (skewed ids) flags[1] is set and the
 // caller must rebuild with the generic builder — never a wrong plan.  Ties are impossible (composites are unique), so
 // the unstable bucket placement does not leak into the result.
@@ -20,7 +23,7 @@
 namespace wr {
 
 constexpr int kBuckets = 256;    // row-range buckets per batch
-constexpr int kMaxCap = 4096;    // largest bucket an LDS sort handles here (32 KiB of 8-byte composites)
+constexpr int kMaxCap = 4096;    // largest bucket handled in LDS (2 x 32 KiB of 8-byte composites + counters)
 
 struct FastLayout {
     unsigned user_bits, item_bits, shift_u, shift_i;
@@ -46,6 +49,7 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
     const int64_t cu = 2 * ((B + kBuckets - 1) / kBuckets) + 64;
     const int64_t ci = 2 * ((2 * B + kBuckets - 1) / kBuckets) + 64;
     if (cu > kMaxCap || ci > kMaxCap) return false;
+    if (L.shift_u > 12 || L.shift_i > 12) return false;  // 1 << shift LDS counters per bucket: tables up to 2^20 rows
     L.cap_u = (int)cu;
     L.cap_i = (int)ci;
     L.cnt_bytes = align_up(2 * L.nb * kBuckets * 4, 256);
@@ -55,41 +59,92 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
     return true;
 }
 
-template <typename Idx>
-__global__ __launch_bounds__(kBlock) void fast_user_scatter(const Idx *__restrict__ u, int64_t n, int64_t B, int64_t n_users,
-                                                             unsigned shift_u, int cap_u, int *__restrict__ cnt_u,
-                                                             unsigned long long *__restrict__ ubuf, int *__restrict__ flags) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    int64_t uu = (int64_t)u[i];
-    if (uu < 0 || uu >= n_users) {
-        flags[0] = 1;
-        uu = 0;
-    }
-    const int64_t b = i / B;
-    const int64_t bucket = b * kBuckets + (uu >> shift_u);
-    const int slot = atomicAdd(&cnt_u[bucket], 1);
-    if (slot < cap_u) ubuf[bucket * cap_u + slot] = ((unsigned long long)uu << 32) | (unsigned long long)(uint32_t)i;
-    else flags[1] = 1;
-}
+constexpr int kTile = 4096;       // elements of one batch handled by one scatter workgroup
+constexpr int kMaxGroup = 32;     // longest run of equal rows a single thread orders by insertion (else: overflow)
 
-// Ascending bitonic sort of n2 (power of two) 64-bit keys in LDS by the whole workgroup.
-__device__ __forceinline__ void bitonic_sort_lds(unsigned long long *a, int n2) {
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (n2 >> 1); t += kBlock) {
-                const int i = ((t / j) * 2 * j) + (t % j);
-                const int l = i + j;
-                const unsigned long long x = a[i], y = a[l];
-                const bool up = (i & k) == 0;
-                if ((x > y) == up) {
-                    a[i] = y;
-                    a[l] = x;
-                }
-            }
-            __syncthreads();
+// Reserve bucket slots for a tile: ranks inside the tile come from LDS atomics, one global atomic per non-empty
+// (tile, bucket) reserves the range.  Placement order inside a bucket is arbitrary; the bucket sort fixes it.
+template <int PER_THREAD, typename KeyFn>
+__device__ __forceinline__ void tile_scatter(int n_local, int *__restrict__ cnt_global, unsigned long long *__restrict__ buf,
+                                             int cap, int *__restrict__ flags, KeyFn key_of) {
+    __shared__ int hist[kBuckets];
+    __shared__ int base[kBuckets];
+    for (int j = threadIdx.x; j < kBuckets; j += kBlock) hist[j] = 0;
+    __syncthreads();
+    unsigned long long key[PER_THREAD];
+    int bucket[PER_THREAD], rank[PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int e = threadIdx.x + k * kBlock;
+        bucket[k] = -1;
+        if (e < n_local) {
+            key[k] = key_of(e, bucket[k]);
+            rank[k] = atomicAdd(&hist[bucket[k]], 1);
         }
     }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kBuckets; j += kBlock) base[j] = hist[j] ? atomicAdd(&cnt_global[j], hist[j]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        if (bucket[k] >= 0) {
+            const int slot = base[bucket[k]] + rank[k];
+            if (slot < cap) buf[(int64_t)bucket[k] * cap + slot] = key[k];
+            else flags[1] = 1;
+        }
+    }
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void fast_user_scatter(const Idx *__restrict__ u, int64_t n, int64_t B, int tiles_per_batch,
+                                                             int64_t n_users, unsigned shift_u, int cap_u, int *__restrict__ cnt_u,
+                                                             unsigned long long *__restrict__ ubuf, int *__restrict__ flags) {
+    const int64_t b = blockIdx.x / tiles_per_batch;
+    const int tile = blockIdx.x % tiles_per_batch;
+    const int64_t lo = b * B + (int64_t)tile * kTile;
+    const int64_t batch_end = (b * B + B < n) ? (b * B + B) : n;
+    const int n_local = (int)((lo + kTile <= batch_end) ? kTile : (batch_end > lo ? batch_end - lo : 0));
+    tile_scatter<kTile / kBlock>(n_local, cnt_u + b * kBuckets, ubuf + b * kBuckets * (int64_t)cap_u, cap_u, flags,
+                                 [&](int e, int &bucket) {
+                                     const int64_t i = lo + e;
+                                     int64_t uu = (int64_t)u[i];
+                                     if (uu < 0 || uu >= n_users) {
+                                         flags[0] = 1;
+                                         uu = 0;
+                                     }
+                                     bucket = (int)(uu >> shift_u);
+                                     return ((unsigned long long)uu << 32) | (unsigned long long)(uint32_t)i;
+                                 });
+}
+
+// Item occurrences of a tile of user-sorted triplets: composite (item, side, sorted index) — positives before negatives
+// for equal items, then by sorted triplet index: the order a stable sort of [positives | negatives] gives.
+__global__ __launch_bounds__(kBlock) void fast_item_scatter(const int *__restrict__ tp, const int *__restrict__ tn, int64_t n,
+                                                             int64_t B, int tiles_per_batch, int64_t n_items, unsigned shift_i,
+                                                             int cap_i,
+                                                             int *__restrict__ cnt_i, unsigned long long *__restrict__ ibuf,
+                                                             int *__restrict__ flags) {
+    const int64_t b = blockIdx.x / tiles_per_batch;
+    const int tile = blockIdx.x % tiles_per_batch;
+    const int64_t Bb = ((b * B + B < n) ? B : (n - b * B));
+    const int64_t lo2 = (int64_t)tile * kTile;            // offset into the batch's 2*Bb occurrences: [pos | neg]
+    const int n_local = (int)((lo2 + kTile <= 2 * Bb) ? kTile : (2 * Bb > lo2 ? 2 * Bb - lo2 : 0));
+    tile_scatter<kTile / kBlock>(n_local, cnt_i + b * kBuckets, ibuf + b * kBuckets * (int64_t)cap_i, cap_i, flags,
+                                 [&](int e, int &bucket) {
+                                     const int64_t o = lo2 + e;
+                                     const int side = o >= Bb;
+                                     const int tloc = (int)(side ? o - Bb : o);
+                                     int item = (side ? tn : tp)[b * B + tloc];
+                                     // positions the user stage dropped after a bucket overflow were never written:
+                                     // keep every access in range (the plan is already flagged invalid)
+                                     if (item < 0 || item >= n_items) {
+                                         flags[1] = 1;
+                                         item = 0;
+                                     }
+                                     bucket = item >> shift_i;
+                                     return ((unsigned long long)(uint32_t)item << 32) | ((unsigned long long)side << 31) |
+                                            (unsigned long long)(uint32_t)tloc;
+                                 });
 }
 
 __device__ __forceinline__ int pow2_ceil(int x) {
@@ -102,39 +157,102 @@ __device__ __forceinline__ int pow2_ceil(int x) {
 __device__ __forceinline__ int bucket_prefix(const int *__restrict__ cnt_batch, int bucket, int cap, int *scratch) {
     int a = 0;
     for (int j = threadIdx.x; j < bucket; j += kBlock) a += min(cnt_batch[j], cap);
-    // integer block sum through LDS (order irrelevant for integers)
     __syncthreads();
     if (threadIdx.x == 0) scratch[0] = 0;
     __syncthreads();
-    if (a) atomicAdd(&scratch[0], a);
+    if (a) atomicAdd(&scratch[0], a);  // integer sum: order irrelevant
     __syncthreads();
     return scratch[0];
 }
 
+// Sorts the `count` composites of one bucket ascending, in LDS, into `out`:
+//   counting sort on the top `bin_bits` of the `low_bits` row bits that vary inside a bucket (about one composite per
+//   bin), then every bin's run is ordered on the full composite by one thread (insertion sort; runs are short in any
+//   non-degenerate batch).  `cnt` has 1 << bin_bits ints.  Runs longer than kMaxGroup raise the overflow flag.
+__device__ __forceinline__ void bucket_sort_lds(const unsigned long long *__restrict__ kin, unsigned long long *__restrict__ out,
+                                                int *__restrict__ cnt, int *__restrict__ wave_tot, int count, unsigned low_bits,
+                                                unsigned bin_bits, int *__restrict__ flags) {
+    const int nbin = 1 << bin_bits;
+    const unsigned down = low_bits - bin_bits;
+    const unsigned mask = (unsigned)nbin - 1u;
+    for (int j = threadIdx.x; j < nbin; j += kBlock) cnt[j] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < count; j += kBlock) atomicAdd(&cnt[((unsigned)(kin[j] >> 32) >> down) & mask], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0..nbin): thread t owns counters [t*per, (t+1)*per)
+    const int per = (nbin + kBlock - 1) / kBlock;
+    const int c0 = threadIdx.x * per;
+    int local = 0;
+    for (int j = 0; j < per; ++j)
+        if (c0 + j < nbin) local += cnt[c0 + j];
+    int incl = local;  // inclusive scan over the 64 lanes of the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wave_tot[w];
+    for (int j = 0; j < per; ++j)
+        if (c0 + j < nbin) {
+            const int c = cnt[c0 + j];
+            cnt[c0 + j] = run;
+            run += c;
+        }
+    __syncthreads();
+    for (int j = threadIdx.x; j < count; j += kBlock) {
+        const unsigned long long kv = kin[j];
+        out[atomicAdd(&cnt[((unsigned)(kv >> 32) >> down) & mask], 1)] = kv;
+    }
+    __syncthreads();
+    // after placement cnt[b] is the END of bin b; its start is the end of bin b-1
+    for (int bin = threadIdx.x; bin < nbin; bin += kBlock) {
+        const int r = bin ? cnt[bin - 1] : 0;
+        const int m = cnt[bin] - r;
+        if (m < 2) continue;
+        if (m > kMaxGroup) {
+            flags[1] = 1;
+            continue;
+        }
+        for (int a = 1; a < m; ++a) {  // insertion sort of out[r .. r+m)
+            const unsigned long long x = out[r + a];
+            int bpos = a - 1;
+            while (bpos >= 0 && out[r + bpos] > x) {
+                out[r + bpos + 1] = out[r + bpos];
+                --bpos;
+            }
+            out[r + bpos + 1] = x;
+        }
+    }
+    __syncthreads();
+}
+
 template <typename Idx>
 __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__ p, const Idx *__restrict__ nn, int64_t n,
-                                                          int64_t B, int64_t n_items, int cap_u, int cap_i, unsigned shift_i,
+                                                          int64_t B, int64_t n_items, int cap_u, unsigned shift_u, unsigned bin_bits,
                                                           const int *__restrict__ cnt_u, const unsigned long long *__restrict__ ubuf,
-                                                          int *__restrict__ cnt_i, unsigned long long *__restrict__ ibuf,
                                                           int *__restrict__ tu, int *__restrict__ tp, int *__restrict__ tn,
                                                           int *__restrict__ torig, int *__restrict__ flags) {
-    extern __shared__ unsigned long long keys[];
+    extern __shared__ unsigned long long lds[];  // kin[cap] | out[cap] | cnt[1<<shift] (ints)
     __shared__ int scratch[1];
+    __shared__ int wave_tot[kBlock / 64];
+    unsigned long long *kin = lds, *out = lds + cap_u;
+    int *cnt = reinterpret_cast<int *>(lds + 2 * cap_u);
     const int64_t b = blockIdx.x / kBuckets;
     const int bucket = blockIdx.x % kBuckets;
     const int count = min(cnt_u[blockIdx.x], cap_u);
     const int prefix = bucket_prefix(cnt_u + b * kBuckets, bucket, cap_u, scratch);
     if (count == 0) return;
-    const int n2 = pow2_ceil(count);
     const unsigned long long *src = ubuf + (int64_t)blockIdx.x * cap_u;
-    for (int j = threadIdx.x; j < n2; j += kBlock) keys[j] = (j < count) ? src[j] : ~0ull;
+    for (int j = threadIdx.x; j < count; j += kBlock) kin[j] = src[j];
     __syncthreads();
-    bitonic_sort_lds(keys, n2);
+    bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_u, bin_bits, flags);
     for (int r = threadIdx.x; r < count; r += kBlock) {
-        const unsigned long long kv = keys[r];
+        const unsigned long long kv = out[r];
         const uint32_t orig = (uint32_t)kv;
-        const int tloc = prefix + r;                 // position inside the batch, user-sorted
-        const int64_t t = b * B + tloc;
+        const int64_t t = b * B + prefix + r;  // position in the user-sorted batch
         int64_t pi = (int64_t)p[orig], ni = (int64_t)nn[orig];
         if (pi < 0 || pi >= n_items || ni < 0 || ni >= n_items) {
             flags[0] = 1;
@@ -145,42 +263,30 @@ __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__
         tp[t] = (int)pi;
         tn[t] = (int)ni;
         if (torig) torig[t] = (int)orig;
-        // item occurrences: composite (item, side, sorted index) — positives before negatives for equal items,
-        // then by sorted triplet index: the order a stable sort of [positives | negatives] gives
-        {
-            const int64_t bk = b * kBuckets + (pi >> shift_i);
-            const int slot = atomicAdd(&cnt_i[bk], 1);
-            if (slot < cap_i) ibuf[bk * cap_i + slot] = ((unsigned long long)pi << 32) | (unsigned long long)(uint32_t)tloc;
-            else flags[1] = 1;
-        }
-        {
-            const int64_t bk = b * kBuckets + (ni >> shift_i);
-            const int slot = atomicAdd(&cnt_i[bk], 1);
-            if (slot < cap_i)
-                ibuf[bk * cap_i + slot] = ((unsigned long long)ni << 32) | 0x80000000ull | (unsigned long long)(uint32_t)tloc;
-            else flags[1] = 1;
-        }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, int cap_i, const int *__restrict__ cnt_i,
-                                                          const unsigned long long *__restrict__ ibuf, int *__restrict__ oc_item,
-                                                          int *__restrict__ oc_src, int *__restrict__ tp, int *__restrict__ tn) {
-    extern __shared__ unsigned long long keys[];
+__global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, int cap_i, unsigned shift_i, unsigned bin_bits,
+                                                          const int *__restrict__ cnt_i, const unsigned long long *__restrict__ ibuf,
+                                                          int *__restrict__ oc_item, int *__restrict__ oc_src, int *__restrict__ tp,
+                                                          int *__restrict__ tn, int *__restrict__ flags) {
+    extern __shared__ unsigned long long lds[];
     __shared__ int scratch[1];
+    __shared__ int wave_tot[kBlock / 64];
+    unsigned long long *kin = lds, *out = lds + cap_i;
+    int *cnt = reinterpret_cast<int *>(lds + 2 * cap_i);
     const int64_t b = blockIdx.x / kBuckets;
     const int bucket = blockIdx.x % kBuckets;
     const int count = min(cnt_i[blockIdx.x], cap_i);
     const int prefix = bucket_prefix(cnt_i + b * kBuckets, bucket, cap_i, scratch);
     if (count == 0) return;
-    const int n2 = pow2_ceil(count);
     const unsigned long long *src = ibuf + (int64_t)blockIdx.x * cap_i;
-    for (int j = threadIdx.x; j < n2; j += kBlock) keys[j] = (j < count) ? src[j] : ~0ull;
+    for (int j = threadIdx.x; j < count; j += kBlock) kin[j] = src[j];
     __syncthreads();
-    bitonic_sort_lds(keys, n2);
+    bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_i, bin_bits, flags);
     const int64_t base = 2 * b * B + prefix;
     for (int r = threadIdx.x; r < count; r += kBlock) {
-        const unsigned long long kv = keys[r];
+        const unsigned long long kv = out[r];
         const int item = (int)(kv >> 32);
         const uint32_t lo = (uint32_t)kv;
         const int side = (int)(lo >> 31);
@@ -188,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, i
         oc_item[base + r] = item;
         oc_src[base + r] = (tloc << 1) | side;
         // equal items always share a bucket, so neighbours inside the sorted bucket decide "several occurrences"
-        const bool shared = (r > 0 && (int)(keys[r - 1] >> 32) == item) || (r + 1 < count && (int)(keys[r + 1] >> 32) == item);
+        const bool shared = (r > 0 && (int)(out[r - 1] >> 32) == item) || (r + 1 < count && (int)(out[r + 1] >> 32) == item);
         if (shared) {
             int *dst = side ? tn : tp;
             dst[b * B + tloc] |= (int)0x80000000;  // one writer per (triplet, side)
@@ -214,18 +320,29 @@ static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_
     unsigned long long *ubuf = reinterpret_cast<unsigned long long *>(ws + L.cnt_bytes);
     unsigned long long *ibuf = reinterpret_cast<unsigned long long *>(ws + L.cnt_bytes + L.ubuf_bytes);
     WR_HIP(hipMemsetAsync(cnt_u, 0, (size_t)(2 * L.nb * kBuckets * 4), stream));
-    const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock);
+    const int tiles_u = (int)((B + kTile - 1) / kTile), tiles_i = (int)((2 * B + kTile - 1) / kTile);
     const unsigned gb = (unsigned)(L.nb * kBuckets);
-    hipLaunchKernelGGL((fast_user_scatter<Idx>), dim3(g1), dim3(kBlock), 0, stream, u, n, B, n_users, L.shift_u, L.cap_u,
-                       cnt_u, ubuf, flags);
+    hipLaunchKernelGGL((fast_user_scatter<Idx>), dim3((unsigned)(L.nb * tiles_u)), dim3(kBlock), 0, stream, u, n, B, tiles_u,
+                       n_users, L.shift_u, L.cap_u, cnt_u, ubuf, flags);
     WR_LAUNCH_CHECK("fast_user_scatter");
-    const size_t lds_u = (size_t)8 << (31 - __builtin_clz((unsigned)(2 * L.cap_u - 1)));  // pow2_ceil(cap_u) * 8
-    const size_t lds_i = (size_t)8 << (31 - __builtin_clz((unsigned)(2 * L.cap_i - 1)));
-    hipLaunchKernelGGL((fast_user_sort<Idx>), dim3(gb), dim3(kBlock), lds_u, stream, p, nn, n, B, n_items, L.cap_u, L.cap_i,
-                       L.shift_i, cnt_u, ubuf, cnt_i, ibuf, tu, tp, tn, torig, flags);
+    // bins per bucket: about one composite per bin (twice the mean bucket population, power of two), never more
+    // bins than distinct low-bit patterns
+    auto bins_for = [](int cap, unsigned shift) {
+        unsigned b = 0;
+        while ((1 << b) < cap) ++b;
+        return b < shift ? b : shift;
+    };
+    const unsigned bb_u = bins_for(L.cap_u, L.shift_u), bb_i = bins_for(L.cap_i, L.shift_i);
+    const size_t lds_u = (size_t)L.cap_u * 16 + ((size_t)4 << bb_u);
+    const size_t lds_i = (size_t)L.cap_i * 16 + ((size_t)4 << bb_i);
+    hipLaunchKernelGGL((fast_user_sort<Idx>), dim3(gb), dim3(kBlock), lds_u, stream, p, nn, n, B, n_items, L.cap_u, L.shift_u,
+                       bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags);
     WR_LAUNCH_CHECK("fast_user_sort");
-    hipLaunchKernelGGL(fast_item_sort, dim3(gb), dim3(kBlock), lds_i, stream, n, B, L.cap_i, cnt_i, ibuf, oc_item, oc_src, tp,
-                       tn);
+    hipLaunchKernelGGL(fast_item_scatter, dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B, tiles_i,
+                       n_items, L.shift_i, L.cap_i, cnt_i, ibuf, flags);
+    WR_LAUNCH_CHECK("fast_item_scatter");
+    hipLaunchKernelGGL(fast_item_sort, dim3(gb), dim3(kBlock), lds_i, stream, n, B, L.cap_i, L.shift_i, bb_i, cnt_i, ibuf,
+                       oc_item, oc_src, tp, tn, flags);
     WR_LAUNCH_CHECK("fast_item_sort");
     return WR_OK;
 }

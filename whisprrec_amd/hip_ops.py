@@ -103,9 +103,9 @@ class BatchPlan:
     ``u, p, n`` are the epoch's triplets in batch order (int64 as in the reference, or int32); batch k is
     ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201)."""
 
-    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="generic"):
-        """builder: "generic" = radix-sort builder (default); "auto" = hand-written bucket/LDS-sort builder when applicable,
-        generic otherwise or when a bucket overflowed (skewed ids); "fast" forces the hand-written one (tests)."""
+    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="auto"):
+        """builder: "auto" (default) = hand-written bucket/LDS-sort builder when applicable, generic radix-sort builder
+        otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one."""
         L = abi.lib()
         if u.dtype not in (torch.int64, torch.int32):
             raise TypeError("indices must be int64 or int32")
