@@ -37,8 +37,8 @@ variants = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["
 L = abi.lib()
 for rep in range(2):
     for v in variants:
-        if hasattr(L, "wr_internal_set_variant"):
-            L.wr_internal_set_variant(v)
+        if hasattr(L, "wr_internal_set_user_slots"):
+            L.wr_internal_set_user_slots(v)
         tabs.run_sgd(plan, 0, 4, 0.05)
         t = timeit(lambda k: tabs.run_sgd(plan, 0, NB, 0.05), 1) / NB
         print("variant %d: step (user+item phase): %.2f us" % (v, t))

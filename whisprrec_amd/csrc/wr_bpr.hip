@@ -25,8 +25,6 @@
 
 namespace wr {
 
-static int g_variant = 0;  // tuning experiments (wr_internal_set_variant); 0 = shipped configuration
-
 // ----------------------------------------------------------------------------------------------- forward only
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
@@ -71,112 +69,144 @@ __global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__rest
 // MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.
 // MODE 2 (row-sharded step): user rows applied in place, item gradients emitted (the item "table" is the buffer of
 // rows received from their owners and gradI the buffer of gradient rows sent back).
-template <int T, int NV, bool FULL, int MODE>
+// Each team works on SLOTS positions (t, t + seg, ...): the index loads of all slots are issued together, then the row
+// loads of all slots, then the slots are finished one after the other — twice the bytes in flight per team and a grid
+// that fits the chip in one resident round at the headline batch size.
+template <int T, int NV, bool FULL, int MODE, int SLOTS>
 __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
                                                             const int *__restrict__ tn, int B, float lr, float l2,
                                                             float *__restrict__ Z, float *__restrict__ partials,
                                                             float *__restrict__ gradU, int *__restrict__ stampU,
                                                             float *__restrict__ gradI, int *__restrict__ stampI,
-                                                            int step_id, int flags, float denom) {
+                                                            int step_id, float denom) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
-    const int t0 = blockIdx.x * TEAMS + threadIdx.x / T;
-    const bool wt = (flags & 1) != 0;
+    const int team = blockIdx.x * TEAMS + threadIdx.x / T;
+    const int seg = (B + SLOTS - 1) / SLOTS;
     float term_acc = 0.f;
-    if (t0 < B) {
-        const int u = tu[t0];
-        const bool head = (t0 == 0) || (tu[t0 - 1] != u);
-        if (head) {
-            const Row<NV> ur = load_row<T, NV, FULL>(U, u, D, lane);
-            Row<NV> g;
+
+    int t0[SLOTS], uu[SLOTS], praw0[SLOTS], nraw0[SLOTS];
+    bool head[SLOTS];
 #pragma unroll
-            for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            int t = t0;
-            int praw = tp[t], nraw = tn[t];  // bit 31 set: the item row has other occurrences in this batch
-            bool more;
-            do {
-                const int p = praw & 0x7fffffff, n = nraw & 0x7fffffff;
-                const bool p_shared = praw < 0, n_shared = nraw < 0;
-                const Row<NV> pr = load_row<T, NV, FULL>(I, p, D, lane);
-                const Row<NV> nr = load_row<T, NV, FULL>(I, n, D, lane);
-                const int tnext = t + 1;
-                more = (tnext < B) && (tu[tnext] == u);
-                if (more) {  // indices of the next triplet of this user, issued before the dot/transcendentals
-                    praw = tp[tnext];
-                    nraw = tn[tnext];
-                }
-                const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
-                const float sn = team_sum<T>(dot_partial<NV>(ur, nr));
-                float term, c;
-                bpr_terms(sp, sn, denom, term, c);
-                term_acc += term;
-                Row<NV> z;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    g.v[k].x = fmaf(c, pr.v[k].x - nr.v[k].x, g.v[k].x);
-                    g.v[k].y = fmaf(c, pr.v[k].y - nr.v[k].y, g.v[k].y);
-                    g.v[k].z = fmaf(c, pr.v[k].z - nr.v[k].z, g.v[k].z);
-                    g.v[k].w = fmaf(c, pr.v[k].w - nr.v[k].w, g.v[k].w);
-                    z.v[k] = make_float4(c * ur.v[k].x, c * ur.v[k].y, c * ur.v[k].z, c * ur.v[k].w);
-                }
-                // An item row that occurs once in the batch is read by this team only: finish it here
-                // (gradient = +z for the positive, -z for the negative), no stash, no item-phase work.
-                if (!p_shared) {
-                    Row<NV> w;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        if (MODE == 0) {
-                            w.v[k].x = pr.v[k].x - lr * fmaf(l2, pr.v[k].x, z.v[k].x);
-                            w.v[k].y = pr.v[k].y - lr * fmaf(l2, pr.v[k].y, z.v[k].y);
-                            w.v[k].z = pr.v[k].z - lr * fmaf(l2, pr.v[k].z, z.v[k].z);
-                            w.v[k].w = pr.v[k].w - lr * fmaf(l2, pr.v[k].w, z.v[k].w);
-                        } else {
-                            w.v[k] = z.v[k];
-                        }
-                    }
-                    if (wt) store_row_wt<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w); else store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
-                    if (stampI != nullptr && lane == 0) stampI[p] = step_id;
-                }
-                if (!n_shared) {
-                    Row<NV> w;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        if (MODE == 0) {
-                            w.v[k].x = nr.v[k].x - lr * fmaf(l2, nr.v[k].x, -z.v[k].x);
-                            w.v[k].y = nr.v[k].y - lr * fmaf(l2, nr.v[k].y, -z.v[k].y);
-                            w.v[k].z = nr.v[k].z - lr * fmaf(l2, nr.v[k].z, -z.v[k].z);
-                            w.v[k].w = nr.v[k].w - lr * fmaf(l2, nr.v[k].w, -z.v[k].w);
-                        } else {
-                            w.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
-                        }
-                    }
-                    if (wt) store_row_wt<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w); else store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
-                    if (stampI != nullptr && lane == 0) stampI[n] = step_id;
-                }
-                if (p_shared || n_shared) { if (wt) store_row_wt<T, NV, FULL>(Z, t, D, lane, z); else store_row<T, NV, FULL>(Z, t, D, lane, z); }
-                t = tnext;
-            } while (more);
-            if (MODE != 1) {
-                Row<NV> w;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {  // torch.optim.SGD: g' = g + l2 w ; w -= lr g'
-                    w.v[k].x = ur.v[k].x - lr * fmaf(l2, ur.v[k].x, g.v[k].x);
-                    w.v[k].y = ur.v[k].y - lr * fmaf(l2, ur.v[k].y, g.v[k].y);
-                    w.v[k].z = ur.v[k].z - lr * fmaf(l2, ur.v[k].z, g.v[k].z);
-                    w.v[k].w = ur.v[k].w - lr * fmaf(l2, ur.v[k].w, g.v[k].w);
-                }
-                if (wt) store_row_wt<T, NV, FULL>(U, u, D, lane, w); else store_row<T, NV, FULL>(U, u, D, lane, w);
-            } else {
-                store_row<T, NV, FULL>(gradU, u, D, lane, g);
-            }
-            if (stampU != nullptr && lane == 0) stampU[u] = step_id;
-            if (lane != 0) term_acc = 0.f;  // every lane of the team holds the same terms: count them once
+    for (int s = 0; s < SLOTS; ++s) {
+        t0[s] = team + s * seg;
+        head[s] = false;
+        uu[s] = praw0[s] = nraw0[s] = 0;
+        if (team < seg && t0[s] < B) {
+            uu[s] = tu[t0[s]];
+            head[s] = (t0[s] == 0) || (tu[t0[s] - 1] != uu[s]);   // first position of a run of equal users
+            praw0[s] = tp[t0[s]];                                   // bit 31 set: the item row has other occurrences
+            nraw0[s] = tn[t0[s]];
         }
     }
-    const float s = block_sum(term_acc, scratch);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    Row<NV> ur[SLOTS], pr0[SLOTS], nr0[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        if (head[s]) {
+            ur[s] = load_row<T, NV, FULL>(U, uu[s], D, lane);
+            pr0[s] = load_row<T, NV, FULL>(I, praw0[s] & 0x7fffffff, D, lane);
+            nr0[s] = load_row<T, NV, FULL>(I, nraw0[s] & 0x7fffffff, D, lane);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        if (!head[s]) continue;
+        const int u = uu[s];
+        Row<NV> g;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = t0[s];
+        int praw = praw0[s], nraw = nraw0[s];
+        Row<NV> pr = pr0[s], nr = nr0[s];
+        float terms = 0.f;
+        bool more;
+        do {
+            const int p = praw & 0x7fffffff, n = nraw & 0x7fffffff;
+            const bool p_shared = praw < 0, n_shared = nraw < 0;
+            const int tnext = t + 1;
+            more = (tnext < B) && (tu[tnext] == u);
+            Row<NV> pr_next, nr_next;
+            if (more) {  // next triplet of this user: indices and rows requested before the dot / transcendentals
+                praw = tp[tnext];
+                nraw = tn[tnext];
+                pr_next = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
+                nr_next = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
+            }
+            const float sp = team_sum<T>(dot_partial<NV>(ur[s], pr));
+            const float sn = team_sum<T>(dot_partial<NV>(ur[s], nr));
+            float term, c;
+            bpr_terms(sp, sn, denom, term, c);
+            terms += term;
+            Row<NV> z;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                g.v[k].x = fmaf(c, pr.v[k].x - nr.v[k].x, g.v[k].x);
+                g.v[k].y = fmaf(c, pr.v[k].y - nr.v[k].y, g.v[k].y);
+                g.v[k].z = fmaf(c, pr.v[k].z - nr.v[k].z, g.v[k].z);
+                g.v[k].w = fmaf(c, pr.v[k].w - nr.v[k].w, g.v[k].w);
+                z.v[k] = make_float4(c * ur[s].v[k].x, c * ur[s].v[k].y, c * ur[s].v[k].z, c * ur[s].v[k].w);
+            }
+            // An item row that occurs once in the batch is read by this team only: finish it here
+            // (gradient = +z for the positive, -z for the negative), no stash, no item-phase work.
+            if (!p_shared) {
+                Row<NV> w;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (MODE == 0) {
+                        w.v[k].x = pr.v[k].x - lr * fmaf(l2, pr.v[k].x, z.v[k].x);
+                        w.v[k].y = pr.v[k].y - lr * fmaf(l2, pr.v[k].y, z.v[k].y);
+                        w.v[k].z = pr.v[k].z - lr * fmaf(l2, pr.v[k].z, z.v[k].z);
+                        w.v[k].w = pr.v[k].w - lr * fmaf(l2, pr.v[k].w, z.v[k].w);
+                    } else {
+                        w.v[k] = z.v[k];
+                    }
+                }
+                store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
+                if (stampI != nullptr && lane == 0) stampI[p] = step_id;
+            }
+            if (!n_shared) {
+                Row<NV> w;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (MODE == 0) {
+                        w.v[k].x = nr.v[k].x - lr * fmaf(l2, nr.v[k].x, -z.v[k].x);
+                        w.v[k].y = nr.v[k].y - lr * fmaf(l2, nr.v[k].y, -z.v[k].y);
+                        w.v[k].z = nr.v[k].z - lr * fmaf(l2, nr.v[k].z, -z.v[k].z);
+                        w.v[k].w = nr.v[k].w - lr * fmaf(l2, nr.v[k].w, -z.v[k].w);
+                    } else {
+                        w.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
+                    }
+                }
+                store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
+                if (stampI != nullptr && lane == 0) stampI[n] = step_id;
+            }
+            if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
+            t = tnext;
+            if (more) {
+                pr = pr_next;
+                nr = nr_next;
+            }
+        } while (more);
+        if (MODE != 1) {
+            Row<NV> w;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {  // torch.optim.SGD: g' = g + l2 w ; w -= lr g'
+                w.v[k].x = ur[s].v[k].x - lr * fmaf(l2, ur[s].v[k].x, g.v[k].x);
+                w.v[k].y = ur[s].v[k].y - lr * fmaf(l2, ur[s].v[k].y, g.v[k].y);
+                w.v[k].z = ur[s].v[k].z - lr * fmaf(l2, ur[s].v[k].z, g.v[k].z);
+                w.v[k].w = ur[s].v[k].w - lr * fmaf(l2, ur[s].v[k].w, g.v[k].w);
+            }
+            store_row<T, NV, FULL>(U, u, D, lane, w);
+        } else {
+            store_row<T, NV, FULL>(gradU, u, D, lane, g);
+        }
+        if (stampU != nullptr && lane == 0) stampU[u] = step_id;
+        if (lane == 0) term_acc += terms;  // every lane of the team holds the same terms: count them once
+    }
+    const float sum = block_sum(term_acc, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = sum;
 }
 
 // ----------------------------------------------------------------------------------------------- item phase
@@ -186,10 +216,9 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             const float *__restrict__ Z, float lr, float l2,
                                                             float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
                                                             const float *__restrict__ partials, int n_partials,
-                                                            float loss_denom, float *__restrict__ loss_out, int flags) {
+                                                            float loss_denom, float *__restrict__ loss_out) {
     __shared__ float scratch[kBlock / 64];
     __shared__ int heads[kBlock];
-    if (flags & 4) return;  // experiment: fixed cost of the launch alone
     __shared__ int item_tile[kBlock + 8];  // oc_item of this tile plus up to 8 entries beyond it
     __shared__ int src_tile[kBlock + 8];
     __shared__ int n_heads;
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
         }
     }
     __syncthreads();
-    const int nh = (flags & 2) ? 0 : n_heads;  // experiment: scan only
+    const int nh = n_heads;
     // 2) one TEAM per run: the row and the first stashed contributions are requested together (second round
     //    trip); contributions are summed in sorted (fixed) order and the row is rewritten once.
     for (int h = threadIdx.x / T; h < nh; h += TEAMS) {
@@ -325,20 +354,23 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     if (denom <= 0.f) denom = (float)B;  // single-device step: mean over this batch
     const StepWs w = carve_step_ws(workspace, B, D);
     const dim3 block(kBlock);
+    // SLOTS = 1: two positions per team (twice the loads in flight, one resident round of workgroups at B = 65,536) was
+    // A/B-tested on MI355X and is ~4 % slower — the kernel is bound by the memory system's random 256-B row rate, not by
+    // bytes in flight.
     const dim3 gridA((unsigned)n_blocks_for(B, D));
     const dim3 gridB((unsigned)((2 * B + kBlock - 1) / kBlock));  // item phase: one thread per occurrence
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[0]), stream));
-#define WR_CALL_USER(T_, NV_, FULL_)                                                                                  \
-    hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE>), gridA, block, 0, stream, U, I, D, tu, tp, tn, (int)B, \
-                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, g_variant, denom)
+#define WR_CALL_USER(T_, NV_, FULL_)                                                                                     \
+    hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1>), gridA, block, 0, stream, U, I, D, tu, tp, tn, (int)B, \
+                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
     WR_LAUNCH_CHECK("bprmf_user_phase");
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[1]), stream));
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
     hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
-                       (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)w.n_partials, denom,    \
-                       loss_out, g_variant)
+                       (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)gridA.x, denom,         \
+                       loss_out)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
     WR_LAUNCH_CHECK("bprmf_item_phase");
@@ -358,9 +390,6 @@ static int32_t check_plan_args(const void *tu, const void *tp, const void *tn, c
 using namespace wr;
 
 extern "C" {
-
-// Not part of the public ABI (absent from include/whisprrec_hip.h): selects experimental kernel variants.
-void wr_internal_set_variant(int v) { g_variant = v; }
 
 int64_t wr_bpr_fwd_workspace_bytes(int64_t B) { return align_up(((B + 15) / 16 + 1) * 4, 256); }
 

@@ -131,26 +131,6 @@ __device__ __forceinline__ void store_row(float *__restrict__ base, int64_t row,
     }
 }
 
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-// Write-through (sc1) 16-byte store: the line is not left dirty in the XCD's L2, so the end-of-kernel
-// write-back has nothing to flush for it (MI355X_MICROARCH.md, "stores of each flavour").  The trailing s_nop
-// keeps hipcc from reusing the data registers before the store has read them (cdna_hip_programming.md §5.7).
-__device__ __forceinline__ void store_f4_wt(float4 *p, const float4 &v) {
-    f32x4_t x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-}
-
-template <int T, int NV, bool FULL>
-__device__ __forceinline__ void store_row_wt(float *__restrict__ base, int64_t row, int D, int lane, const Row<NV> &r) {
-    float4 *p = reinterpret_cast<float4 *>(base + row * (int64_t)D);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int c = chunk_of<T>(lane, k);
-        if (FULL || c * 4 < D) store_f4_wt(p + c, r.v[k]);
-    }
-}
-
 template <int NV>
 __device__ __forceinline__ float dot_partial(const Row<NV> &a, const Row<NV> &b) {
     float s = 0.f;
