@@ -99,6 +99,22 @@ int32_t wr_bprmf_plan_build_fast_i32(const int32_t *u, const int32_t *p, const i
                                      void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Epoch preparation on the device — GeneralModel.Dataset.actions_before_epoch (src/models/BaseModel.py:167-177):
+ * one negative per training row, uniform over [1, n_items) (item 0 is never drawn, :168), redrawn while it is in the
+ * user's train set (:172-174).  clicked_ptr int64 [n_users+1] / clicked_idx int32 (ascending per user) is the CSR of
+ * train_clicked_set.  Counter-based generator keyed by (seed, epoch, row, attempt): rows are independent, the result
+ * is reproducible and equals oracle.sample_negatives_counter bit for bit; it is NOT NumPy's MT19937 stream (the
+ * bit-exact NumPy sampler stays available on the host for small-scale parity).  err_flag (int32, device, caller-
+ * zeroed): 1 = user id out of range, 2 = some user has clicked every item.
+ * --------------------------------------------------------------------------------------------------- */
+int32_t wr_sample_negatives_i64(const int64_t *users, int64_t n, int64_t n_users, int64_t n_items, const int64_t *clicked_ptr,
+                                const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int64_t *neg_items,
+                                int32_t *err_flag, void *stream);
+int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users, int64_t n_items, const int64_t *clicked_ptr,
+                                const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int32_t *neg_items,
+                                int32_t *err_flag, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K1-K5 fused  One BaseRunner.fit iteration for BPRMF with torch.optim.SGD —
  *   zero_grad -> predict -> backward -> step  (BaseRunner.py:196-199, optimizer per :120-124)
  * Two kernels: (A) one 16-lane team per user row: gathers U[u], I[p], I[n], BPR loss + coefficient,

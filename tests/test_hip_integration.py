@@ -56,6 +56,22 @@ def test_hip_runner_sgd(g2):
     assert rel_err(model.item_embeddings.weight.detach().cpu().numpy(), g2["sgd_Iend"]) < TOL
 
 
+def test_hip_runner_device_epoch_prep(g2):
+    """--device_epoch_prep 1: negatives and shuffle produced on the device.  Not the NumPy stream, so no golden curve; the
+    sampler rule must hold and training must make progress from the same initial tables."""
+    from whisprrec_amd import runner, hip_ops
+    args, corpus, model, ds = _setup(g2, device_epoch_prep=1, random_seed=3407, lr=2.0)
+    r = runner.HipRunner(args)
+    u, p, n = r._device_epoch(ds, args.device, 1)
+    assert sorted(zip(u.cpu().tolist(), p.cpu().tolist())) == sorted(zip(g2["train_user"].tolist(), g2["train_item"].tolist()))
+    ptr, idx = g2["clicked_ptr"], g2["clicked_idx"]
+    un, nn = u.cpu().numpy(), n.cpu().numpy()
+    assert nn.min() >= 1 and nn.max() < 1574
+    assert not np.isin(un.astype(np.int64) * 1574 + nn, g2["train_user"].astype(np.int64) * 1574 + g2["train_item"]).any()
+    losses = [r.fit(ds, epoch=e) for e in range(1, 9)]
+    assert losses[-1] < losses[0] - 1e-4 and all(np.isfinite(losses))
+
+
 def test_hip_runner_adam_default_optimizer(g2):
     """reference default optimizer (BaseRunner.py:36), README learning rate"""
     from whisprrec_amd import runner

@@ -1,0 +1,78 @@
+"""Device negative sampler (wr_sample_negatives) vs its NumPy restatement in the oracle: bit-exact indices, the
+reference's rule (range [1, n_items), never an item of the user's train set — src/models/BaseModel.py:167-177), and
+reproducibility."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(sets, nU):
+    ptr = np.zeros(nU + 1, np.int64); chunks = []
+    for u in range(nU):
+        it = sorted(sets.get(u, ()))
+        ptr[u + 1] = ptr[u] + len(it)
+        chunks.append(np.asarray(it, np.int32))
+    idx = np.concatenate(chunks) if chunks else np.zeros(0, np.int32)
+    return ptr, (idx if len(idx) else np.zeros(1, np.int32))
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_matches_oracle_bit_exact(g3, dtype):
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    nI = int(g3["n_items"][0])
+    ptr = g3["clicked_ptr"].astype(np.int64); idx = g3["clicked_idx"].astype(np.int32)
+    users = g3["users"]
+    nU = len(ptr) - 1
+    for epoch in (0, 1, 7):
+        neg, err = hip_ops.sample_negatives(torch.from_numpy(users).to(dev).to(dtype), nU, nI, torch.from_numpy(ptr).to(dev),
+                                            torch.from_numpy(idx).to(dev), 3407, epoch)
+        ref = oracle.sample_negatives_counter(users, nI, ptr, idx, 3407, epoch)
+        got = neg.cpu().numpy().astype(np.int64)
+        assert np.array_equal(got, ref)                      # indices bit-exact
+        assert int(err.item()) == 0
+        assert got.min() >= 1 and got.max() < nI              # item 0 is never a negative (BaseModel.py:168)
+        for uu, nn in zip(users, got):
+            assert nn not in idx[ptr[uu]:ptr[uu + 1]]         # user 3 clicked 55 of 57 items: long redraw chains
+    a, _ = hip_ops.sample_negatives(torch.from_numpy(users).to(dev), nU, nI, torch.from_numpy(ptr).to(dev),
+                                    torch.from_numpy(idx).to(dev), 3407, 0)
+    b, _ = hip_ops.sample_negatives(torch.from_numpy(users).to(dev), nU, nI, torch.from_numpy(ptr).to(dev),
+                                    torch.from_numpy(idx).to(dev), 3408, 0)
+    assert not torch.equal(a, b)
+
+
+def test_large_uniformity_and_exclusion():
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(0)
+    nU, nI, n = 2000, 5000, 1_000_000
+    sets = {u: set(rng.randint(0, nI, rng.randint(1, 60)).tolist()) for u in range(nU)}
+    ptr, idx = _csr(sets, nU)
+    users = rng.randint(0, nU, n)
+    neg, err = hip_ops.sample_negatives(torch.from_numpy(users).to(dev), nU, nI, torch.from_numpy(ptr).to(dev),
+                                        torch.from_numpy(idx).to(dev), 1, 0)
+    got = neg.cpu().numpy()
+    assert int(err.item()) == 0 and got.min() >= 1 and got.max() < nI
+    # exclusion, vectorised: (user, item) pairs of the train set never appear
+    train_keys = np.concatenate([np.full(ptr[u + 1] - ptr[u], u, np.int64) * nI + idx[ptr[u]:ptr[u + 1]] for u in range(nU)])
+    assert not np.isin(users.astype(np.int64) * nI + got, train_keys).any()
+    counts = np.bincount(got, minlength=nI)[1:]
+    assert abs(counts.mean() - n / (nI - 1)) < 1e-6 and counts.std() / counts.mean() < 0.15   # flat histogram
+    sample = slice(0, 3000)
+    assert np.array_equal(got[sample], oracle.sample_negatives_counter(users[sample], nI, ptr, idx, 1, 0))
+
+
+def test_user_who_clicked_everything_is_flagged():
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    nI = 20
+    sets = {0: set(range(nI)), 1: {3}}
+    ptr, idx = _csr(sets, 2)
+    neg, err = hip_ops.sample_negatives(torch.tensor([0, 1, 1], device=dev), 2, nI, torch.from_numpy(ptr).to(dev),
+                                        torch.from_numpy(idx).to(dev), 5, 0)
+    assert int(err.item()) == 2
+    assert neg[1].item() != 3 and neg[2].item() != 3

@@ -29,6 +29,10 @@ SIGNATURES = {
                                              c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_plan_build_fast_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                              c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "wr_sample_negatives_i64": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp, c_vp,
+                                        c_vp]),
+    "wr_sample_negatives_i32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp, c_vp,
+                                        c_vp]),
     "wr_bprmf_step_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "wr_bprmf_step_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32,
                                   c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),

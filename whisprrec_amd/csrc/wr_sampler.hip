@@ -1,0 +1,102 @@
+// wr_sampler.hip — on-device epoch preparation: negative sampling with rejection against the user's train set.
+//
+// Device counterpart of GeneralModel.Dataset.actions_before_epoch (reference src/models/BaseModel.py:167-177): one negative
+// per training row, uniform over [1, n_items) — item 0 is never drawn, like the reference (:168) — redrawn while it is in
+// the user's train set (:172-174).  The reference consumes NumPy's MT19937 stream row by row on the host (minutes at
+// 100 M rows); this kernel uses a counter-based generator keyed by (seed, epoch, row, attempt), so rows are independent
+// and the result does not depend on scheduling.  It is NOT stream-compatible with NumPy (documented in DESIGN.md): the
+// host path in whisprrec_amd/host.py keeps the bit-exact NumPy sampler for small-scale parity; the oracle restates THIS
+// generator in NumPy and tests compare bit for bit.
+#include "wr_common.h"
+
+namespace wr {
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+__host__ __device__ __forceinline__ uint32_t draw_item(uint64_t seed, uint64_t epoch, uint64_t row, uint32_t attempt,
+                                                       uint32_t n_items) {
+    const uint64_t x = mix64(mix64(seed ^ (epoch * 0x9E3779B97F4A7C15ull)) ^ mix64(row * 0xD1B54A32D192ED03ull + attempt));
+    // unbiased-enough multiply-high reduction of the top 32 bits onto [0, n_items-1), then shift to [1, n_items)
+    return 1u + (uint32_t)(((x >> 32) * (uint64_t)(n_items - 1)) >> 32);
+}
+
+__device__ __forceinline__ bool clicked(const int *__restrict__ idx, int64_t lo, int64_t hi, int item) {
+    while (lo < hi) {  // binary search in the user's ascending item list
+        const int64_t mid = (lo + hi) >> 1;
+        const int v = idx[mid];
+        if (v == item) return true;
+        if (v < item) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+constexpr uint32_t kMaxAttempts = 64;
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void sample_negatives_kernel(const Idx *__restrict__ users, int64_t n, int64_t n_users,
+                                                                   uint32_t n_items, const int64_t *__restrict__ ptr,
+                                                                   const int *__restrict__ idx, uint64_t seed, uint64_t epoch,
+                                                                   Idx *__restrict__ neg, int *__restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int64_t u = (int64_t)users[i];
+    if (u < 0 || u >= n_users) {
+        if (err) *err = 1;
+        u = 0;
+    }
+    const int64_t lo = ptr[u], hi = ptr[u + 1];
+    uint32_t attempt = 0;
+    uint32_t cand = draw_item(seed, epoch, (uint64_t)i, attempt, n_items);
+    while (clicked(idx, lo, hi, (int)cand)) {
+        if (++attempt < kMaxAttempts) {
+            cand = draw_item(seed, epoch, (uint64_t)i, attempt, n_items);
+        } else {
+            // a user who clicked (almost) everything: walk forward cyclically over [1, n_items) from the last draw
+            cand = (cand + 1u >= n_items) ? 1u : cand + 1u;
+            if (attempt >= kMaxAttempts + n_items) {  // every item clicked: keep the reference's range, flag it
+                if (err) *err = 2;
+                break;
+            }
+        }
+    }
+    neg[i] = (Idx)cand;
+}
+
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" {
+
+int32_t wr_sample_negatives_i64(const int64_t *users, int64_t n, int64_t n_users, int64_t n_items, const int64_t *clicked_ptr,
+                                const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int64_t *neg_items,
+                                int32_t *err_flag, void *stream) {
+    WR_REQUIRE(users && clicked_ptr && clicked_idx && neg_items, WR_E_NULL, "sampler: NULL argument");
+    WR_REQUIRE(n >= 0 && n_users > 0 && n_items >= 2 && n_items < (int64_t(1) << 31), WR_E_SHAPE, "sampler: bad sizes");
+    if (n == 0) return WR_OK;
+    hipLaunchKernelGGL((sample_negatives_kernel<int64_t>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), users, n, n_users, (uint32_t)n_items, clicked_ptr, clicked_idx,
+                       seed, epoch, neg_items, err_flag);
+    WR_LAUNCH_CHECK("sample_negatives_kernel");
+    return WR_OK;
+}
+
+int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users, int64_t n_items, const int64_t *clicked_ptr,
+                                const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int32_t *neg_items,
+                                int32_t *err_flag, void *stream) {
+    WR_REQUIRE(users && clicked_ptr && clicked_idx && neg_items, WR_E_NULL, "sampler: NULL argument");
+    WR_REQUIRE(n >= 0 && n_users > 0 && n_items >= 2 && n_items < (int64_t(1) << 31), WR_E_SHAPE, "sampler: bad sizes");
+    if (n == 0) return WR_OK;
+    hipLaunchKernelGGL((sample_negatives_kernel<int32_t>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), users, n, n_users, (uint32_t)n_items, clicked_ptr, clicked_idx,
+                       seed, epoch, neg_items, err_flag);
+    WR_LAUNCH_CHECK("sample_negatives_kernel");
+    return WR_OK;
+}
+
+}  // extern "C"

@@ -258,6 +258,36 @@ class BprmfTables:
         return loss_out, self.step_id
 
 
+# ----------------------------------------------------------------------------------------------- epoch prep
+def sample_negatives(users, n_users, n_items, clicked_ptr, clicked_idx, seed, epoch):
+    """Device negative sampler (reference src/models/BaseModel.py:167-177 semantics, counter-based generator)."""
+    if users.dtype not in (torch.int64, torch.int32):
+        raise TypeError("users must be int64 or int32")
+    users = _req(users.contiguous(), users.dtype, "users", 1)
+    _req(clicked_ptr, torch.int64, "clicked_ptr", 1)
+    _req(clicked_idx, torch.int32, "clicked_idx", 1)
+    neg = torch.empty_like(users)
+    err = torch.zeros(1, dtype=torch.int32, device=users.device)
+    fn = abi.lib().wr_sample_negatives_i64 if users.dtype == torch.int64 else abi.lib().wr_sample_negatives_i32
+    abi.check(fn(_p(users), users.numel(), n_users, n_items, _p(clicked_ptr), _p(clicked_idx), seed, epoch, _p(neg), _p(err),
+                 _stream()), "wr_sample_negatives")
+    return neg, err
+
+
+def clicked_csr(train_clicked_set, n_users, device):
+    """train_clicked_set (dict user -> set of items, reference BaseReader.py:35-46) -> device CSR with ascending items."""
+    import numpy as np
+    ptr = np.zeros(n_users + 1, np.int64)
+    chunks = []
+    for uu in range(n_users):
+        items = train_clicked_set.get(uu, ())
+        ptr[uu + 1] = ptr[uu] + len(items)
+        if len(items):
+            chunks.append(np.sort(np.fromiter(items, dtype=np.int32, count=len(items))))
+    idx = np.concatenate(chunks) if chunks else np.zeros(1, np.int32)
+    return torch.from_numpy(ptr).to(device), torch.from_numpy(idx).to(device)
+
+
 # ----------------------------------------------------------------------------------------------- optimizers
 def sgd_dense(tab, grad, lr, l2=0.0, stamp=None, step_id=0):
     abi.check(abi.lib().wr_sgd_dense(_p(_req(tab, torch.float32, "tab", 2)), tab.shape[0], tab.shape[1],

@@ -196,16 +196,50 @@ class BaseRunner(object):
 
 def make_hip_runner(base_runner_cls):
     class HipRunner(base_runner_cls):
+        @staticmethod
+        def parse_runner_args(parser):
+            parser.add_argument("--device_epoch_prep", type=int, default=0,
+                                help="1: sample negatives and shuffle on the device (counter-based generator; same rule "
+                                     "as the reference sampler but not its NumPy stream). 0: reference streams, bit-exact.")
+            return base_runner_cls.parse_runner_args(parser)
+
+        def __init__(self, args):
+            super().__init__(args)
+            self.device_epoch_prep = int(getattr(args, "device_epoch_prep", 0))
+            self.seed = int(getattr(args, "random_seed", 3407))
+            self._epoch_cache = None
+
+        def _device_epoch(self, dataset, dev, epoch):
+            """negatives (wr_sample_negatives) + shuffle, all on the device: no Python loop over rows"""
+            from . import hip_ops
+            model, corpus = dataset.model, dataset.corpus
+            if self._epoch_cache is None or self._epoch_cache[0] is not dataset:
+                users = torch.from_numpy(np.ascontiguousarray(dataset.data["user_id"])).to(torch.int64).to(dev)
+                items = torch.from_numpy(np.ascontiguousarray(dataset.data["item_id"])).to(torch.int64).to(dev)
+                ptr, idx = hip_ops.clicked_csr(corpus.train_clicked_set, model.user_num, dev)
+                self._epoch_cache = (dataset, users, items, ptr, idx)
+            _, users, items, ptr, idx = self._epoch_cache
+            neg, err = hip_ops.sample_negatives(users, model.user_num, model.item_num, ptr, idx, self.seed, max(epoch, 0))
+            g = torch.Generator(device=dev)
+            g.manual_seed(self.seed * 1000003 + max(epoch, 0))
+            order = torch.randperm(users.numel(), device=dev, generator=g)
+            if int(err.item()) == 1:
+                raise IndexError("user id out of range in the training frame")
+            return users[order], items[order], neg[order]
+
         def fit(self, dataset, epoch=-1):
             model = dataset.model
             if not hasattr(model, "train_epoch") or self.optimizer_name not in ("SGD", "Adam"):
                 return base_runner_cls.fit(self, dataset, epoch)
-            dataset.actions_before_epoch()          # must happen before the shuffle draws, as in the reference
-            model.train()
-            order = epoch_order(len(dataset), self.batch_size)
             dev = model.user_embeddings.weight.device
-            cols = [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64)[order].to(dev)
-                    for k in ("user_id", "item_id", "neg_items")]
+            model.train()
+            if self.device_epoch_prep:
+                cols = self._device_epoch(dataset, dev, epoch)
+            else:
+                dataset.actions_before_epoch()          # must happen before the shuffle draws, as in the reference
+                order = epoch_order(len(dataset), self.batch_size)
+                cols = [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64)[order].to(dev)
+                        for k in ("user_id", "item_id", "neg_items")]
             losses = model.train_epoch(cols[0], cols[1], cols[2], self.batch_size, self.learning_rate, float(self.l2),
                                        self.optimizer_name)
             return float(np.mean(losses.cpu().numpy()))  # one sync per epoch instead of one per batch (:200)
