@@ -207,6 +207,13 @@ int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float 
  * --------------------------------------------------------------------------------------------------- */
 int32_t wr_spmm_csr(int64_t n_rows, const int64_t *row_ptr, const int32_t *col, const float *val, const float *X,
                     int32_t D, float *Y, float *acc, void *stream);
+/* Load-balanced form for power-law graphs: the rows are pre-cut (once, on the host: the adjacency is static) into
+ * consecutive chunks of at most L non-zeros; chunk c covers non-zeros [chunk_ptr[c], chunk_ptr[c+1]) of row chunk_row[c],
+ * every row has at least one (possibly empty) chunk, the chunks of a row are consecutive.  partials: fp32 [n_chunks, D]
+ * scratch.  Rows with several chunks are summed in chunk order (reproducible). */
+int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                            const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
+                            float *partials, void *stream);
 /* out = alpha * x  /  y += alpha * x  over numel floats (layer-mean scaling, gradient accumulation) */
 int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream);
 /* EmbLoss pieces (src/utils/loss.py:94-98): sq[0..2] = sum of squares of the gathered U[u], I[p], I[n] blocks */

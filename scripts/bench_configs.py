@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configs other than the bench.py headline (run on the GPU box).
+Prints one JSON object per line; copy the output to profiles/."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from whisprrec_amd import hip_ops, host
+
+dev = torch.device("cuda:0")
+
+
+def ev_time(fn, iters):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(iters):
+        fn(k)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def synth(nU, nI, n, zipf=0.0, seed=1):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    u = torch.randint(0, nU, (n,), generator=g, device=dev, dtype=torch.int32)
+    if zipf > 0:
+        r = torch.rand(n, generator=g, device=dev, dtype=torch.float64)
+        p = (torch.exp(r * np.log(nI)).to(torch.int64) - 1).clamp_(0, nI - 1).to(torch.int32)
+    else:
+        p = torch.randint(0, nI, (n,), generator=g, device=dev, dtype=torch.int32)
+    ng = torch.randint(1, nI, (n,), generator=g, device=dev, dtype=torch.int32)
+    return u, p, ng
+
+
+def tables(nU, nI, D, seed=1):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    return (torch.randn(nU, D, generator=g, device=dev) * 0.01, torch.randn(nI, D, generator=g, device=dev) * 0.01)
+
+
+def bprmf_case(name, nU, nI, D, B, NB, opt="SGD", l2=0.0, zipf=0.0):
+    U, I = tables(nU, nI, D)
+    u, p, n = synth(nU, nI, NB * B, zipf)
+    tabs = hip_ops.BprmfTables(U, I)
+    t0 = time.perf_counter(); plan = hip_ops.BatchPlan(u, p, n, B, nU, nI); torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
+    t0 = time.perf_counter(); plan = hip_ops.BatchPlan(u, p, n, B, nU, nI); torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
+    if opt == "SGD" and l2 == 0.0:
+        tabs.run_sgd(plan, 0, min(NB, 4), 0.05)
+        t = ev_time(lambda k: tabs.run_sgd(plan, 0, NB, 0.05), 1) / NB
+    elif opt == "SGD":
+        tabs.step_sgd(plan, 0, 0.05, l2)
+        t = ev_time(lambda k: tabs.step_sgd(plan, k, 0.05, l2), NB)
+    else:
+        gU, gI = torch.zeros_like(U), torch.zeros_like(I)
+        st = [torch.zeros_like(U), torch.zeros_like(U), torch.zeros_like(I), torch.zeros_like(I)]
+        def step(k):
+            _, sid = tabs.grads(plan, k, gU, gI)
+            hip_ops.adam_dense(tabs.U, st[0], st[1], gU, k + 1, 1e-3, l2, stamp=tabs.stamp_u, step_id=sid)
+            hip_ops.adam_dense(tabs.I, st[2], st[3], gI, k + 1, 1e-3, l2, stamp=tabs.stamp_i, step_id=sid)
+        step(0)
+        t = ev_time(step, NB)
+    emit(case=name, users=nU, items=nI, D=D, batch=B, optimizer=opt, l2=l2, zipf=zipf, plan_builder=plan.builder,
+         step_us=t * 1e6, plan_us_per_step=t_plan / NB * 1e6, triplets_per_s_steps_only=B / t,
+         triplets_per_s_with_plan=B / (t + t_plan / NB), algorithmic_GBs=(6 * D * 4 + 12) * B / t / 1e9)
+    del U, I, tabs, plan
+    torch.cuda.empty_cache()
+
+
+def lightgcn_case():
+    from whisprrec_amd.lightgcn import LightGCN
+    rng = np.random.RandomState(0)
+    nU, nI, B = 6040, 3706, 2048
+    sets = {}
+    n_pairs = 0
+    for uu in range(nU):   # ml-1m-shaped: >= 16 train items per user, power-law item popularity
+        k = int(min(nI - 1, max(16, rng.pareto(1.2) * 40)))
+        items = np.unique(np.minimum((rng.pareto(0.8, k) * 30).astype(np.int64), nI - 1))
+        sets[uu] = set(items.tolist()); n_pairs += len(items)
+    corpus = host.Corpus(nU, nI, {"train": {"user_id": [], "item_id": []}, "dev": {"user_id": [], "item_id": []},
+                                  "test": {"user_id": [], "item_id": []}}, sets, {})
+    args = argparse.Namespace(device=dev, model_path="/tmp/x.pt", buffer=1, num_neg=1, test_all=1, embedding_size=64,
+                              gcn_layers=2, reg_weight=1e-5, optimizer="Adam", lr=2e-3, l2=0.0)
+    m = LightGCN(args, corpus).to(dev); m.train()
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    batch = {"user_id": torch.randint(0, nU, (B,), generator=g, device=dev), "pos_item": torch.randint(0, nI, (B,), generator=g, device=dev),
+             "neg_items": torch.randint(1, nI, (B,), generator=g, device=dev)}
+    def step(k):
+        m.optimizer.zero_grad(); loss = m.predict(batch); loss.backward(); m.optimizer.step()
+    for _ in range(3): step(0)
+    t = ev_time(step, 20)
+    cptr, crow, col, val = m._csr()
+    E = torch.cat([m.user_embedding.weight.data, m.item_embedding.weight.data])
+    part = torch.empty((crow.numel(), 64), device=dev)
+    t_spmm = ev_time(lambda k: hip_ops.spmm_csr_chunked(cptr, crow, col, val, E, partials=part), 50)
+    nnz = int(col.numel())
+    emit(case="C3 LightGCN L=2 D=64 ml-1m-shaped synthetic graph, Adam, B=2048 (zero_grad/predict/backward/step)", nodes=nU + nI,
+         nnz=nnz, step_ms=t * 1e3, triplets_per_s=B / t, spmm_us=t_spmm * 1e6,
+         spmm_GBs=(nnz * 8 + 2 * (nU + nI) * 64 * 4) / t_spmm / 1e9, spmm_GFLOPs=2 * nnz * 64 / t_spmm / 1e9)
+
+
+def sasrec_embedding_case():
+    nI, D, B, T = 3706, 64, 2048, 20
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    W = torch.randn(nI, D, generator=g, device=dev)
+    hist = torch.randint(0, nI, (B, T), generator=g, device=dev)
+    pn = torch.randint(0, nI, (2 * B,), generator=g, device=dev)
+    idx = torch.cat([hist.reshape(-1), pn])
+    grad_out = torch.randn(idx.numel(), D, generator=g, device=dev)
+    G = torch.zeros_like(W)
+    t_g = ev_time(lambda k: hip_ops.gather_rows(W, idx), 50)
+    t_s = ev_time(lambda k: hip_ops.scatter_add_rows(G, idx, grad_out, padding_idx=0), 50)
+    emit(case="C5 SASRec item-embedding slice: gather + sorted scatter-add of B*(T+2) rows, D=64", rows=int(idx.numel()),
+         gather_us=t_g * 1e6, scatter_us=t_s * 1e6, gather_GBs=idx.numel() * 512 / t_g / 1e9)
+
+
+def ml100k_dropin_case():
+    import argparse as ap
+    from whisprrec_amd.bprmf import BPRMF
+    from whisprrec_amd import runner
+    g2 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g2_ml100k_curve.npz"))
+    ptr, idx = g2["clicked_ptr"], g2["clicked_idx"]
+    tcs = {u: set(idx[ptr[u]:ptr[u + 1]].tolist()) for u in range(943)}
+    data = {"train": {"user_id": g2["train_user"].astype(np.int64), "item_id": g2["train_item"].astype(np.int64)},
+            "dev": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)},
+            "test": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)}}
+    corpus = host.Corpus(943, 1574, data, tcs, {u: set() for u in range(943)})
+    for opt, rname in (("Adam", "BaseRunner"), ("SGD", "BaseRunner"), ("Adam", "HipRunner"), ("SGD", "HipRunner"), ("SGD", "HipRunner+device_epoch_prep")):
+        args = ap.Namespace(device=dev, model_path="/tmp/x.pt", buffer=1, num_neg=1, test_all=1, embedding_size=64, fused=1,
+                            epoch=1, check_epoch=1, test_epoch=-1, early_stop=10, lr=1e-3, l2=0.0, batch_size=2048,
+                            eval_batch_size=2048, optimizer=opt, num_workers=0, pin_memory=0, topk="10,20", metric="NDCG, HR",
+                            device_epoch_prep=1 if "device" in rname else 0, random_seed=3407)
+        model = BPRMF(args, corpus).to(dev)
+        ds = BPRMF.Dataset(model, corpus, "train")
+        r = (runner.BaseRunner if rname == "BaseRunner" else runner.HipRunner)(args)
+        r.fit(ds, 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for e in range(3): r.fit(ds, e + 2)
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 3
+        emit(case="C1 BPRMF ml-100k (943x1574, 66,016 train rows, B=2048) whole fit() epoch incl. sampler + batching",
+             runner=rname, optimizer=opt, epoch_s=t, triplets_per_s=66016 / t)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c4", "c3", "c5", "c1"]
+    if "c2" in which:
+        for B, NB in ((2048, 256), (16384, 128), (65536, 64), (262144, 16)):
+            bprmf_case("C2 BPRMF 1Mx1M D=64 SGD l2=0", 1_000_000, 1_000_000, 64, B, NB)
+        bprmf_case("C2 SGD l2=1e-6 (dense weight decay)", 1_000_000, 1_000_000, 64, 65536, 16, l2=1e-6)
+        bprmf_case("C2 Adam (dense, reference default optimizer)", 1_000_000, 1_000_000, 64, 65536, 16, opt="Adam")
+        bprmf_case("C2 Zipf(1.0) items", 1_000_000, 1_000_000, 64, 65536, 64, zipf=1.0)
+    if "c4" in which:
+        bprmf_case("C4 shapes on ONE GPU: 10Mx10M D=128 SGD l2=0", 10_000_000, 10_000_000, 128, 65536, 32)
+    if "c3" in which:
+        lightgcn_case()
+    if "c5" in which:
+        sasrec_embedding_case()
+    if "c1" in which:
+        ml100k_dropin_case()

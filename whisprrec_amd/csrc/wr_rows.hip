@@ -203,6 +203,95 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(int64_t n_rows, const 
     }
 }
 
+// Load-balanced form: the rows are cut into chunks of at most L non-zeros (the adjacency is static, the cut is made once
+// on the host).  One team per chunk, four neighbour rows requested per round.  A row with a single chunk is written
+// directly; the chunks of a longer row go to `partials` and are summed in chunk order by the second kernel, so the
+// result is reproducible and a power-law hub (thousands of neighbours) no longer serialises on one team.
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const int64_t *__restrict__ chunk_ptr,
+                                                             const int *__restrict__ chunk_row, const int *__restrict__ col,
+                                                             const float *__restrict__ val, const float *__restrict__ X, int D,
+                                                             float *__restrict__ Y, float *__restrict__ acc,
+                                                             float *__restrict__ partials) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int c = blockIdx.x * TEAMS + threadIdx.x / T;
+    if (c >= n_chunks) return;
+    const int row = chunk_row[c];
+    const bool multi = (c > 0 && chunk_row[c - 1] == row) || (c + 1 < n_chunks && chunk_row[c + 1] == row);
+    Row<NV> s;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t k = chunk_ptr[c];
+    const int64_t k1 = chunk_ptr[c + 1];
+    for (; k + 4 <= k1; k += 4) {
+        const float a0 = val[k], a1 = val[k + 1], a2 = val[k + 2], a3 = val[k + 3];
+        const Row<NV> x0 = load_row<T, NV, FULL>(X, col[k], D, lane);
+        const Row<NV> x1 = load_row<T, NV, FULL>(X, col[k + 1], D, lane);
+        const Row<NV> x2 = load_row<T, NV, FULL>(X, col[k + 2], D, lane);
+        const Row<NV> x3 = load_row<T, NV, FULL>(X, col[k + 3], D, lane);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {  // same order as the sequential loop: ((((s + a0 x0) + a1 x1) + a2 x2) + a3 x3)
+            s.v[q].x = fmaf(a3, x3.v[q].x, fmaf(a2, x2.v[q].x, fmaf(a1, x1.v[q].x, fmaf(a0, x0.v[q].x, s.v[q].x))));
+            s.v[q].y = fmaf(a3, x3.v[q].y, fmaf(a2, x2.v[q].y, fmaf(a1, x1.v[q].y, fmaf(a0, x0.v[q].y, s.v[q].y))));
+            s.v[q].z = fmaf(a3, x3.v[q].z, fmaf(a2, x2.v[q].z, fmaf(a1, x1.v[q].z, fmaf(a0, x0.v[q].z, s.v[q].z))));
+            s.v[q].w = fmaf(a3, x3.v[q].w, fmaf(a2, x2.v[q].w, fmaf(a1, x1.v[q].w, fmaf(a0, x0.v[q].w, s.v[q].w))));
+        }
+    }
+    for (; k < k1; ++k) {
+        const float a = val[k];
+        const Row<NV> x = load_row<T, NV, FULL>(X, col[k], D, lane);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            s.v[q].x = fmaf(a, x.v[q].x, s.v[q].x); s.v[q].y = fmaf(a, x.v[q].y, s.v[q].y);
+            s.v[q].z = fmaf(a, x.v[q].z, s.v[q].z); s.v[q].w = fmaf(a, x.v[q].w, s.v[q].w);
+        }
+    }
+    if (multi) {
+        store_row<T, NV, FULL>(partials, c, D, lane, s);
+        return;
+    }
+    store_row<T, NV, FULL>(Y, row, D, lane, s);
+    if (acc != nullptr) {
+        Row<NV> a = load_row<T, NV, FULL>(acc, row, D, lane);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            a.v[q].x += s.v[q].x; a.v[q].y += s.v[q].y; a.v[q].z += s.v[q].z; a.v[q].w += s.v[q].w;
+        }
+        store_row<T, NV, FULL>(acc, row, D, lane, a);
+    }
+}
+
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, const int *__restrict__ chunk_row,
+                                                               const float *__restrict__ partials, int D, float *__restrict__ Y,
+                                                               float *__restrict__ acc) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int c = blockIdx.x * TEAMS + threadIdx.x / T;
+    if (c >= n_chunks) return;
+    const int row = chunk_row[c];
+    const bool head = (c == 0 || chunk_row[c - 1] != row) && (c + 1 < n_chunks && chunk_row[c + 1] == row);
+    if (!head) return;
+    Row<NV> s = load_row<T, NV, FULL>(partials, c, D, lane);
+    for (int j = c + 1; j < n_chunks && chunk_row[j] == row; ++j) {
+        const Row<NV> x = load_row<T, NV, FULL>(partials, j, D, lane);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            s.v[q].x += x.v[q].x; s.v[q].y += x.v[q].y; s.v[q].z += x.v[q].z; s.v[q].w += x.v[q].w;
+        }
+    }
+    store_row<T, NV, FULL>(Y, row, D, lane, s);
+    if (acc != nullptr) {
+        Row<NV> a = load_row<T, NV, FULL>(acc, row, D, lane);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            a.v[q].x += s.v[q].x; a.v[q].y += s.v[q].y; a.v[q].z += s.v[q].z; a.v[q].w += s.v[q].w;
+        }
+        store_row<T, NV, FULL>(acc, row, D, lane, a);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ EmbLoss
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void embloss_sumsq_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
@@ -407,6 +496,32 @@ int32_t wr_spmm_csr(int64_t n_rows, const int64_t *row_ptr, const int32_t *col, 
     WR_DISPATCH_D(D, WR_CALL_M);
 #undef WR_CALL_M
     WR_LAUNCH_CHECK("spmm_csr_kernel");
+    return WR_OK;
+}
+
+int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                            const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
+                            float *partials, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(X, n_rows, D, "X")) != WR_OK) return rc;
+    if ((rc = check_table(Y, n_rows, D, "Y")) != WR_OK) return rc;
+    WR_REQUIRE(chunk_ptr && chunk_row && col && val && partials, WR_E_NULL, "chunked CSR arrays must not be NULL");
+    WR_REQUIRE(n_chunks >= n_rows && n_chunks < (int64_t(1) << 31), WR_E_SHAPE, "every row needs at least one chunk");
+    WR_REQUIRE(X != Y, WR_E_SHAPE, "spmm: X and Y must not alias");
+    WR_REQUIRE(aligned16(partials) && (acc == nullptr || aligned16(acc)), WR_E_ALIGN, "partials/acc not 16-byte aligned");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int tpb = teams_per_block_for(D);
+    const unsigned grid = (unsigned)((n_chunks + tpb - 1) / tpb);
+#define WR_CALL_MC(T_, NV_, FULL_)                                                                                      \
+    do {                                                                                                                \
+        hipLaunchKernelGGL((spmm_chunk_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,      \
+                           chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials);                                     \
+        hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,    \
+                           chunk_row, partials, D, Y, acc);                                                             \
+    } while (0)
+    WR_DISPATCH_D(D, WR_CALL_MC);
+#undef WR_CALL_MC
+    WR_LAUNCH_CHECK("spmm_chunk_kernel");
     return WR_OK;
 }
 

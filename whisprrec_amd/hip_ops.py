@@ -344,6 +344,37 @@ def spmm_csr(row_ptr, col, val, X, Y=None, acc=None):
     return Y
 
 
+def spmm_chunks(row_ptr, max_nnz=32):
+    """Cut CSR rows into chunks of at most `max_nnz` non-zeros (host, once per graph).  Returns (chunk_ptr int64
+    [n_chunks+1], chunk_row int32 [n_chunks]) as CPU tensors; every row gets at least one chunk."""
+    import numpy as np
+    rp = row_ptr.cpu().numpy() if isinstance(row_ptr, torch.Tensor) else np.asarray(row_ptr)
+    deg = np.diff(rp)
+    per = np.maximum(1, (deg + max_nnz - 1) // max_nnz)
+    chunk_row = np.repeat(np.arange(len(deg), dtype=np.int32), per)
+    first = np.cumsum(per) - per                       # index of each row's first chunk
+    within = np.arange(chunk_row.size) - np.repeat(first, per)
+    start = rp[:-1][chunk_row] + within * max_nnz
+    chunk_ptr = np.concatenate([start, rp[-1:]]).astype(np.int64)
+    return torch.from_numpy(chunk_ptr), torch.from_numpy(chunk_row)
+
+
+def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partials=None):
+    _req(chunk_ptr, torch.int64, "chunk_ptr", 1)
+    _req(chunk_row, torch.int32, "chunk_row", 1)
+    _req(col, torch.int32, "col", 1)
+    _req(val, torch.float32, "val", 1)
+    _req(X, torch.float32, "X", 2)
+    if Y is None:
+        Y = torch.empty_like(X)
+    if partials is None:
+        partials = torch.empty((chunk_row.numel(), X.shape[1]), dtype=torch.float32, device=X.device)
+    abi.check(abi.lib().wr_spmm_csr_chunked(X.shape[0], chunk_row.numel(), _p(chunk_ptr), _p(chunk_row), _p(col), _p(val),
+                                            _p(X), X.shape[1], _p(Y), _p(acc), _p(partials), _stream()),
+              "wr_spmm_csr_chunked")
+    return Y
+
+
 def axpy(y, x, alpha, overwrite=False):
     abi.check(abi.lib().wr_axpy(_p(_req(y, torch.float32, "y")), _p(_req(x, torch.float32, "x")), y.numel(), alpha,
                                 1 if overwrite else 0, _stream()), "wr_axpy")

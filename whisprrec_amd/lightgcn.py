@@ -122,8 +122,10 @@ def make_lightgcn(general_model_cls):
             self.item_embedding = nn.Embedding(self.n_items, self.emb_size)
             rp, col, val = build_norm_adj_csr(self.n_users, self.n_items, corpus.train_clicked_set)
             # plain attributes like the reference's norm_adj (not buffers: absent from state_dict, LightGCN.py:49-51)
-            self._csr_host = (torch.from_numpy(rp), torch.from_numpy(col), torch.from_numpy(val))
+            cptr, crow = hip_ops.spmm_chunks(rp)   # rows cut into <= 32-non-zero chunks: hubs do not serialise on one team
+            self._csr_host = (cptr, crow, torch.from_numpy(col), torch.from_numpy(val))
             self._csr_dev = None
+            self._partials = None
             nn.init.xavier_uniform_(self.user_embedding.weight.data)   # LightGCN.py:52, init.py:32-48
             nn.init.xavier_uniform_(self.item_embedding.weight.data)
             name = getattr(args, "optimizer", None)
@@ -140,11 +142,13 @@ def make_lightgcn(general_model_cls):
 
         def _propagate(self, E0):
             """mean over layers of A^l E0, l = 0..L (LightGCN.py:134-143)."""
-            rp, col, val = self._csr()
+            cptr, crow, col, val = self._csr()
             acc = E0.clone()
             cur = E0
+            if self._partials is None or self._partials.device != E0.device:
+                self._partials = torch.empty((crow.numel(), E0.shape[1]), dtype=torch.float32, device=E0.device)
             for _ in range(self.gcn_layers):
-                cur = hip_ops.spmm_csr(rp, col, val, cur, acc=acc)
+                cur = hip_ops.spmm_csr_chunked(cptr, crow, col, val, cur, acc=acc, partials=self._partials)
             out = torch.empty_like(acc)
             hip_ops.axpy(out, acc, 1.0 / (self.gcn_layers + 1), overwrite=True)
             return out
