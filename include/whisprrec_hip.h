@@ -114,6 +114,25 @@ int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users
                                 const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int32_t *neg_items,
                                 int32_t *err_flag, void *stream);
 
+/* Long runs ("hot rows": an item row with more than 32 occurrences in one batch, e.g. power-law ids).  Optional second
+ * part of a plan: every such run is cut into pieces of at most 256 occurrences so that the step can sum a hot row with
+ * many workgroups instead of one 16-lane team (still in a fixed order: reproducible).  Arrays are per batch, capacities
+ * wr_bprmf_hot_caps(batch_size): piece_q/piece_len [n_batches*cap_pieces] (start inside the batch's occurrence array,
+ * length), run_q/run_first/run_np [n_batches*cap_runs] (head position, first piece, piece count); counts: int32
+ * [n_batches*2] on the DEVICE, caller-zeroed: pieces and runs per batch.  The caller copies `counts` to the host (it
+ * sizes the extra launches) and hands everything to the step calls through wr_hot_runs (NULL = none: long runs are then
+ * summed sequentially — correct, but slow on skewed data). */
+typedef struct wr_hot_runs {
+    const int32_t *piece_q, *piece_len;           /* device */
+    const int32_t *run_q, *run_first, *run_np;    /* device */
+    const int32_t *counts_host;                   /* HOST: pieces, runs per batch */
+    int64_t cap_pieces, cap_runs;
+} wr_hot_runs;
+void wr_bprmf_hot_caps(int64_t batch_size, int64_t *cap_pieces, int64_t *cap_runs);
+int32_t wr_bprmf_plan_hot_runs(const int32_t *oc_item, int64_t n_triplets, int64_t batch_size, int32_t *piece_q,
+                               int32_t *piece_len, int32_t *run_q, int32_t *run_first, int32_t *run_np, int32_t *counts,
+                               void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K1-K5 fused  One BaseRunner.fit iteration for BPRMF with torch.optim.SGD —
  *   zero_grad -> predict -> backward -> step  (BaseRunner.py:196-199, optimizer per :120-124)
@@ -129,7 +148,8 @@ int64_t wr_bprmf_step_workspace_bytes(int64_t B, int32_t D);
 int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
                           const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                           const int32_t *oc_src, int64_t B, float lr, float l2, int32_t *stamp_u, int32_t *stamp_i,
-                          int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes, void *stream);
+                          int32_t step_id, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                          int64_t workspace_bytes, void *stream);
 
 /* Runs consecutive steps over batches [first_batch, first_batch + n_batches) of a plan built with
  * `batch_size` over `n_triplets` triplets (the native inner loop of BaseRunner.fit, BaseRunner.py:194-200).
@@ -139,8 +159,8 @@ int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int
 int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
                          const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                          const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
-                         int64_t n_batches, float lr, float *loss_out, void *const *phase_events, void *workspace,
-                         int64_t workspace_bytes, void *stream);
+                         int64_t n_batches, float lr, float *loss_out, void *const *phase_events, const wr_hot_runs *hot,
+                         void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Same two kernels in gradient-emitting mode: instead of updating the tables, writes the reduced
  * gradient rows (embedding_dense_backward of BaseRunner.py:198) to grad_u[r,:] / grad_i[r,:] for rows in
@@ -149,8 +169,8 @@ int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int6
 int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item_tab, int64_t n_items, int32_t D,
                        const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                        const int32_t *oc_src, int64_t B, float *grad_u, float *grad_i, int32_t *stamp_u,
-                       int32_t *stamp_i, int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes,
-                       void *stream);
+                       int32_t *stamp_i, int32_t step_id, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                       int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K5  optimizers over a whole table — torch.optim.{SGD,Adam}.step as built at BaseRunner.py:120-124.
@@ -197,7 +217,8 @@ int32_t wr_apply_rows_sorted(float *tab, int64_t n_rows, int32_t D, const int32_
 int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,
                             const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                             const int32_t *oc_src, int64_t B, int64_t global_batch, float lr, float *grad_slots,
-                            float *loss_partial, void *workspace, int64_t workspace_bytes, void *stream);
+                            float *loss_partial, const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K6-K7  LightGCN propagation — src/models/general/LightGCN.py:134-148

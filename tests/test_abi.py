@@ -17,7 +17,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int32_t|int64_t|const char \*)\s*(wr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int32_t|int64_t|void|const char \*)\s*(wr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(3).strip()
         nargs = 0 if args in ("", "void") else len(args.split(","))
         decls[m.group(2)] = (m.group(1), nargs)
@@ -31,7 +31,7 @@ def test_header_and_binding_agree():
     for name, (ret, nargs) in decls.items():
         res, args = abi.SIGNATURES[name]
         assert len(args) == nargs, name
-        assert {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "const char *": ctypes.c_char_p}[ret] is res, name
+        assert {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "const char *": ctypes.c_char_p, "void": None}[ret] is res, name
 
 
 def test_library_exports_every_declared_symbol():

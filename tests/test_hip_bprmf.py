@@ -303,6 +303,46 @@ def test_single_hot_row_and_untouched_rows(ops, dev):
     assert np.array_equal(Ug[keep_u], U[keep_u]) and np.array_equal(Ig[keep_i], I[keep_i])
 
 
+@pytest.mark.parametrize("D", [64, 32, 128])
+def test_hot_rows_power_law_items(ops, dev, D):
+    """Power-law positives: a handful of item rows take hundreds to thousands of occurrences per batch.  Those runs are cut
+    into pieces by the plan and summed by many workgroups (bprmf_item_hot_*); result must match the oracle, be bitwise
+    reproducible, and the gradient-emitting mode must agree too."""
+    rng = np.random.RandomState(D)
+    nU, nI, B = 20000, 30000, 16384
+    U = (rng.standard_normal((nU, D)) * 0.3).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) * 0.3).astype(np.float32)
+    N = 2 * B + 1000                                            # third batch is short
+    u = rng.randint(0, nU, N)
+    p = np.minimum((rng.pareto(0.8, N) * 2).astype(np.int64), nI - 1)
+    n = rng.randint(1, nI, N)
+    n[::5] = 7                                                  # a hot NEGATIVE row as well (sign handling)
+    runs = []
+    for rep in range(2):
+        tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+        plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI)
+        assert plan.hot is not None and int(plan.hot["counts_host"].view(-1, 2)[:, 1].min()) >= 2   # every batch has hot runs
+        losses = tabs.run_sgd(plan, 0, plan.n_batches, 0.2).cpu().numpy()
+        runs.append((tabs.U.cpu().numpy().copy(), tabs.I.cpu().numpy().copy(), losses))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    Uo, Io = U.copy(), I.copy()
+    ref = [oracle.bprmf_step_sgd(Uo, Io, u[k * B:(k + 1) * B], p[k * B:(k + 1) * B], n[k * B:(k + 1) * B], 0.2, 0.0)
+           for k in range(3)]
+    assert rel_err(runs[0][2], np.asarray(ref)) < TOL
+    assert rel_err(runs[0][0], Uo) < TOL and rel_err(runs[0][1], Io) < TOL
+    # single-step entry point and gradient mode on the first batch
+    tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+    plan = ops.BatchPlan(T(u[:B], dev), T(p[:B], dev), T(n[:B], dev), B, nU, nI)
+    gU = torch.zeros_like(tabs.U); gI = torch.zeros_like(tabs.I)
+    tabs.grads(plan, 0, gU, gI)
+    rU, rI, _ = oracle.bpr_dense_grads(U, I, u[:B], p[:B], n[:B])
+    assert rel_err(gU.cpu().numpy(), rU) < TOL and rel_err(gI.cpu().numpy(), rI) < TOL
+    tabs.step_sgd(plan, 0, 0.2)
+    U1, I1 = U.copy(), I.copy()
+    oracle.bprmf_step_sgd(U1, I1, u[:B], p[:B], n[:B], 0.2, 0.0)
+    assert rel_err(tabs.I.cpu().numpy(), I1) < TOL
+
+
 def test_step_is_bitwise_reproducible(ops, dev):
     rng = np.random.RandomState(77)
     nU, nI, D, B = 5000, 3000, 64, 16384

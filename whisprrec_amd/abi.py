@@ -34,12 +34,14 @@ SIGNATURES = {
     "wr_sample_negatives_i32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp, c_vp,
                                         c_vp]),
     "wr_bprmf_step_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "wr_bprmf_hot_caps": (None, [c_i64, c_vp, c_vp]),
+    "wr_bprmf_plan_hot_runs": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_bprmf_step_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32,
-                                  c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
+                                  c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_run_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
-                                 c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+                                 c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_grads": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
-                               c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
+                               c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_sgd_decay_untouched": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_f32, c_f32, c_vp]),
     "wr_sgd_dense": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_f32, c_f32, c_vp]),
     "wr_adam_dense": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32,
@@ -49,12 +51,20 @@ SIGNATURES = {
     "wr_scatter_add_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_i64, c_vp]),
     "wr_apply_rows_sorted": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
     "wr_bprmf_shard_step": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32,
-                                    c_vp, c_vp, c_vp, c_i64, c_vp]),
+                                    c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_spmm_csr": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "wr_spmm_csr_chunked": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "wr_axpy": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_i32, c_vp]),
     "wr_embloss_sumsq": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
 }
+
+
+
+class HotRuns(ctypes.Structure):
+    """struct wr_hot_runs of include/whisprrec_hip.h"""
+    _fields_ = [("piece_q", c_vp), ("piece_len", c_vp), ("run_q", c_vp), ("run_first", c_vp), ("run_np", c_vp),
+                ("counts_host", c_vp), ("cap_pieces", c_i64), ("cap_runs", c_i64)]
+
 
 _lib = None
 

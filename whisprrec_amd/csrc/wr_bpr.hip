@@ -25,6 +25,9 @@
 
 namespace wr {
 
+constexpr int kHotRun = 32;     // an item row with more occurrences than this in one batch is "hot" (must match wr_plan.hip)
+constexpr int kHotPiece = 256;  // occurrences summed by one workgroup
+
 // ----------------------------------------------------------------------------------------------- forward only
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             const float *__restrict__ Z, float lr, float l2,
                                                             float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
                                                             const float *__restrict__ partials, int n_partials,
-                                                            float loss_denom, float *__restrict__ loss_out) {
+                                                            float loss_denom, float *__restrict__ loss_out, int skip_hot) {
     __shared__ float scratch[kBlock / 64];
     __shared__ int heads[kBlock];
     __shared__ int item_tile[kBlock + 8];  // oc_item of this tile plus up to 8 entries beyond it
@@ -256,6 +259,8 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
     for (int h = threadIdx.x / T; h < nh; h += TEAMS) {
         const int j0 = heads[h];
         const int r = item_tile[j0];
+        // runs longer than kHotRun are cut into pieces by the plan and summed by bprmf_item_hot_* (many workgroups)
+        if (skip_hot && tile0 + j0 + kHotRun < B2 && oc_item[tile0 + j0 + kHotRun] == r) continue;
         {
             const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
             const int s0 = src_tile[j0], s1 = src_tile[j0 + 1];
@@ -313,6 +318,89 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
     }
 }
 
+// ----------------------------------------------------------------------------------------------- hot rows
+// A piece = up to kHotPiece consecutive occurrences of ONE item row.  One workgroup per piece: team j sums occurrences
+// j, j+TEAMS, ... (next one prefetched), the TEAMS partial rows are added in team order through LDS.
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void bprmf_item_hot_pieces(int D, const int *__restrict__ oc_src, const float *__restrict__ Z,
+                                                                 const int *__restrict__ piece_q, const int *__restrict__ piece_len,
+                                                                 float *__restrict__ hotP) {
+    extern __shared__ float rows[];  // [TEAMS][D]
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T, team = threadIdx.x / T;
+    const int q0 = piece_q[blockIdx.x], len = piece_len[blockIdx.x];
+    Row<NV> g;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = team;
+    int src = (k < len) ? oc_src[q0 + k] : 0;
+    Row<NV> z = (k < len) ? load_row<T, NV, FULL>(Z, src >> 1, D, lane) : g;
+    while (k < len) {
+        const int kn = k + TEAMS;
+        int src_n = 0;
+        Row<NV> zn = g;
+        if (kn < len) {
+            src_n = oc_src[q0 + kn];
+            zn = load_row<T, NV, FULL>(Z, src_n >> 1, D, lane);
+        }
+        const float sgn = (src & 1) ? -1.0f : 1.0f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            g.v[c].x = fmaf(sgn, z.v[c].x, g.v[c].x); g.v[c].y = fmaf(sgn, z.v[c].y, g.v[c].y);
+            g.v[c].z = fmaf(sgn, z.v[c].z, g.v[c].z); g.v[c].w = fmaf(sgn, z.v[c].w, g.v[c].w);
+        }
+        k = kn; src = src_n; z = zn;
+    }
+    store_row<T, NV, FULL>(rows, team, D, lane, g);
+    __syncthreads();
+    for (int c = threadIdx.x; c * 4 < D; c += kBlock) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < TEAMS; ++j) {
+            const float4 v = reinterpret_cast<const float4 *>(rows + (int64_t)j * D)[c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4 *>(hotP + (int64_t)blockIdx.x * D)[c] = a;
+    }
+}
+
+// One team per hot row: adds its pieces in piece order and finishes the row like the item phase does.
+template <int T, int NV, bool FULL, int MODE>
+__global__ __launch_bounds__(kBlock) void bprmf_item_hot_combine(float *__restrict__ I, int D, const int *__restrict__ oc_item,
+                                                                  const int *__restrict__ run_q, const int *__restrict__ run_first,
+                                                                  const int *__restrict__ run_np, int n_runs,
+                                                                  const float *__restrict__ hotP, float lr, float l2,
+                                                                  float *__restrict__ gradI, int *__restrict__ stampI, int step_id) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int h = blockIdx.x * TEAMS + threadIdx.x / T;
+    if (h >= n_runs) return;
+    const int r = oc_item[run_q[h]];
+    const int first = run_first[h], np = run_np[h];
+    Row<NV> g = load_row<T, NV, FULL>(hotP, first, D, lane);
+    for (int k = 1; k < np; ++k) {
+        const Row<NV> x = load_row<T, NV, FULL>(hotP, first + k, D, lane);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            g.v[c].x += x.v[c].x; g.v[c].y += x.v[c].y; g.v[c].z += x.v[c].z; g.v[c].w += x.v[c].w;
+        }
+    }
+    if (MODE == 0) {
+        const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
+        Row<NV> w;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            w.v[c].x = ir.v[c].x - lr * fmaf(l2, ir.v[c].x, g.v[c].x);
+            w.v[c].y = ir.v[c].y - lr * fmaf(l2, ir.v[c].y, g.v[c].y);
+            w.v[c].z = ir.v[c].z - lr * fmaf(l2, ir.v[c].z, g.v[c].z);
+            w.v[c].w = ir.v[c].w - lr * fmaf(l2, ir.v[c].w, g.v[c].w);
+        }
+        store_row<T, NV, FULL>(I, r, D, lane, w);
+    } else {
+        store_row<T, NV, FULL>(gradI, r, D, lane, g);
+    }
+    if (stampI != nullptr && lane == 0) stampI[r] = step_id;
+}
+
 // ----------------------------------------------------------------------------------------------- host side
 static inline int teams_per_block(int D) {
     if (D >= 64) return kBlock / 16;
@@ -330,18 +418,42 @@ static inline int64_t n_blocks_for(int64_t n_teams, int D) {
 struct StepWs {
     float *Z;
     float *partials;
+    float *hotP;
     int64_t n_partials;
 };
 
+static inline int64_t hot_cap_pieces(int64_t B) { return 2 * B / kHotPiece + 2 * B / kHotRun + 8; }
+static inline int64_t hot_cap_runs(int64_t B) { return 2 * B / kHotRun + 8; }
+
+struct HotBatch {  // hot runs of ONE batch (device pointers already offset), counts from the host copy
+    const int32_t *piece_q, *piece_len, *run_q, *run_first, *run_np;
+    int n_pieces, n_runs;
+};
+
+static inline HotBatch hot_of(const wr_hot_runs *hot, int64_t batch) {
+    HotBatch h{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (hot == nullptr || hot->counts_host == nullptr) return h;
+    h.n_pieces = hot->counts_host[2 * batch];
+    h.n_runs = hot->counts_host[2 * batch + 1];
+    h.piece_q = hot->piece_q + batch * hot->cap_pieces;
+    h.piece_len = hot->piece_len + batch * hot->cap_pieces;
+    h.run_q = hot->run_q + batch * hot->cap_runs;
+    h.run_first = hot->run_first + batch * hot->cap_runs;
+    h.run_np = hot->run_np + batch * hot->cap_runs;
+    return h;
+}
+
 static inline int64_t step_ws_bytes(int64_t B, int32_t D) {
     // Z stash [B, D] + loss partials (one per user-phase block; bounded by B for the smallest team count)
-    return align_up(B * (int64_t)D * 4, 256) + align_up(n_blocks_for(B, D) * 4, 256);
+    return align_up(B * (int64_t)D * 4, 256) + align_up(n_blocks_for(B, D) * 4, 256) +
+           align_up(hot_cap_pieces(B) * (int64_t)D * 4, 256);
 }
 
 static inline StepWs carve_step_ws(void *workspace, int64_t B, int32_t D) {
     StepWs w;
     w.Z = reinterpret_cast<float *>(workspace);
     w.partials = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + align_up(B * (int64_t)D * 4, 256));
+    w.hotP = reinterpret_cast<float *>(reinterpret_cast<char *>(w.partials) + align_up(n_blocks_for(B, D) * 4, 256));
     w.n_partials = n_blocks_for(B, D);
     return w;
 }
@@ -350,10 +462,16 @@ template <int MODE>
 static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
                            const int32_t *oc_item, const int32_t *oc_src, int64_t B, float lr, float l2, float *gradU,
                            float *gradI, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id, float *loss_out,
-                           void *workspace, hipStream_t stream, void *const *events = nullptr, float denom = 0.f) {
+                           void *workspace, hipStream_t stream, void *const *events = nullptr, float denom = 0.f,
+                           HotBatch hot = HotBatch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
+                           int64_t ws_batch = 0) {
     if (denom <= 0.f) denom = (float)B;  // single-device step: mean over this batch
-    const StepWs w = carve_step_ws(workspace, B, D);
+    if (ws_batch <= 0) ws_batch = B;     // the workspace was sized for the plan's batch size (>= this batch)
+    const StepWs w = carve_step_ws(workspace, ws_batch, D);
     const dim3 block(kBlock);
+    const bool have_hot = hot.n_runs > 0 && hot.n_pieces > 0;
+    WR_REQUIRE(!have_hot || (hot.n_pieces <= hot_cap_pieces(ws_batch) && hot.n_runs <= hot_cap_runs(ws_batch)), WR_E_RANGE,
+               "hot-run counts exceed their capacity");
     // SLOTS = 1: two positions per team (twice the loads in flight, one resident round of workgroups at B = 65,536) was
     // A/B-tested on MI355X and is ~4 % slower — the kernel is bound by the memory system's random 256-B row rate, not by
     // bytes in flight.
@@ -370,10 +488,24 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
     hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
                        (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)gridA.x, denom,         \
-                       loss_out)
+                       loss_out, have_hot ? 1 : 0)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
     WR_LAUNCH_CHECK("bprmf_item_phase");
+    if (have_hot) {
+        const size_t lds = (size_t)teams_per_block(D) * D * 4;
+        const unsigned grun = (unsigned)n_blocks_for(hot.n_runs, D);
+#define WR_CALL_HOT(T_, NV_, FULL_)                                                                                      \
+    do {                                                                                                                \
+        hipLaunchKernelGGL((bprmf_item_hot_pieces<T_, NV_, FULL_>), dim3((unsigned)hot.n_pieces), block, lds, stream, D,  \
+                           oc_src, w.Z, hot.piece_q, hot.piece_len, w.hotP);                                            \
+        hipLaunchKernelGGL((bprmf_item_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, I, D, oc_item,  \
+                           hot.run_q, hot.run_first, hot.run_np, hot.n_runs, w.hotP, lr, l2, gradI, stamp_i, step_id);   \
+    } while (0)
+        WR_DISPATCH_D(D, WR_CALL_HOT);
+#undef WR_CALL_HOT
+        WR_LAUNCH_CHECK("bprmf_item_hot_*");
+    }
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[2]), stream));
     return WR_OK;
 }
@@ -422,10 +554,16 @@ int32_t wr_bpr_fwd(const float *user_tab, int64_t n_users, const float *item_tab
 
 int64_t wr_bprmf_step_workspace_bytes(int64_t B, int32_t D) { return step_ws_bytes(B, D); }
 
+void wr_bprmf_hot_caps(int64_t batch_size, int64_t *cap_pieces, int64_t *cap_runs) {
+    if (cap_pieces) *cap_pieces = hot_cap_pieces(batch_size);
+    if (cap_runs) *cap_runs = hot_cap_runs(batch_size);
+}
+
 int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
                           const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                           const int32_t *oc_src, int64_t B, float lr, float l2, int32_t *stamp_u, int32_t *stamp_i,
-                          int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes, void *stream_) {
+                          int32_t step_id, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                          int64_t workspace_bytes, void *stream_) {
     int32_t rc;
     if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
     if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
@@ -434,14 +572,15 @@ int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int
     WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
                "wr_bprmf_step_sgd: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
     return launch_step<0>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, B, lr, l2, nullptr, nullptr, stamp_u,
-                          stamp_i, step_id, loss_out, workspace, reinterpret_cast<hipStream_t>(stream_));
+                          stamp_i, step_id, loss_out, workspace, reinterpret_cast<hipStream_t>(stream_), nullptr, 0.f,
+                          hot_of(hot, 0));
 }
 
 int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
                          const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                          const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
-                         int64_t n_batches, float lr, float *loss_out, void *const *phase_events, void *workspace,
-                         int64_t workspace_bytes, void *stream_) {
+                         int64_t n_batches, float lr, float *loss_out, void *const *phase_events, const wr_hot_runs *hot,
+                         void *workspace, int64_t workspace_bytes, void *stream_) {
     int32_t rc;
     if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
     if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
@@ -460,7 +599,8 @@ int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int6
         const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
         rc = launch_step<0>(user_tab, item_tab, D, tu + off, tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk,
                             lr, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, loss_out ? loss_out + k : nullptr,
-                            workspace, stream, phase_events ? phase_events + 3 * k : nullptr);
+                            workspace, stream, phase_events ? phase_events + 3 * k : nullptr, 0.f, hot_of(hot, b),
+                            batch_size);
         if (rc != WR_OK) return rc;
     }
     return WR_OK;
@@ -469,8 +609,8 @@ int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int6
 int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item_tab, int64_t n_items, int32_t D,
                        const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                        const int32_t *oc_src, int64_t B, float *grad_u, float *grad_i, int32_t *stamp_u,
-                       int32_t *stamp_i, int32_t step_id, float *loss_out, void *workspace, int64_t workspace_bytes,
-                       void *stream_) {
+                       int32_t *stamp_i, int32_t step_id, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                       int64_t workspace_bytes, void *stream_) {
     int32_t rc;
     if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
     if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
@@ -482,13 +622,14 @@ int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item
     // MODE 1 never writes the tables; the const_cast only serves the shared kernel signature.
     return launch_step<1>(const_cast<float *>(user_tab), const_cast<float *>(item_tab), D, tu, tp, tn, oc_item, oc_src, B,
                           0.f, 0.f, grad_u, grad_i, stamp_u, stamp_i, step_id, loss_out, workspace,
-                          reinterpret_cast<hipStream_t>(stream_));
+                          reinterpret_cast<hipStream_t>(stream_), nullptr, 0.f, hot_of(hot, 0));
 }
 
 int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,
                             const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                             const int32_t *oc_src, int64_t B, int64_t global_batch, float lr, float *grad_slots,
-                            float *loss_partial, void *workspace, int64_t workspace_bytes, void *stream_) {
+                            float *loss_partial, const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes,
+                            void *stream_) {
     int32_t rc;
     if ((rc = check_table(user_shard, n_user_rows, D, "user_shard")) != WR_OK) return rc;
     if ((rc = check_table(item_rows, n_slots, D, "item_rows")) != WR_OK) return rc;
@@ -500,7 +641,7 @@ int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float 
     // MODE 2 never writes item_rows; the const_cast only serves the shared kernel signature.
     return launch_step<2>(user_shard, const_cast<float *>(item_rows), D, tu, tp, tn, oc_item, oc_src, B, lr, 0.f, nullptr,
                           grad_slots, nullptr, nullptr, 0, loss_partial, workspace, reinterpret_cast<hipStream_t>(stream_),
-                          nullptr, (float)global_batch);
+                          nullptr, (float)global_batch, hot_of(hot, 0));
 }
 
 }  // extern "C"

@@ -124,8 +124,12 @@ class BatchPlan:
         self.tu, self.tp, self.tn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
         self.torig = torch.empty(N, **i32) if keep_orig else None
         self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
-        self.flags = torch.zeros(2, **i32)      # [0] index out of range, [1] fast-builder bucket overflow
+        # one small tensor read back per plan: [0] index out of range, [1] fast-builder bucket overflow, then per batch
+        # the number of hot-run pieces and hot runs (wr_bprmf_plan_hot_runs)
+        self.meta = torch.zeros(2 + 2 * self.n_batches, **i32)
+        self.flags = self.meta[:2]
         self.err = self.flags[:1]
+        self.hot = None
         self.builder = None
         args = (N, self.batch_size, self.n_users, self.n_items)
         if builder in ("auto", "fast"):
@@ -152,12 +156,45 @@ class BatchPlan:
                          _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(), _stream()),
                       "wr_bprmf_plan_build")
             self.builder = "generic"
+        self._plan_hot_runs(dev)
         if validate:
             self.validate()
 
+    def _plan_hot_runs(self, dev):
+        """Cuts item rows with more than 32 occurrences in a batch into pieces for the many-workgroup path (power-law
+        ids); one device-to-host copy of the small meta tensor tells whether there are any."""
+        L = abi.lib()
+        cp, cr = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.wr_bprmf_hot_caps(self.batch_size, ctypes.addressof(cp), ctypes.addressof(cr))
+        cp, cr = cp.value, cr.value
+        i32 = dict(dtype=torch.int32, device=dev)
+        arrs = [torch.empty(self.n_batches * cp, **i32), torch.empty(self.n_batches * cp, **i32),
+                torch.empty(self.n_batches * cr, **i32), torch.empty(self.n_batches * cr, **i32),
+                torch.empty(self.n_batches * cr, **i32)]
+        counts = self.meta[2:]
+        abi.check(L.wr_bprmf_plan_hot_runs(_p(self.oc_item), self.n_triplets, self.batch_size, *[_p(a) for a in arrs],
+                                           _p(counts), _stream()), "wr_bprmf_plan_hot_runs")
+        self.meta_host = self.meta.cpu()
+        counts_host = self.meta_host[2:].contiguous()
+        if int(counts_host.sum().item()) > 0:
+            self.hot = {"arrs": arrs, "counts_host": counts_host, "cap_pieces": cp, "cap_runs": cr}
+
+    def hot_struct(self, batch=None):
+        """ctypes wr_hot_runs for the whole plan (batch=None) or for one batch; None when the plan has no hot runs."""
+        if self.hot is None:
+            return None
+        h = self.hot
+        k = 0 if batch is None else batch
+        cp, cr = h["cap_pieces"], h["cap_runs"]
+        a = h["arrs"]
+        st = abi.HotRuns(a[0].data_ptr() + 4 * k * cp, a[1].data_ptr() + 4 * k * cp, a[2].data_ptr() + 4 * k * cr,
+                         a[3].data_ptr() + 4 * k * cr, a[4].data_ptr() + 4 * k * cr,
+                         h["counts_host"].data_ptr() + 8 * k, cp, cr)
+        return st
+
     def validate(self):
         """nn.Embedding raises IndexError for out-of-range ids; so does the plan (one sync)."""
-        if int(self.err.item()) != 0:
+        if int(self.meta_host[0].item()) != 0:
             raise IndexError("index out of range in batch (user_id >= n_users or item id >= n_items)")
 
     def batch_len(self, k):
@@ -205,8 +242,10 @@ class BprmfTables:
         self.step_id += 1
         if l2 != 0.0:
             su, si = self._stamps()
+        hot = plan.hot_struct(k)
         abi.check(L.wr_bprmf_step_sgd(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, tu, tp, tn, oi,
-                                      os_, B, lr, l2, _p(su), _p(si), self.step_id, _p(loss_out), _p(ws), ws.numel(),
+                                      os_, B, lr, l2, _p(su), _p(si), self.step_id, _p(loss_out),
+                                      ctypes.addressof(hot) if hot is not None else None, _p(ws), ws.numel(),
                                       _stream()), "wr_bprmf_step_sgd")
         if l2 != 0.0:  # dense weight decay on the rows the batch did not touch (torch.optim.SGD semantics)
             abi.check(L.wr_sgd_decay_untouched(_p(self.U), self.U.shape[0], self.D, _p(su), self.step_id, lr, l2,
@@ -224,6 +263,7 @@ class BprmfTables:
         ws = self._ws(plan.batch_size)
         if losses is None:
             losses = torch.empty(count, dtype=torch.float32, device=self.dev)
+        hot = plan.hot_struct()
         ev = None
         if phase_events is not None:
             if len(phase_events) != 3 * count:
@@ -237,7 +277,8 @@ class BprmfTables:
         abi.check(L.wr_bprmf_run_sgd(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(plan.tu),
                                      _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets,
                                      plan.batch_size, first, count, lr, _p(losses),
-                                     ctypes.addressof(ev) if ev is not None else None, _p(ws), ws.numel(), _stream()),
+                                     ctypes.addressof(ev) if ev is not None else None,
+                                     ctypes.addressof(hot) if hot is not None else None, _p(ws), ws.numel(), _stream()),
                   "wr_bprmf_run_sgd")
         self.step_id += count
         return losses
@@ -252,9 +293,11 @@ class BprmfTables:
         if loss_out is None:
             loss_out = torch.empty((), dtype=torch.float32, device=self.dev)
         self.step_id += 1
+        hot = plan.hot_struct(k)
         abi.check(L.wr_bprmf_grads(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, tu, tp, tn, oi, os_,
-                                   B, _p(grad_u), _p(grad_i), _p(su), _p(si), self.step_id, _p(loss_out), _p(ws),
-                                   ws.numel(), _stream()), "wr_bprmf_grads")
+                                   B, _p(grad_u), _p(grad_i), _p(su), _p(si), self.step_id, _p(loss_out),
+                                   ctypes.addressof(hot) if hot is not None else None, _p(ws), ws.numel(), _stream()),
+                  "wr_bprmf_grads")
         return loss_out, self.step_id
 
 

@@ -52,12 +52,15 @@ class HipBackend:
         B = plan.batch_len(k)
         nbytes = self.abi.check_size(L.wr_bprmf_step_workspace_bytes(plan.batch_size, U.shape[1]), "workspace")
         ws = ops.workspace(U.device, "step").get(nbytes)
+        import ctypes
+        hot = plan.hot_struct(k)
         self.abi.check(L.wr_bprmf_shard_step(U.data_ptr(), U.shape[0], item_rows.data_ptr(), item_rows.shape[0], U.shape[1],
                                              plan.tu.data_ptr() + 4 * off, plan.tp.data_ptr() + 4 * off,
                                              plan.tn.data_ptr() + 4 * off, plan.oc_item.data_ptr() + 8 * off,
                                              plan.oc_src.data_ptr() + 8 * off, B, global_batch, lr, grad_slots.data_ptr(),
-                                             loss_out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             torch.cuda.current_stream().cuda_stream), "wr_bprmf_shard_step")
+                                             loss_out.data_ptr(), ctypes.addressof(hot) if hot is not None else None,
+                                             ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                       "wr_bprmf_shard_step")
 
     def apply_sorted(self, tab, sorted_rows, perm, src, alpha):
         self.abi.check(self.abi.lib().wr_apply_rows_sorted(tab.data_ptr(), tab.shape[0], tab.shape[1], sorted_rows.data_ptr(),
