@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__rest
 // loads of all slots, then the slots are finished one after the other — twice the bytes in flight per team and a grid
 // that fits the chip in one resident round at the headline batch size.
 template <int T, int NV, bool FULL, int MODE, int SLOTS>
-__global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
+__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0) ? 8 : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
                                                             const int *__restrict__ tn, int B, float lr, float l2,
                                                             float *__restrict__ Z, float *__restrict__ partials,
@@ -130,12 +130,10 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
             const bool p_shared = praw < 0, n_shared = nraw < 0;
             const int tnext = t + 1;
             more = (tnext < B) && (tu[tnext] == u);
-            Row<NV> pr_next, nr_next;
-            if (more) {  // next triplet of this user: indices and rows requested before the dot / transcendentals
-                praw = tp[tnext];
-                nraw = tn[tnext];
-                pr_next = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
-                nr_next = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
+            int praw_next = 0, nraw_next = 0;
+            if (more) {  // indices of the next triplet of this user, requested before the dot / transcendentals
+                praw_next = tp[tnext];
+                nraw_next = tn[tnext];
             }
             const float sp = team_sum<T>(dot_partial<NV>(ur[s], pr));
             const float sn = team_sum<T>(dot_partial<NV>(ur[s], nr));
@@ -187,9 +185,11 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_phase(float *__restrict__ U
             }
             if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
             t = tnext;
-            if (more) {
-                pr = pr_next;
-                nr = nr_next;
+            if (more) {  // rows of the next triplet (loaded only now: keeps the kernel at 8 waves per SIMD)
+                praw = praw_next;
+                nraw = nraw_next;
+                pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
+                nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
             }
         } while (more);
         if (MODE != 1) {
