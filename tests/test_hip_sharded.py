@@ -64,3 +64,27 @@ def test_shard_step_global_batch_scaling(pg):
     assert abs(losses[0] - lo / 4) / (lo / 4) < 1e-5
     Uf, If = m.gather_full()
     assert rel_err(Uf.cpu().numpy(), Uo) < 1e-5 and rel_err(If.cpu().numpy(), Io) < 1e-5
+
+
+def test_plan_slots_equals_generic_slotify(pg):
+    """HipBackend.plan_slots (slots from the batch plan's sort) must give the unique-key lists and slot ids of the
+    torch.unique restatement that the CPU/gloo tests exercise"""
+    from whisprrec_amd.sharded import HipBackend, slotify_generic
+    dev = pg
+    rng = np.random.RandomState(5)
+    G, nI, nUloc, B, N = 4, 5003, 700, 1024, 3 * 1024 + 300
+    M = (nI + G - 1) // G
+    u_loc = torch.from_numpy(rng.randint(0, nUloc, N)).to(dev)
+    p = torch.from_numpy(np.minimum((rng.pareto(1.0, N) * 40).astype(np.int64), nI - 1)).to(dev)
+    n = torch.from_numpy(rng.randint(1, nI, N)).to(dev)
+    rk_p, rk_n = (p % G) * M + p // G, (n % G) * M + n // G
+    sp, sn, key, step, nq = slotify_generic(u_loc, rk_p, rk_n, B, G * M)
+    plan, key2, step2, nq2 = HipBackend().plan_slots(u_loc, rk_p, rk_n, B, nUloc, G * M)
+    assert torch.equal(key, key2) and torch.equal(step, step2) and torch.equal(nq, nq2)
+    # the plan is sorted by user: undo through the slots it carries
+    tp = (plan.tp & 0x7FFFFFFF).cpu().numpy(); tn = (plan.tn & 0x7FFFFFFF).cpu().numpy(); tu = plan.tu.cpu().numpy()
+    for k in range(plan.n_batches):
+        lo, hi = k * B, min(N, (k + 1) * B)
+        order = lo + np.argsort(u_loc.cpu().numpy()[lo:hi], kind="stable")
+        assert np.array_equal(tu[lo:hi], u_loc.cpu().numpy()[order])
+        assert np.array_equal(tp[lo:hi], sp.cpu().numpy()[order]) and np.array_equal(tn[lo:hi], sn.cpu().numpy()[order])

@@ -19,11 +19,13 @@ class OracleBackend:
     class _Plan:
         pass
 
-    def prepare_chunk(self, u_loc, slot_p, slot_n, batch, n_user_rows, max_slots):
+    def plan_slots(self, u_loc, rk_p, rk_n, batch, n_user_rows, GM):
+        from whisprrec_amd.sharded import slotify_generic
+        slot_p, slot_n, u_key, u_step, nq = slotify_generic(u_loc, rk_p, rk_n, batch, GM)
         pl = self._Plan()
         pl.u, pl.p, pl.n, pl.batch_size = u_loc.numpy(), slot_p.numpy(), slot_n.numpy(), batch
-        assert pl.u.max() < n_user_rows and max(pl.p.max(), pl.n.max()) < max_slots
-        return pl
+        assert pl.u.max() < n_user_rows
+        return pl, u_key, u_step, nq
 
     def gather_rows(self, tab, idx):
         return torch.from_numpy(oracle.gather_rows(tab.numpy(), idx.numpy()))

@@ -31,6 +31,21 @@ import torch
 import torch.distributed as dist
 
 
+def slotify_generic(u_loc, rk_p, rk_n, batch, GM):
+    """Per step: unique routed item keys (ascending) and the slot (rank of its key inside the step) of every occurrence.
+    Device-agnostic restatement with torch.unique; HipBackend.slotify gets the same result from the batch plan's sort.
+    Returns (slot_p, slot_n, uniq_key, uniq_step, nq)."""
+    dev = u_loc.device
+    N = u_loc.numel()
+    nb = (N + batch - 1) // batch
+    step_of = torch.arange(N, device=dev) // batch
+    ck = torch.cat([step_of * GM + rk_p, step_of * GM + rk_n])
+    uniq, inv = torch.unique(ck, return_inverse=True)                      # sorted by (step, routed key)
+    step_starts = torch.searchsorted(uniq, torch.arange(nb + 1, device=dev) * GM)
+    slots = inv - step_starts[torch.cat([step_of, step_of])]
+    return slots[:N], slots[N:], uniq % GM, uniq // GM, step_starts[1:] - step_starts[:-1]
+
+
 class HipBackend:
     """Local compute through the C-ABI.  (Tests substitute an oracle-backed object with the same methods to exercise
     the exchange logic on CPU/gloo; the product never does.)"""
@@ -39,9 +54,38 @@ class HipBackend:
         from . import abi, hip_ops
         self.abi, self.ops = abi, hip_ops
 
-    def prepare_chunk(self, u_loc, slot_p, slot_n, batch, n_user_rows, max_slots):
-        return self.ops.BatchPlan(u_loc.to(torch.int32), slot_p.to(torch.int32), slot_n.to(torch.int32), batch, n_user_rows,
-                                  max_slots, validate=True)
+    def plan_slots(self, u_loc, rk_p, rk_n, batch, n_user_rows, GM):
+        """Batch plan + slot ids in one go: the plan is built on the ROUTED item keys (a bijection of item ids, so runs and
+        flags are the same), the heads of the sorted runs are the step's unique keys, a prefix sum over the head flags
+        gives every occurrence its slot, and tp/tn/oc_item are rewritten from keys to slots.  The sort is the plan
+        builder's (hand-written kernels); what is left here is flag/prefix/scatter glue on int32 vectors."""
+        dev = u_loc.device
+        N, B = u_loc.numel(), batch
+        plan = self.ops.BatchPlan(u_loc.to(torch.int32), rk_p.to(torch.int32), rk_n.to(torch.int32), B, n_user_rows, GM,
+                                  validate=True)
+        nb = plan.n_batches
+        oi = plan.oc_item
+        pos = torch.arange(2 * N, device=dev)
+        bidx = pos // (2 * B)
+        head = torch.ones(2 * N, dtype=torch.bool, device=dev)
+        head[1:] = oi[1:] != oi[:-1]
+        head[bidx * (2 * B) == pos] = True
+        csum = torch.cumsum(head.to(torch.int32), 0)
+        slot = (csum - csum[bidx * (2 * B)]).to(torch.int32)               # 0-based rank of the run inside its batch
+        uniq_key = oi[head].to(torch.int64)
+        uniq_step = bidx[head]
+        nq = torch.bincount(uniq_step, minlength=nb)
+        t_idx = bidx * B + (plan.oc_src >> 1).to(torch.int64)
+        neg_side = (plan.oc_src & 1).bool()
+        slot_p = torch.empty(N, dtype=torch.int32, device=dev)
+        slot_n = torch.empty(N, dtype=torch.int32, device=dev)
+        slot_p[t_idx[~neg_side]] = slot[~neg_side]
+        slot_n[t_idx[neg_side]] = slot[neg_side]
+        flag = torch.tensor(-2 ** 31, dtype=torch.int32, device=dev)
+        plan.tp = (plan.tp & flag) | slot_p                                    # keep bit 31 (several occurrences), swap key for slot
+        plan.tn = (plan.tn & flag) | slot_n
+        plan.oc_item = slot.contiguous()
+        return plan, uniq_key, uniq_step, nq
 
     def gather_rows(self, tab, idx):
         return self.ops.gather_rows(tab, idx)
@@ -123,24 +167,13 @@ class ShardedBprmf:
         N = u.numel()
         nb = (N + batch - 1) // batch
         u, p, n = u.to(torch.int64), p.to(torch.int64), n.to(torch.int64)
-        step_of = torch.arange(N, device=dev) // batch
-        # routed key of an item: (owner, local row); composite with the step so one unique() serves the whole chunk
-        def routed(x):
-            return (x % G) * M + x // G
         GM = G * M
-        ck = torch.cat([step_of * GM + routed(p), step_of * GM + routed(n)])
-        uniq, inv = torch.unique(ck, return_inverse=True)                      # sorted by (step, owner, local row)
-        step_starts = torch.searchsorted(uniq, torch.arange(nb + 1, device=dev) * GM)   # first uniq index of each step
-        slots = inv - step_starts[torch.cat([step_of, step_of])]
-        slot_p, slot_n = slots[:N], slots[N:]
-        nq = (step_starts[1:] - step_starts[:-1])                              # unique items per step
-        bounds = (torch.arange(nb, device=dev)[:, None] * GM + torch.arange(G + 1, device=dev)[None, :] * M).reshape(-1)
-        cuts = torch.searchsorted(uniq, bounds).reshape(nb, G + 1)
-        req_counts = (cuts[:, 1:] - cuts[:, :-1])                              # [nb, G] rows requested from each owner
+        # routed key of an item: (owner, local row) — a bijection of the item id that makes each owner's rows contiguous
+        rk_p, rk_n = (p % G) * M + p // G, (n % G) * M + n // G
+        local_plan, u_key, u_step, nq = self.backend.plan_slots(u // G, rk_p, rk_n, batch, self.U.shape[0], GM)
+        u_owner, u_row = u_key // M, u_key % M
+        req_counts = torch.bincount(u_step * G + u_owner, minlength=nb * G).reshape(nb, G)   # rows requested per owner
         # ---- exchange the request lists of the whole chunk: destination-major, then step
-        u_owner = (uniq % GM) // M
-        u_step = uniq // GM
-        u_row = (uniq % GM) % M
         order = torch.sort(u_owner * nb + u_step, stable=True)[1]
         send_rows = u_row[order]
         send_counts = req_counts.t().contiguous()                              # [G, nb]
@@ -150,26 +183,31 @@ class ShardedBprmf:
         recv_tot = recv_counts.sum(1).tolist()
         recv_rows = torch.empty(int(sum(recv_tot)), dtype=torch.int64, device=dev)
         dist.all_to_all_single(recv_rows, send_rows, output_split_sizes=recv_tot, input_split_sizes=send_tot, group=self.group)
-        # recv_rows is (source, step)-major; per step we serve the concatenation over sources
+        # recv_rows is (source, step)-major; per step we serve the concatenation over sources: one stable sort by step
+        # regroups the whole chunk, a second one (by (step, row)) fixes every step's summation order
         rc = recv_counts.cpu()                                                 # [G, nb]
-        src_off = torch.zeros(G, nb + 1, dtype=torch.int64)
-        src_off[:, 1:] = torch.cumsum(rc, 1)
-        base = torch.zeros(G, dtype=torch.int64)
-        base[1:] = torch.cumsum(rc.sum(1), 0)[:-1]
+        seg_step = torch.arange(nb, device=dev).repeat(G)                      # step of each (source, step) segment
+        recv_step = torch.repeat_interleave(seg_step, recv_counts.reshape(-1))
+        order1 = torch.sort(recv_step, stable=True)[1]
+        serve_all = recv_rows[order1]                                          # step-major, sources in rank order inside a step
+        step_sorted = recv_step[order1]
+        serve_cnt = rc.sum(0)                                                  # rows served per step
+        serve_off = torch.zeros(nb + 1, dtype=torch.int64)
+        serve_off[1:] = torch.cumsum(serve_cnt, 0)
+        L = max(int(self.I.shape[0]), 1)
+        srt_key, order2 = torch.sort(step_sorted * L + serve_all, stable=True)
+        apply_rows_all = (srt_key % L).to(torch.int32)
+        apply_perm_all = (order2 - serve_off.to(dev)[step_sorted]).to(torch.int32)   # sorting keeps every element in its step
         cp = ChunkPlan()
         cp.nb, cp.batch, cp.N = nb, batch, N
-        cp.local = self.backend.prepare_chunk(u // G, slot_p, slot_n, batch, self.U.shape[0], int(nq.max().item()))
+        cp.local = local_plan
         cp.nq = nq.tolist()
         cp.req_splits = req_counts.tolist()                                    # [nb][G] what I receive from owner d
         cp.serve_splits = rc.t().contiguous().tolist()                         # [nb][G] what I send to requester s
-        cp.serve_rows, cp.apply_rows, cp.apply_perm = [], [], []
-        for k in range(nb):
-            segs = [recv_rows[int(base[s] + src_off[s, k]): int(base[s] + src_off[s, k + 1])] for s in range(G)]
-            rows_k = torch.cat(segs) if segs else recv_rows[:0]
-            cp.serve_rows.append(rows_k)
-            srt, perm = torch.sort(rows_k, stable=True)
-            cp.apply_rows.append(srt.to(torch.int32))
-            cp.apply_perm.append(perm.to(torch.int32))
+        so = serve_off.tolist()
+        cp.serve_rows = [serve_all[so[k]:so[k + 1]] for k in range(nb)]
+        cp.apply_rows = [apply_rows_all[so[k]:so[k + 1]] for k in range(nb)]
+        cp.apply_perm = [apply_perm_all[so[k]:so[k + 1]] for k in range(nb)]
         cp.max_nq = max(cp.nq) if cp.nq else 0
         cp.max_serve = max((r.numel() for r in cp.serve_rows), default=0)
         return cp
