@@ -242,6 +242,14 @@ int32_t wr_embloss_sumsq(const float *user_tab, const float *item_tab, int32_t D
                          const int64_t *n, int64_t B, float *sq3, void *workspace, int64_t workspace_bytes,
                          void *stream);
 
+/* Backward of EmbLoss for one planned batch: grad_user[u,:] += m_u * w/(B*sqrt(sq3[0])) * user_tab[u,:] for a user with m_u
+ * triplets in the batch; grad_item[r,:] += (m_pos * w/(B*sqrt(sq3[1])) + m_neg * w/(B*sqrt(sq3[2]))) * item_tab[r,:].
+ * tu / oc_item / oc_src are the plan arrays of that batch (oc_item must hold plain row ids), sq3 the device output of
+ * wr_embloss_sumsq: no host round trip. */
+int32_t wr_embloss_grad(const float *user_tab, const float *item_tab, int32_t D, const int32_t *tu, const int32_t *oc_item,
+                        const int32_t *oc_src, int64_t B, const float *sq3, float reg_weight, float *grad_user,
+                        float *grad_item, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

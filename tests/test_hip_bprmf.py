@@ -343,6 +343,42 @@ def test_hot_rows_power_law_items(ops, dev, D):
     assert rel_err(tabs.I.cpu().numpy(), I1) < TOL
 
 
+@pytest.mark.parametrize("case", range(12))
+def test_random_shapes_vs_oracle(ops, dev, case):
+    """seeded random table sizes, embedding sizes, batch sizes and id distributions (uniform, clustered, power-law, with a
+    short last batch) through plan + multi-step driver, against the oracle; both plan builders must give the same bits"""
+    rng = np.random.RandomState(1000 + case)
+    D = int(rng.choice([4, 8, 12, 16, 32, 48, 64, 64, 96, 128, 256]))
+    nU, nI = int(rng.randint(3, 5000)), int(rng.randint(3, 5000))
+    B = int(rng.choice([7, 64, 100, 1000, 2048, 5000]))
+    steps = int(rng.randint(1, 4))
+    N = B * steps - int(rng.randint(0, B // 2 + 1))
+    kind = case % 3
+    if kind == 0:
+        u, p, n = rng.randint(0, nU, N), rng.randint(0, nI, N), rng.randint(0, nI, N)
+    elif kind == 1:
+        u = rng.randint(0, max(1, nU // 50), N); p = rng.randint(0, max(1, nI // 50), N); n = rng.randint(0, nI, N)
+    else:
+        u = np.minimum((rng.pareto(1.0, N) * 3).astype(np.int64), nU - 1)
+        p = np.minimum((rng.pareto(0.7, N) * 2).astype(np.int64), nI - 1)
+        n = rng.randint(0, nI, N)
+    U = (rng.standard_normal((nU, D)) / np.sqrt(D) * 2).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) / np.sqrt(D) * 2).astype(np.float32)
+    lr = float(rng.choice([0.01, 0.3]))
+    out = []
+    for builder in ("generic", "auto"):
+        tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+        plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, builder=builder)
+        losses = tabs.run_sgd(plan, 0, plan.n_batches, lr).cpu().numpy()
+        out.append((tabs.U.cpu().numpy(), tabs.I.cpu().numpy(), losses))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    Uo, Io = U.copy(), I.copy()
+    ref = [oracle.bprmf_step_sgd(Uo, Io, u[k * B:(k + 1) * B], p[k * B:(k + 1) * B], n[k * B:(k + 1) * B], lr, 0.0)
+           for k in range((N + B - 1) // B)]
+    assert rel_err(out[0][2], np.asarray(ref)) < TOL
+    assert rel_err(out[0][0], Uo) < TOL and rel_err(out[0][1], Io) < TOL
+
+
 def test_step_is_bitwise_reproducible(ops, dev):
     rng = np.random.RandomState(77)
     nU, nI, D, B = 5000, 3000, 64, 16384

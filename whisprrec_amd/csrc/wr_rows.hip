@@ -335,6 +335,37 @@ __global__ __launch_bounds__(kBlock) void embloss_finish_kernel(const float *__r
     }
 }
 
+// Gradient of EmbLoss w.r.t. the gathered ego rows, accumulated per table row using a batch plan: every occurrence of row
+// r in block k contributes (reg_weight / (B * ||block_k||_F)) * row, so a run of m occurrences adds m times that.
+// side: 0 = user rows (runs of tu), 1 = item rows (runs of oc_item, positives and negatives have different norms).
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void embloss_grad_kernel(int side, const float *__restrict__ tab, float *__restrict__ grad,
+                                                               int D, const int *__restrict__ keys, const int *__restrict__ src,
+                                                               int n, const float *__restrict__ sq3, float reg_over_B) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int q0 = blockIdx.x * TEAMS + threadIdx.x / T;
+    if (q0 >= n) return;
+    const int r = keys[q0];
+    if (q0 > 0 && keys[q0 - 1] == r) return;  // not the head of its run
+    int m_a = 0, m_b = 0;                      // users: all in m_a; items: positives in m_a, negatives in m_b
+    for (int q = q0; q < n && keys[q] == r; ++q) {
+        if (side == 1 && (src[q] & 1)) ++m_b; else ++m_a;
+    }
+    const float na = sqrtf(sq3[side == 0 ? 0 : 1]), nb = sqrtf(sq3[2]);
+    float coef = 0.f;
+    if (m_a > 0 && na > 0.f) coef += (float)m_a * (reg_over_B / na);
+    if (m_b > 0 && nb > 0.f) coef += (float)m_b * (reg_over_B / nb);
+    const Row<NV> x = load_row<T, NV, FULL>(tab, r, D, lane);
+    Row<NV> g = load_row<T, NV, FULL>(grad, r, D, lane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        g.v[k].x = fmaf(coef, x.v[k].x, g.v[k].x); g.v[k].y = fmaf(coef, x.v[k].y, g.v[k].y);
+        g.v[k].z = fmaf(coef, x.v[k].z, g.v[k].z); g.v[k].w = fmaf(coef, x.v[k].w, g.v[k].w);
+    }
+    store_row<T, NV, FULL>(grad, r, D, lane, g);
+}
+
 static inline int teams_per_block_for(int D) {
     if (D >= 64) return kBlock / 16;
     if (D == 32) return kBlock / 8;
@@ -561,6 +592,32 @@ int32_t wr_embloss_sumsq(const float *user_tab, const float *item_tab, int32_t D
     WR_LAUNCH_CHECK("embloss_sumsq_kernel");
     hipLaunchKernelGGL(embloss_finish_kernel, dim3(1), dim3(kBlock), 0, stream, partials, nblk, sq3);
     WR_LAUNCH_CHECK("embloss_finish_kernel");
+    return WR_OK;
+}
+
+int32_t wr_embloss_grad(const float *user_tab, const float *item_tab, int32_t D, const int32_t *tu, const int32_t *oc_item,
+                        const int32_t *oc_src, int64_t B, const float *sq3, float reg_weight, float *grad_user,
+                        float *grad_item, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, 1, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, 1, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_table(grad_user, 1, D, "grad_user")) != WR_OK) return rc;
+    if ((rc = check_table(grad_item, 1, D, "grad_item")) != WR_OK) return rc;
+    WR_REQUIRE(tu && oc_item && oc_src && sq3, WR_E_NULL, "embloss_grad: NULL argument");
+    WR_REQUIRE(B > 0 && B <= (int64_t(1) << 29), WR_E_SHAPE, "B out of range");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int tpb = teams_per_block_for(D);
+    const float rob = reg_weight / (float)B;
+#define WR_CALL_EG(T_, NV_, FULL_)                                                                                        \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((embloss_grad_kernel<T_, NV_, FULL_>), dim3((unsigned)((B + tpb - 1) / tpb)), dim3(kBlock), 0,  \
+                           stream, 0, user_tab, grad_user, D, tu, (const int *)nullptr, (int)B, sq3, rob);                \
+        hipLaunchKernelGGL((embloss_grad_kernel<T_, NV_, FULL_>), dim3((unsigned)((2 * B + tpb - 1) / tpb)), dim3(kBlock), \
+                           0, stream, 1, item_tab, grad_item, D, oc_item, oc_src, (int)(2 * B), sq3, rob);                \
+    } while (0)
+    WR_DISPATCH_D(D, WR_CALL_EG);
+#undef WR_CALL_EG
+    WR_LAUNCH_CHECK("embloss_grad_kernel");
     return WR_OK;
 }
 

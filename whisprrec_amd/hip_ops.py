@@ -103,7 +103,8 @@ class BatchPlan:
     ``u, p, n`` are the epoch's triplets in batch order (int64 as in the reference, or int32); batch k is
     ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201)."""
 
-    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="auto"):
+    def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="auto",
+                 hot=True):
         """builder: "auto" (default) = hand-written bucket/LDS-sort builder when applicable, generic radix-sort builder
         otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one."""
         L = abi.lib()
@@ -156,7 +157,9 @@ class BatchPlan:
                          _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(), _stream()),
                       "wr_bprmf_plan_build")
             self.builder = "generic"
-        self._plan_hot_runs(dev)
+        self.meta_host = None
+        if hot:
+            self._plan_hot_runs(dev)
         if validate:
             self.validate()
 
@@ -194,6 +197,8 @@ class BatchPlan:
 
     def validate(self):
         """nn.Embedding raises IndexError for out-of-range ids; so does the plan (one sync)."""
+        if self.meta_host is None:
+            self.meta_host = self.meta.cpu()
         if int(self.meta_host[0].item()) != 0:
             raise IndexError("index out of range in batch (user_id >= n_users or item id >= n_items)")
 
@@ -422,6 +427,15 @@ def axpy(y, x, alpha, overwrite=False):
     abi.check(abi.lib().wr_axpy(_p(_req(y, torch.float32, "y")), _p(_req(x, torch.float32, "x")), y.numel(), alpha,
                                 1 if overwrite else 0, _stream()), "wr_axpy")
     return y
+
+
+def embloss_grad(user_tab, item_tab, plan, k, sq3, reg_weight, grad_user, grad_item):
+    """EmbLoss backward for batch k of a plan (wr_embloss_grad): adds into grad_user / grad_item, no host sync."""
+    off = k * plan.batch_size
+    abi.check(abi.lib().wr_embloss_grad(_p(user_tab), _p(item_tab), user_tab.shape[1], plan.tu.data_ptr() + 4 * off,
+                                        plan.oc_item.data_ptr() + 8 * off, plan.oc_src.data_ptr() + 8 * off,
+                                        plan.batch_len(k), _p(sq3), reg_weight, _p(grad_user), _p(grad_item), _stream()),
+              "wr_embloss_grad")
 
 
 def embloss_sumsq(user_tab, item_tab, u, p, n):

@@ -169,26 +169,25 @@ def make_lightgcn(general_model_cls):
             norms = torch.sqrt(sq)                                     # ||U[u]||_F, ||I[p]||_F, ||I[n]||_F
             reg = norms.sum() / u.numel()
             loss = (mf + self.reg_weight * reg).reshape(1)             # the reference returns shape (1,) (loss.py:94)
-            return loss, (allE, norms)
+            return loss, (allE, sq)
 
         def _backward(self, idx, saved):
             u, p, n = idx
-            allE, norms = saved
+            allE, sq = saved
             nU, D, B = self.n_users, self.emb_size, u.numel()
             Ua, Ia = allE[:nU].contiguous(), allE[nU:].contiguous()
-            # gradient w.r.t. the propagated tables: BPRMF gradient kernels on (Ua, Ia)
+            # gradient w.r.t. the propagated tables: BPRMF gradient kernels on (Ua, Ia).  One small batch: the radix-sort
+            # builder and the sequential run path need no host round trip besides the index check.
             tabs = hip_ops.BprmfTables(Ua, Ia)
-            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items)
+            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="generic", hot=False)
             gOut = torch.zeros(nU + self.n_items, D, device=allE.device)
             tabs.grads(plan, 0, gOut[:nU], gOut[nU:])
             # back through the propagation: A is symmetric, d(mean_l A^l E0) = mean_l A^l gOut
             gE = self._propagate(gOut)
-            # EmbLoss: d/dx ||X||_F = x/||X||_F per gathered row, duplicates add up (loss.py:94-98)
-            U0, I0 = self.user_embedding.weight.data, self.item_embedding.weight.data
-            nv = norms.tolist()
-            for tab, g, ix, nrm in ((U0, gE[:nU], u, nv[0]), (I0, gE[nU:], p, nv[1]), (I0, gE[nU:], n, nv[2])):
-                if nrm > 0.0:
-                    hip_ops.scatter_add_rows(g, ix, hip_ops.gather_rows(tab, ix), alpha=self.reg_weight / (B * nrm))
+            # EmbLoss: d/dx ||X||_F = x/||X||_F per gathered row, duplicates add up (loss.py:94-98); the plan's runs give
+            # the multiplicities, the norms stay on the device
+            hip_ops.embloss_grad(self.user_embedding.weight.data, self.item_embedding.weight.data, plan, 0, sq,
+                                 self.reg_weight, gE[:nU], gE[nU:])
             return gE
 
         def _batch(self, feed_dict):
