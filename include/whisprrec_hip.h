@@ -114,22 +114,23 @@ int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users
                                 const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int32_t *neg_items,
                                 int32_t *err_flag, void *stream);
 
-/* Long runs ("hot rows": an item row with more than 32 occurrences in one batch, e.g. power-law ids).  Optional second
- * part of a plan: every such run is cut into pieces of at most 256 occurrences so that the step can sum a hot row with
- * many workgroups instead of one 16-lane team (still in a fixed order: reproducible).  Arrays are per batch, capacities
- * wr_bprmf_hot_caps(batch_size): piece_q/piece_len [n_batches*cap_pieces] (start inside the batch's occurrence array,
- * length), run_q/run_first/run_np [n_batches*cap_runs] (head position, first piece, piece count); counts: int32
- * [n_batches*2] on the DEVICE, caller-zeroed: pieces and runs per batch.  The caller copies `counts` to the host (it
- * sizes the extra launches) and hands everything to the step calls through wr_hot_runs (NULL = none: long runs are then
- * summed sequentially — correct, but slow on skewed data). */
+/* Long runs ("hot rows": a table row with more than 32 occurrences in one batch, e.g. power-law ids).  Optional second
+ * part of a plan: every such run is cut into pieces of at most 256 positions so that the step can work on a hot row with
+ * many workgroups instead of one 16-lane team (still in a fixed order: reproducible).  Two sides: kind 0 = item rows (runs of
+ * oc_item, 2*B positions per batch), kind 1 = user rows (runs of tu, B positions per batch).  Arrays are per batch with the
+ * capacities of wr_bprmf_hot_caps(batch_size, kind): piece_q/piece_len [n_batches*cap_pieces] (start inside the batch,
+ * length), run_q/run_first/run_np [n_batches*cap_runs] (head position, first piece, piece count).  counts: int32
+ * [n_batches*4] on the DEVICE, caller-zeroed: item pieces, item runs, user pieces, user runs per batch.  The caller copies
+ * `counts` to the host (it sizes the extra launches) and hands everything to the step calls through wr_hot_runs (NULL = none:
+ * long runs are then walked sequentially by one team — correct, but slow on skewed data). */
 typedef struct wr_hot_runs {
-    const int32_t *piece_q, *piece_len;           /* device */
-    const int32_t *run_q, *run_first, *run_np;    /* device */
-    const int32_t *counts_host;                   /* HOST: pieces, runs per batch */
-    int64_t cap_pieces, cap_runs;
+    const int32_t *piece_q, *piece_len, *run_q, *run_first, *run_np;             /* device, item side */
+    const int32_t *u_piece_q, *u_piece_len, *u_run_q, *u_run_first, *u_run_np;   /* device, user side */
+    const int32_t *counts_host;                                                   /* HOST, 4 per batch */
+    int64_t cap_pieces, cap_runs, cap_u_pieces, cap_u_runs;
 } wr_hot_runs;
-void wr_bprmf_hot_caps(int64_t batch_size, int64_t *cap_pieces, int64_t *cap_runs);
-int32_t wr_bprmf_plan_hot_runs(const int32_t *oc_item, int64_t n_triplets, int64_t batch_size, int32_t *piece_q,
+void wr_bprmf_hot_caps(int64_t batch_size, int32_t kind, int64_t *cap_pieces, int64_t *cap_runs);
+int32_t wr_bprmf_plan_hot_runs(const int32_t *keys, int32_t kind, int64_t n_triplets, int64_t batch_size, int32_t *piece_q,
                                int32_t *piece_len, int32_t *run_q, int32_t *run_first, int32_t *run_np, int32_t *counts,
                                void *stream);
 

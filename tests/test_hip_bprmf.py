@@ -321,7 +321,7 @@ def test_hot_rows_power_law_items(ops, dev, D):
     for rep in range(2):
         tabs = ops.BprmfTables(T(U, dev), T(I, dev))
         plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI)
-        assert plan.hot is not None and int(plan.hot["counts_host"].view(-1, 2)[:, 1].min()) >= 2   # every batch has hot runs
+        assert plan.hot is not None and int(plan.hot["counts_host"].view(-1, 4)[:, 1].min()) >= 2   # every batch has hot runs
         losses = tabs.run_sgd(plan, 0, plan.n_batches, 0.2).cpu().numpy()
         runs.append((tabs.U.cpu().numpy().copy(), tabs.I.cpu().numpy().copy(), losses))
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
@@ -377,6 +377,41 @@ def test_random_shapes_vs_oracle(ops, dev, case):
            for k in range((N + B - 1) // B)]
     assert rel_err(out[0][2], np.asarray(ref)) < TOL
     assert rel_err(out[0][0], Uo) < TOL and rel_err(out[0][1], Io) < TOL
+
+
+@pytest.mark.parametrize("D", [64, 16])
+def test_hot_rows_power_law_users(ops, dev, D):
+    """Power-law USERS: a few users own hundreds to thousands of the batch's triplets (their runs are cut into pieces and
+    worked on by many workgroups, bprmf_user_hot_*), combined with hot items.  Oracle parity, bitwise reproducibility,
+    gradient mode."""
+    rng = np.random.RandomState(40 + D)
+    nU, nI, B = 30000, 20000, 16384
+    U = (rng.standard_normal((nU, D)) * 0.3).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) * 0.3).astype(np.float32)
+    N = 2 * B + 700
+    u = np.minimum((rng.pareto(0.8, N) * 2).astype(np.int64), nU - 1)
+    p = np.minimum((rng.pareto(1.0, N) * 3).astype(np.int64), nI - 1)
+    n = rng.randint(1, nI, N)
+    runs = []
+    for rep in range(2):
+        tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+        plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI)
+        c = plan.hot["counts_host"].view(-1, 4)
+        assert int(c[:, 3].min()) >= 2 and int(c[:, 1].min()) >= 1          # hot users and hot items in every batch
+        losses = tabs.run_sgd(plan, 0, plan.n_batches, 0.2).cpu().numpy()
+        runs.append((tabs.U.cpu().numpy().copy(), tabs.I.cpu().numpy().copy(), losses))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    Uo, Io = U.copy(), I.copy()
+    ref = [oracle.bprmf_step_sgd(Uo, Io, u[k * B:(k + 1) * B], p[k * B:(k + 1) * B], n[k * B:(k + 1) * B], 0.2, 0.0)
+           for k in range(3)]
+    assert rel_err(runs[0][2], np.asarray(ref)) < TOL
+    assert rel_err(runs[0][0], Uo) < TOL and rel_err(runs[0][1], Io) < TOL
+    tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+    plan = ops.BatchPlan(T(u[:B], dev), T(p[:B], dev), T(n[:B], dev), B, nU, nI)
+    gU = torch.zeros_like(tabs.U); gI = torch.zeros_like(tabs.I)
+    loss, _ = tabs.grads(plan, 0, gU, gI)
+    rU, rI, rl = oracle.bpr_dense_grads(U, I, u[:B], p[:B], n[:B])
+    assert rel_err(gU.cpu().numpy(), rU) < TOL and rel_err(gI.cpu().numpy(), rI) < TOL and abs(float(loss) - rl) / rl < TOL
 
 
 def test_step_is_bitwise_reproducible(ops, dev):

@@ -34,8 +34,8 @@ SIGNATURES = {
     "wr_sample_negatives_i32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp, c_vp,
                                         c_vp]),
     "wr_bprmf_step_workspace_bytes": (c_i64, [c_i64, c_i32]),
-    "wr_bprmf_hot_caps": (None, [c_i64, c_vp, c_vp]),
-    "wr_bprmf_plan_hot_runs": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "wr_bprmf_hot_caps": (None, [c_i64, c_i32, c_vp, c_vp]),
+    "wr_bprmf_plan_hot_runs": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_bprmf_step_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32,
                                   c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_run_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
@@ -64,7 +64,9 @@ SIGNATURES = {
 class HotRuns(ctypes.Structure):
     """struct wr_hot_runs of include/whisprrec_hip.h"""
     _fields_ = [("piece_q", c_vp), ("piece_len", c_vp), ("run_q", c_vp), ("run_first", c_vp), ("run_np", c_vp),
-                ("counts_host", c_vp), ("cap_pieces", c_i64), ("cap_runs", c_i64)]
+                ("u_piece_q", c_vp), ("u_piece_len", c_vp), ("u_run_q", c_vp), ("u_run_first", c_vp), ("u_run_np", c_vp),
+                ("counts_host", c_vp), ("cap_pieces", c_i64), ("cap_runs", c_i64), ("cap_u_pieces", c_i64),
+                ("cap_u_runs", c_i64)]
 
 
 _lib = None

@@ -27,6 +27,7 @@ namespace wr {
 
 constexpr int kHotRun = 32;     // an item row with more occurrences than this in one batch is "hot" (must match wr_plan.hip)
 constexpr int kHotPiece = 256;  // occurrences summed by one workgroup
+constexpr double kHotLossScale = 68719476736.0;  // 2^36: fixed-point scale of the hot pieces' loss terms
 
 // ----------------------------------------------------------------------------------------------- forward only
 template <int T, int NV, bool FULL>
@@ -72,11 +73,91 @@ __global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__rest
 // MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.
 // MODE 2 (row-sharded step): user rows applied in place, item gradients emitted (the item "table" is the buffer of
 // rows received from their owners and gradI the buffer of gradient rows sent back).
+// Everything one triplet contributes, given the three rows in registers: loss term, coefficient, user-row gradient,
+// single-occurrence item rows finished in place (or their gradient emitted), stash for multi-occurrence item rows.
+template <int T, int NV, bool FULL, int MODE>
+__device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &pr, const Row<NV> &nr, int praw, int nraw, int t,
+                                             float *I, float *__restrict__ gradI, float *__restrict__ Z,
+                                             int *__restrict__ stampI, int step_id, int D, int lane, float lr, float l2,
+                                             float denom, Row<NV> &g, float &terms) {
+    const int p = praw & 0x7fffffff, n = nraw & 0x7fffffff;
+    const bool p_shared = praw < 0, n_shared = nraw < 0;   // bit 31: the item row has other occurrences in this batch
+    const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
+    const float sn = team_sum<T>(dot_partial<NV>(ur, nr));
+    float term, c;
+    bpr_terms(sp, sn, denom, term, c);
+    terms += term;
+    Row<NV> z;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        g.v[k].x = fmaf(c, pr.v[k].x - nr.v[k].x, g.v[k].x);
+        g.v[k].y = fmaf(c, pr.v[k].y - nr.v[k].y, g.v[k].y);
+        g.v[k].z = fmaf(c, pr.v[k].z - nr.v[k].z, g.v[k].z);
+        g.v[k].w = fmaf(c, pr.v[k].w - nr.v[k].w, g.v[k].w);
+        z.v[k] = make_float4(c * ur.v[k].x, c * ur.v[k].y, c * ur.v[k].z, c * ur.v[k].w);
+    }
+    // An item row that occurs once in the batch is read by this team only: finish it here
+    // (gradient = +z for the positive, -z for the negative), no stash, no item-phase work.
+    if (!p_shared) {
+        Row<NV> w;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (MODE == 0) {
+                w.v[k].x = pr.v[k].x - lr * fmaf(l2, pr.v[k].x, z.v[k].x);
+                w.v[k].y = pr.v[k].y - lr * fmaf(l2, pr.v[k].y, z.v[k].y);
+                w.v[k].z = pr.v[k].z - lr * fmaf(l2, pr.v[k].z, z.v[k].z);
+                w.v[k].w = pr.v[k].w - lr * fmaf(l2, pr.v[k].w, z.v[k].w);
+            } else {
+                w.v[k] = z.v[k];
+            }
+        }
+        store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
+        if (stampI != nullptr && lane == 0) stampI[p] = step_id;
+    }
+    if (!n_shared) {
+        Row<NV> w;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (MODE == 0) {
+                w.v[k].x = nr.v[k].x - lr * fmaf(l2, nr.v[k].x, -z.v[k].x);
+                w.v[k].y = nr.v[k].y - lr * fmaf(l2, nr.v[k].y, -z.v[k].y);
+                w.v[k].z = nr.v[k].z - lr * fmaf(l2, nr.v[k].z, -z.v[k].z);
+                w.v[k].w = nr.v[k].w - lr * fmaf(l2, nr.v[k].w, -z.v[k].w);
+            } else {
+                w.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
+            }
+        }
+        store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
+        if (stampI != nullptr && lane == 0) stampI[n] = step_id;
+    }
+    if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
+}
+
+// torch.optim.SGD on a finished user row: g' = g + l2 w ; w -= lr g'   (MODE 1: emit g instead)
+template <int T, int NV, bool FULL, int MODE>
+__device__ __forceinline__ void finish_user_row(float *__restrict__ U, float *__restrict__ gradU, int *__restrict__ stampU,
+                                                int step_id, int u, int D, int lane, float lr, float l2, const Row<NV> &ur,
+                                                const Row<NV> &g) {
+    if (MODE != 1) {
+        Row<NV> w;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            w.v[k].x = ur.v[k].x - lr * fmaf(l2, ur.v[k].x, g.v[k].x);
+            w.v[k].y = ur.v[k].y - lr * fmaf(l2, ur.v[k].y, g.v[k].y);
+            w.v[k].z = ur.v[k].z - lr * fmaf(l2, ur.v[k].z, g.v[k].z);
+            w.v[k].w = ur.v[k].w - lr * fmaf(l2, ur.v[k].w, g.v[k].w);
+        }
+        store_row<T, NV, FULL>(U, u, D, lane, w);
+    } else {
+        store_row<T, NV, FULL>(gradU, u, D, lane, g);
+    }
+    if (stampU != nullptr && lane == 0) stampU[u] = step_id;
+}
+
 // Each team works on SLOTS positions (t, t + seg, ...): the index loads of all slots are issued together, then the row
-// loads of all slots, then the slots are finished one after the other — twice the bytes in flight per team and a grid
-// that fits the chip in one resident round at the headline batch size.
-template <int T, int NV, bool FULL, int MODE, int SLOTS>
-__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0) ? 8 : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
+// loads of all slots, then the slots are finished one after the other.  (Launched with SLOTS = 1; see launch_step.)
+template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT>
+__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? 8 : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
                                                             const int *__restrict__ tn, int B, float lr, float l2,
                                                             float *__restrict__ Z, float *__restrict__ partials,
@@ -100,7 +181,9 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0) ? 8 : 
         if (team < seg && t0[s] < B) {
             uu[s] = tu[t0[s]];
             head[s] = (t0[s] == 0) || (tu[t0[s] - 1] != uu[s]);   // first position of a run of equal users
-            praw0[s] = tp[t0[s]];                                   // bit 31 set: the item row has other occurrences
+            // users with more than kHotRun triplets in the batch are cut into pieces by the plan (bprmf_user_hot_*)
+            if (SKIP_HOT && head[s] && t0[s] + kHotRun < B && tu[t0[s] + kHotRun] == uu[s]) head[s] = false;
+            praw0[s] = tp[t0[s]];
             nraw0[s] = tn[t0[s]];
         }
     }
@@ -123,93 +206,94 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0) ? 8 : 
         int t = t0[s];
         int praw = praw0[s], nraw = nraw0[s];
         Row<NV> pr = pr0[s], nr = nr0[s];
-        float terms = 0.f;
         bool more;
         do {
-            const int p = praw & 0x7fffffff, n = nraw & 0x7fffffff;
-            const bool p_shared = praw < 0, n_shared = nraw < 0;
-            const int tnext = t + 1;
-            more = (tnext < B) && (tu[tnext] == u);
-            int praw_next = 0, nraw_next = 0;
-            if (more) {  // indices of the next triplet of this user, requested before the dot / transcendentals
-                praw_next = tp[tnext];
-                nraw_next = tn[tnext];
-            }
-            const float sp = team_sum<T>(dot_partial<NV>(ur[s], pr));
-            const float sn = team_sum<T>(dot_partial<NV>(ur[s], nr));
-            float term, c;
-            bpr_terms(sp, sn, denom, term, c);
-            terms += term;
-            Row<NV> z;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                g.v[k].x = fmaf(c, pr.v[k].x - nr.v[k].x, g.v[k].x);
-                g.v[k].y = fmaf(c, pr.v[k].y - nr.v[k].y, g.v[k].y);
-                g.v[k].z = fmaf(c, pr.v[k].z - nr.v[k].z, g.v[k].z);
-                g.v[k].w = fmaf(c, pr.v[k].w - nr.v[k].w, g.v[k].w);
-                z.v[k] = make_float4(c * ur[s].v[k].x, c * ur[s].v[k].y, c * ur[s].v[k].z, c * ur[s].v[k].w);
-            }
-            // An item row that occurs once in the batch is read by this team only: finish it here
-            // (gradient = +z for the positive, -z for the negative), no stash, no item-phase work.
-            if (!p_shared) {
-                Row<NV> w;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    if (MODE == 0) {
-                        w.v[k].x = pr.v[k].x - lr * fmaf(l2, pr.v[k].x, z.v[k].x);
-                        w.v[k].y = pr.v[k].y - lr * fmaf(l2, pr.v[k].y, z.v[k].y);
-                        w.v[k].z = pr.v[k].z - lr * fmaf(l2, pr.v[k].z, z.v[k].z);
-                        w.v[k].w = pr.v[k].w - lr * fmaf(l2, pr.v[k].w, z.v[k].w);
-                    } else {
-                        w.v[k] = z.v[k];
-                    }
-                }
-                store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
-                if (stampI != nullptr && lane == 0) stampI[p] = step_id;
-            }
-            if (!n_shared) {
-                Row<NV> w;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    if (MODE == 0) {
-                        w.v[k].x = nr.v[k].x - lr * fmaf(l2, nr.v[k].x, -z.v[k].x);
-                        w.v[k].y = nr.v[k].y - lr * fmaf(l2, nr.v[k].y, -z.v[k].y);
-                        w.v[k].z = nr.v[k].z - lr * fmaf(l2, nr.v[k].z, -z.v[k].z);
-                        w.v[k].w = nr.v[k].w - lr * fmaf(l2, nr.v[k].w, -z.v[k].w);
-                    } else {
-                        w.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
-                    }
-                }
-                store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
-                if (stampI != nullptr && lane == 0) stampI[n] = step_id;
-            }
-            if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
-            t = tnext;
-            if (more) {  // rows of the next triplet (loaded only now: keeps the kernel at 8 waves per SIMD)
-                praw = praw_next;
-                nraw = nraw_next;
+            triplet_body<T, NV, FULL, MODE>(ur[s], pr, nr, praw, nraw, t, I, gradI, Z, stampI, step_id, D, lane, lr, l2, denom, g,
+                                            term_acc);
+            ++t;
+            more = (t < B) && (tu[t] == u);
+            if (more) {  // next triplet of this user (nothing is kept live across the body: 8 waves per SIMD, no spill)
+                praw = tp[t];
+                nraw = tn[t];
                 pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
                 nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
             }
         } while (more);
-        if (MODE != 1) {
-            Row<NV> w;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {  // torch.optim.SGD: g' = g + l2 w ; w -= lr g'
-                w.v[k].x = ur[s].v[k].x - lr * fmaf(l2, ur[s].v[k].x, g.v[k].x);
-                w.v[k].y = ur[s].v[k].y - lr * fmaf(l2, ur[s].v[k].y, g.v[k].y);
-                w.v[k].z = ur[s].v[k].z - lr * fmaf(l2, ur[s].v[k].z, g.v[k].z);
-                w.v[k].w = ur[s].v[k].w - lr * fmaf(l2, ur[s].v[k].w, g.v[k].w);
-            }
-            store_row<T, NV, FULL>(U, u, D, lane, w);
-        } else {
-            store_row<T, NV, FULL>(gradU, u, D, lane, g);
-        }
-        if (stampU != nullptr && lane == 0) stampU[u] = step_id;
-        if (lane == 0) term_acc += terms;  // every lane of the team holds the same terms: count them once
+        finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur[s], g);
     }
+    if (lane != 0) term_acc = 0.f;  // every lane of a team holds the same terms: count them once
     const float sum = block_sum(term_acc, scratch);
     if (threadIdx.x == 0) partials[blockIdx.x] = sum;
+}
+
+// Hot users: a piece = up to kHotPiece consecutive triplets of ONE user.  One workgroup per piece: every team holds the
+// user row, team j takes triplets j, j+TEAMS, ...; the TEAMS partial gradients are added in team order through LDS, the
+// loss terms in wave order.  bprmf_user_hot_combine then adds the pieces in order and rewrites the user row once.
+template <int T, int NV, bool FULL, int MODE>
+__global__ __launch_bounds__(kBlock) void bprmf_user_hot_pieces(const float *__restrict__ U, float *I, int D,
+                                                                 const int *__restrict__ tu, const int *__restrict__ tp,
+                                                                 const int *__restrict__ tn, float lr, float l2,
+                                                                 float *__restrict__ Z, float *__restrict__ /*unused*/,
+                                                                 float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
+                                                                 float denom, const int *__restrict__ piece_q,
+                                                                 const int *__restrict__ piece_len, float *__restrict__ hotPU,
+                                                                 unsigned long long *__restrict__ hot_loss) {
+    extern __shared__ float rows[];  // [TEAMS][D]
+    __shared__ float scratch[kBlock / 64];
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T, team = threadIdx.x / T;
+    const int q0 = piece_q[blockIdx.x], len = piece_len[blockIdx.x];
+    const int u = tu[q0];
+    const Row<NV> ur = load_row<T, NV, FULL>(U, u, D, lane);
+    Row<NV> g;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float terms = 0.f;
+    for (int k = team; k < len; k += TEAMS) {
+        const int t = q0 + k;
+        const int praw = tp[t], nraw = tn[t];
+        const Row<NV> pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
+        const Row<NV> nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
+        triplet_body<T, NV, FULL, MODE>(ur, pr, nr, praw, nraw, t, I, gradI, Z, stampI, step_id, D, lane, lr, l2, denom, g, terms);
+    }
+    store_row<T, NV, FULL>(rows, team, D, lane, g);
+    __syncthreads();
+    for (int c = threadIdx.x; c * 4 < D; c += kBlock) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < TEAMS; ++j) {
+            const float4 v = reinterpret_cast<const float4 *>(rows + (int64_t)j * D)[c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4 *>(hotPU + (int64_t)blockIdx.x * D)[c] = a;
+    }
+    // The order of the pieces in the plan's list is not fixed (atomic append), so their loss terms are accumulated in
+    // 64-bit fixed point (2^-36 resolution): integer addition is order-independent, the loss stays bitwise reproducible.
+    const float sum = block_sum(lane == 0 ? terms : 0.f, scratch);
+    if (threadIdx.x == 0) atomicAdd(hot_loss, (unsigned long long)(long long)llrint((double)sum * kHotLossScale));
+}
+
+template <int T, int NV, bool FULL, int MODE>
+__global__ __launch_bounds__(kBlock) void bprmf_user_hot_combine(float *__restrict__ U, int D, const int *__restrict__ tu,
+                                                                  const int *__restrict__ run_q, const int *__restrict__ run_first,
+                                                                  const int *__restrict__ run_np, int n_runs,
+                                                                  const float *__restrict__ hotPU, float lr, float l2,
+                                                                  float *__restrict__ gradU, int *__restrict__ stampU, int step_id) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int h = blockIdx.x * TEAMS + threadIdx.x / T;
+    if (h >= n_runs) return;
+    const int u = tu[run_q[h]];
+    const int first = run_first[h], np = run_np[h];
+    Row<NV> g = load_row<T, NV, FULL>(hotPU, first, D, lane);
+    for (int k = 1; k < np; ++k) {
+        const Row<NV> x = load_row<T, NV, FULL>(hotPU, first + k, D, lane);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            g.v[c].x += x.v[c].x; g.v[c].y += x.v[c].y; g.v[c].z += x.v[c].z; g.v[c].w += x.v[c].w;
+        }
+    }
+    const Row<NV> ur = load_row<T, NV, FULL>(U, u, D, lane);
+    finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur, g);
 }
 
 // ----------------------------------------------------------------------------------------------- item phase
@@ -219,7 +303,8 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             const float *__restrict__ Z, float lr, float l2,
                                                             float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
                                                             const float *__restrict__ partials, int n_partials,
-                                                            float loss_denom, float *__restrict__ loss_out, int skip_hot) {
+                                                            float loss_denom, float *__restrict__ loss_out, int skip_hot,
+                                                            const unsigned long long *__restrict__ hot_loss) {
     __shared__ float scratch[kBlock / 64];
     __shared__ int heads[kBlock];
     __shared__ int item_tile[kBlock + 8];  // oc_item of this tile plus up to 8 entries beyond it
@@ -313,8 +398,11 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
     }
     if (blockIdx.x == 0 && loss_out != nullptr) {  // uniform per block: fold the user phase's partials
         const float a = strided_partial_sum(partials, n_partials);
-        const float s = block_sum(a, scratch);
-        if (threadIdx.x == 0) loss_out[0] = s / loss_denom;
+        float s = block_sum(a, scratch);
+        if (threadIdx.x == 0) {
+            if (hot_loss != nullptr) s += (float)((double)(long long)hot_loss[0] / kHotLossScale);
+            loss_out[0] = s / loss_denom;
+        }
     }
 }
 
@@ -418,42 +506,52 @@ static inline int64_t n_blocks_for(int64_t n_teams, int D) {
 struct StepWs {
     float *Z;
     float *partials;
-    float *hotP;
+    float *hotP;   // item-side piece sums
+    float *hotPU;  // user-side piece sums
+    unsigned long long *hot_loss;  // fixed-point sum of the hot user pieces' loss terms
     int64_t n_partials;
 };
 
-static inline int64_t hot_cap_pieces(int64_t B) { return 2 * B / kHotPiece + 2 * B / kHotRun + 8; }
-static inline int64_t hot_cap_runs(int64_t B) { return 2 * B / kHotRun + 8; }
+// kind 0: item occurrences (2B positions per batch); kind 1: user positions (B per batch)
+static inline int64_t hot_cap_pieces(int64_t B, int kind = 0) { const int64_t n = kind ? B : 2 * B; return n / kHotPiece + n / kHotRun + 8; }
+static inline int64_t hot_cap_runs(int64_t B, int kind = 0) { const int64_t n = kind ? B : 2 * B; return n / kHotRun + 8; }
 
-struct HotBatch {  // hot runs of ONE batch (device pointers already offset), counts from the host copy
+struct HotSide {  // hot runs of ONE batch on one side (device pointers already offset), counts from the host copy
     const int32_t *piece_q, *piece_len, *run_q, *run_first, *run_np;
     int n_pieces, n_runs;
 };
+struct HotBatch {
+    HotSide item, user;
+};
 
 static inline HotBatch hot_of(const wr_hot_runs *hot, int64_t batch) {
-    HotBatch h{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    HotBatch h{{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}};
     if (hot == nullptr || hot->counts_host == nullptr) return h;
-    h.n_pieces = hot->counts_host[2 * batch];
-    h.n_runs = hot->counts_host[2 * batch + 1];
-    h.piece_q = hot->piece_q + batch * hot->cap_pieces;
-    h.piece_len = hot->piece_len + batch * hot->cap_pieces;
-    h.run_q = hot->run_q + batch * hot->cap_runs;
-    h.run_first = hot->run_first + batch * hot->cap_runs;
-    h.run_np = hot->run_np + batch * hot->cap_runs;
+    const int32_t *c = hot->counts_host + 4 * batch;
+    h.item = HotSide{hot->piece_q + batch * hot->cap_pieces, hot->piece_len + batch * hot->cap_pieces,
+                     hot->run_q + batch * hot->cap_runs, hot->run_first + batch * hot->cap_runs,
+                     hot->run_np + batch * hot->cap_runs, c[0], c[1]};
+    h.user = HotSide{hot->u_piece_q + batch * hot->cap_u_pieces, hot->u_piece_len + batch * hot->cap_u_pieces,
+                     hot->u_run_q + batch * hot->cap_u_runs, hot->u_run_first + batch * hot->cap_u_runs,
+                     hot->u_run_np + batch * hot->cap_u_runs, c[2], c[3]};
     return h;
 }
 
 static inline int64_t step_ws_bytes(int64_t B, int32_t D) {
     // Z stash [B, D] + loss partials (one per user-phase block; bounded by B for the smallest team count)
-    return align_up(B * (int64_t)D * 4, 256) + align_up(n_blocks_for(B, D) * 4, 256) +
-           align_up(hot_cap_pieces(B) * (int64_t)D * 4, 256);
+    return align_up(B * (int64_t)D * 4, 256) + align_up((n_blocks_for(B, D) + hot_cap_pieces(B, 1)) * 4, 256) +
+           align_up(hot_cap_pieces(B, 0) * (int64_t)D * 4, 256) + align_up(hot_cap_pieces(B, 1) * (int64_t)D * 4, 256) + 256;
 }
 
 static inline StepWs carve_step_ws(void *workspace, int64_t B, int32_t D) {
     StepWs w;
     w.Z = reinterpret_cast<float *>(workspace);
     w.partials = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + align_up(B * (int64_t)D * 4, 256));
-    w.hotP = reinterpret_cast<float *>(reinterpret_cast<char *>(w.partials) + align_up(n_blocks_for(B, D) * 4, 256));
+    w.hotP = reinterpret_cast<float *>(reinterpret_cast<char *>(w.partials) +
+                                       align_up((n_blocks_for(B, D) + hot_cap_pieces(B, 1)) * 4, 256));
+    w.hotPU = reinterpret_cast<float *>(reinterpret_cast<char *>(w.hotP) + align_up(hot_cap_pieces(B, 0) * (int64_t)D * 4, 256));
+    w.hot_loss = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(w.hotPU) +
+                                                        align_up(hot_cap_pieces(B, 1) * (int64_t)D * 4, 256));
     w.n_partials = n_blocks_for(B, D);
     return w;
 }
@@ -463,44 +561,70 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
                            const int32_t *oc_item, const int32_t *oc_src, int64_t B, float lr, float l2, float *gradU,
                            float *gradI, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id, float *loss_out,
                            void *workspace, hipStream_t stream, void *const *events = nullptr, float denom = 0.f,
-                           HotBatch hot = HotBatch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
+                           HotBatch hot = HotBatch{{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
+                                                   {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}},
                            int64_t ws_batch = 0) {
     if (denom <= 0.f) denom = (float)B;  // single-device step: mean over this batch
     if (ws_batch <= 0) ws_batch = B;     // the workspace was sized for the plan's batch size (>= this batch)
     const StepWs w = carve_step_ws(workspace, ws_batch, D);
     const dim3 block(kBlock);
-    const bool have_hot = hot.n_runs > 0 && hot.n_pieces > 0;
-    WR_REQUIRE(!have_hot || (hot.n_pieces <= hot_cap_pieces(ws_batch) && hot.n_runs <= hot_cap_runs(ws_batch)), WR_E_RANGE,
-               "hot-run counts exceed their capacity");
+    const bool have_hot = hot.item.n_runs > 0 && hot.item.n_pieces > 0;
+    const bool have_hot_u = hot.user.n_runs > 0 && hot.user.n_pieces > 0;
+    WR_REQUIRE(hot.item.n_pieces <= hot_cap_pieces(ws_batch, 0) && hot.item.n_runs <= hot_cap_runs(ws_batch, 0) &&
+                   hot.user.n_pieces <= hot_cap_pieces(ws_batch, 1) && hot.user.n_runs <= hot_cap_runs(ws_batch, 1),
+               WR_E_RANGE, "hot-run counts exceed their capacity");
+    const size_t lds_rows = (size_t)teams_per_block(D) * D * 4;
     // SLOTS = 1: two positions per team (twice the loads in flight, one resident round of workgroups at B = 65,536) was
     // A/B-tested on MI355X and is ~4 % slower — the kernel is bound by the memory system's random 256-B row rate, not by
     // bytes in flight.
     const dim3 gridA((unsigned)n_blocks_for(B, D));
     const dim3 gridB((unsigned)((2 * B + kBlock - 1) / kBlock));  // item phase: one thread per occurrence
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[0]), stream));
-#define WR_CALL_USER(T_, NV_, FULL_)                                                                                     \
-    hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1>), gridA, block, 0, stream, U, I, D, tu, tp, tn, (int)B, \
-                       lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom)
+#define WR_CALL_USER(T_, NV_, FULL_)                                                                                      \
+    do {                                                                                                                  \
+        if (have_hot_u)                                                                                                   \
+            hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, true>), gridA, block, 0, stream, U, I, D, tu, tp, \
+                               tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom);       \
+        else                                                                                                              \
+            hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, false>), gridA, block, 0, stream, U, I, D, tu,    \
+                               tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom);   \
+    } while (0)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
     WR_LAUNCH_CHECK("bprmf_user_phase");
+    if (have_hot_u) {  // users with more than kHotRun triplets in this batch: many workgroups per user, fixed order
+        WR_HIP(hipMemsetAsync(w.hot_loss, 0, 8, stream));
+        const unsigned grun = (unsigned)n_blocks_for(hot.user.n_runs, D);
+#define WR_CALL_HOTU(T_, NV_, FULL_)                                                                                      \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((bprmf_user_hot_pieces<T_, NV_, FULL_, MODE>), dim3((unsigned)hot.user.n_pieces), block,        \
+                           lds_rows, stream, U, I, D, tu, tp, tn, lr, l2, w.Z, w.partials, gradI, stamp_i, step_id, denom,  \
+                           hot.user.piece_q, hot.user.piece_len, w.hotPU, w.hot_loss);                                    \
+        hipLaunchKernelGGL((bprmf_user_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, U, D, tu,         \
+                           hot.user.run_q, hot.user.run_first, hot.user.run_np, hot.user.n_runs, w.hotPU, lr, l2, gradU,   \
+                           stamp_u, step_id);                                                                            \
+    } while (0)
+        WR_DISPATCH_D(D, WR_CALL_HOTU);
+#undef WR_CALL_HOTU
+        WR_LAUNCH_CHECK("bprmf_user_hot_*");
+    }
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[1]), stream));
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
     hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
                        (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)gridA.x, denom,         \
-                       loss_out, have_hot ? 1 : 0)
+                       loss_out, have_hot ? 1 : 0, have_hot_u ? w.hot_loss : nullptr)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
     WR_LAUNCH_CHECK("bprmf_item_phase");
     if (have_hot) {
-        const size_t lds = (size_t)teams_per_block(D) * D * 4;
-        const unsigned grun = (unsigned)n_blocks_for(hot.n_runs, D);
+        const unsigned grun = (unsigned)n_blocks_for(hot.item.n_runs, D);
 #define WR_CALL_HOT(T_, NV_, FULL_)                                                                                      \
     do {                                                                                                                \
-        hipLaunchKernelGGL((bprmf_item_hot_pieces<T_, NV_, FULL_>), dim3((unsigned)hot.n_pieces), block, lds, stream, D,  \
-                           oc_src, w.Z, hot.piece_q, hot.piece_len, w.hotP);                                            \
+        hipLaunchKernelGGL((bprmf_item_hot_pieces<T_, NV_, FULL_>), dim3((unsigned)hot.item.n_pieces), block, lds_rows,  \
+                           stream, D, oc_src, w.Z, hot.item.piece_q, hot.item.piece_len, w.hotP);                       \
         hipLaunchKernelGGL((bprmf_item_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, I, D, oc_item,  \
-                           hot.run_q, hot.run_first, hot.run_np, hot.n_runs, w.hotP, lr, l2, gradI, stamp_i, step_id);   \
+                           hot.item.run_q, hot.item.run_first, hot.item.run_np, hot.item.n_runs, w.hotP, lr, l2, gradI, \
+                           stamp_i, step_id);                                                                           \
     } while (0)
         WR_DISPATCH_D(D, WR_CALL_HOT);
 #undef WR_CALL_HOT
@@ -554,9 +678,9 @@ int32_t wr_bpr_fwd(const float *user_tab, int64_t n_users, const float *item_tab
 
 int64_t wr_bprmf_step_workspace_bytes(int64_t B, int32_t D) { return step_ws_bytes(B, D); }
 
-void wr_bprmf_hot_caps(int64_t batch_size, int64_t *cap_pieces, int64_t *cap_runs) {
-    if (cap_pieces) *cap_pieces = hot_cap_pieces(batch_size);
-    if (cap_runs) *cap_runs = hot_cap_runs(batch_size);
+void wr_bprmf_hot_caps(int64_t batch_size, int32_t kind, int64_t *cap_pieces, int64_t *cap_runs) {
+    if (cap_pieces) *cap_pieces = hot_cap_pieces(batch_size, kind ? 1 : 0);
+    if (cap_runs) *cap_runs = hot_cap_runs(batch_size, kind ? 1 : 0);
 }
 
 int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,

@@ -95,33 +95,34 @@ __global__ __launch_bounds__(kBlock) void plan_unpack_item(const Key *__restrict
 constexpr int kHotRun = 32;     // must match wr_bpr.hip
 constexpr int kHotPiece = 256;
 
-// One thread per sorted occurrence: the head of a run longer than kHotRun finds the run's end by binary search in its
-// batch's (ascending) item array and appends the run, cut into pieces of kHotPiece, to the batch's hot lists.
-__global__ __launch_bounds__(kBlock) void plan_hot_runs_kernel(const int *__restrict__ oc_item, int64_t n, int64_t B,
+// One thread per sorted position: the head of a run longer than kHotRun finds the run's end by binary search in its
+// batch's (ascending) key array and appends the run, cut into pieces of kHotPiece, to the batch's hot lists.
+// mult = 2 for the item occurrences (2B positions per batch), 1 for the user-sorted triplets (B per batch).
+__global__ __launch_bounds__(kBlock) void plan_hot_runs_kernel(const int *__restrict__ keys, int64_t n, int64_t B, int mult,
                                                                 int64_t cap_pieces, int64_t cap_runs, int *__restrict__ piece_q,
                                                                 int *__restrict__ piece_len, int *__restrict__ run_q,
                                                                 int *__restrict__ run_first, int *__restrict__ run_np,
-                                                                int *__restrict__ counts) {
+                                                                int *__restrict__ counts, int count_stride) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= 2 * n) return;
-    const int64_t b = i / (2 * B);
-    const int64_t base = 2 * b * B;
+    if (i >= mult * n) return;
+    const int64_t b = i / (mult * B);
+    const int64_t base = mult * b * B;
     const int64_t Bb = (b * B + B <= n) ? B : (n - b * B);
-    const int64_t end = base + 2 * Bb;
+    const int64_t end = base + mult * Bb;
     if (i >= end) return;
-    const int r = oc_item[i];
-    if (i > base && oc_item[i - 1] == r) return;                   // not a run head
-    if (i + kHotRun >= end || oc_item[i + kHotRun] != r) return;    // run of at most kHotRun occurrences
-    int64_t lo = i + kHotRun, hi = end;                              // first position > lo whose item differs
+    const int r = keys[i];
+    if (i > base && keys[i - 1] == r) return;                   // not a run head
+    if (i + kHotRun >= end || keys[i + kHotRun] != r) return;    // run of at most kHotRun positions
+    int64_t lo = i + kHotRun, hi = end;                           // keys[lo] == r; keys[hi] != r or hi == end
     while (lo + 1 < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (oc_item[mid] == r) lo = mid; else hi = mid;
+        if (keys[mid] == r) lo = mid; else hi = mid;
     }
     const int len = (int)(hi - i);
     const int np = (len + kHotPiece - 1) / kHotPiece;
-    const int first = atomicAdd(&counts[2 * b], np);
-    const int ridx = atomicAdd(&counts[2 * b + 1], 1);
-    if (first + np > cap_pieces || ridx >= cap_runs) return;         // cannot happen with wr_bprmf_hot_caps capacities
+    const int first = atomicAdd(&counts[count_stride * b], np);
+    const int ridx = atomicAdd(&counts[count_stride * b + 1], 1);
+    if (first + np > cap_pieces || ridx >= cap_runs) return;      // cannot happen with wr_bprmf_hot_caps capacities
     const int q0 = (int)(i - base);
     for (int k = 0; k < np; ++k) {
         piece_q[b * cap_pieces + first + k] = q0 + k * kHotPiece;
@@ -234,17 +235,19 @@ using namespace wr;
 
 extern "C" {
 
-int32_t wr_bprmf_plan_hot_runs(const int32_t *oc_item, int64_t n_triplets, int64_t batch_size, int32_t *piece_q,
+int32_t wr_bprmf_plan_hot_runs(const int32_t *keys, int32_t kind, int64_t n_triplets, int64_t batch_size, int32_t *piece_q,
                                int32_t *piece_len, int32_t *run_q, int32_t *run_first, int32_t *run_np, int32_t *counts,
                                void *stream) {
-    WR_REQUIRE(oc_item && piece_q && piece_len && run_q && run_first && run_np && counts, WR_E_NULL, "hot-run arrays: NULL");
+    WR_REQUIRE(keys && piece_q && piece_len && run_q && run_first && run_np && counts, WR_E_NULL, "hot-run arrays: NULL");
     WR_REQUIRE(n_triplets > 0 && n_triplets < (int64_t(1) << 30) && batch_size > 0, WR_E_SHAPE, "hot runs: bad sizes");
+    WR_REQUIRE(kind == 0 || kind == 1, WR_E_RANGE, "hot runs: kind must be 0 (item occurrences) or 1 (user positions)");
     int64_t cp = 0, cr = 0;
-    wr_bprmf_hot_caps(batch_size, &cp, &cr);
-    const int64_t n2 = 2 * n_triplets;
-    hipLaunchKernelGGL(plan_hot_runs_kernel, dim3((unsigned)((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(stream), oc_item, n_triplets, batch_size, cp, cr, piece_q, piece_len,
-                       run_q, run_first, run_np, counts);
+    wr_bprmf_hot_caps(batch_size, kind, &cp, &cr);
+    const int mult = kind == 0 ? 2 : 1;
+    const int64_t total = mult * n_triplets;
+    hipLaunchKernelGGL(plan_hot_runs_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), keys, n_triplets, batch_size, mult, cp, cr, piece_q, piece_len,
+                       run_q, run_first, run_np, counts + (kind == 0 ? 0 : 2), 4);
     WR_LAUNCH_CHECK("plan_hot_runs_kernel");
     return WR_OK;
 }

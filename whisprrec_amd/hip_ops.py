@@ -127,7 +127,7 @@ class BatchPlan:
         self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
         # one small tensor read back per plan: [0] index out of range, [1] fast-builder bucket overflow, then per batch
         # the number of hot-run pieces and hot runs (wr_bprmf_plan_hot_runs)
-        self.meta = torch.zeros(2 + 2 * self.n_batches, **i32)
+        self.meta = torch.zeros(2 + 4 * self.n_batches, **i32)
         self.flags = self.meta[:2]
         self.err = self.flags[:1]
         self.hot = None
@@ -164,36 +164,39 @@ class BatchPlan:
             self.validate()
 
     def _plan_hot_runs(self, dev):
-        """Cuts item rows with more than 32 occurrences in a batch into pieces for the many-workgroup path (power-law
-        ids); one device-to-host copy of the small meta tensor tells whether there are any."""
+        """Cuts table rows with more than 32 occurrences in a batch (item rows: runs of oc_item; user rows: runs of tu) into
+        pieces for the many-workgroup path (power-law ids); one device-to-host copy of the small meta tensor tells whether
+        there are any."""
         L = abi.lib()
-        cp, cr = ctypes.c_int64(0), ctypes.c_int64(0)
-        L.wr_bprmf_hot_caps(self.batch_size, ctypes.addressof(cp), ctypes.addressof(cr))
-        cp, cr = cp.value, cr.value
         i32 = dict(dtype=torch.int32, device=dev)
-        arrs = [torch.empty(self.n_batches * cp, **i32), torch.empty(self.n_batches * cp, **i32),
-                torch.empty(self.n_batches * cr, **i32), torch.empty(self.n_batches * cr, **i32),
-                torch.empty(self.n_batches * cr, **i32)]
         counts = self.meta[2:]
-        abi.check(L.wr_bprmf_plan_hot_runs(_p(self.oc_item), self.n_triplets, self.batch_size, *[_p(a) for a in arrs],
-                                           _p(counts), _stream()), "wr_bprmf_plan_hot_runs")
+        sides = []
+        for kind, keys in ((0, self.oc_item), (1, self.tu)):
+            cp, cr = ctypes.c_int64(0), ctypes.c_int64(0)
+            L.wr_bprmf_hot_caps(self.batch_size, kind, ctypes.addressof(cp), ctypes.addressof(cr))
+            cp, cr = cp.value, cr.value
+            arrs = [torch.empty(self.n_batches * cp, **i32), torch.empty(self.n_batches * cp, **i32),
+                    torch.empty(self.n_batches * cr, **i32), torch.empty(self.n_batches * cr, **i32),
+                    torch.empty(self.n_batches * cr, **i32)]
+            abi.check(L.wr_bprmf_plan_hot_runs(_p(keys), kind, self.n_triplets, self.batch_size, *[_p(a) for a in arrs],
+                                               _p(counts), _stream()), "wr_bprmf_plan_hot_runs")
+            sides.append((arrs, cp, cr))
         self.meta_host = self.meta.cpu()
         counts_host = self.meta_host[2:].contiguous()
         if int(counts_host.sum().item()) > 0:
-            self.hot = {"arrs": arrs, "counts_host": counts_host, "cap_pieces": cp, "cap_runs": cr}
+            self.hot = {"sides": sides, "counts_host": counts_host}
 
     def hot_struct(self, batch=None):
         """ctypes wr_hot_runs for the whole plan (batch=None) or for one batch; None when the plan has no hot runs."""
         if self.hot is None:
             return None
-        h = self.hot
         k = 0 if batch is None else batch
-        cp, cr = h["cap_pieces"], h["cap_runs"]
-        a = h["arrs"]
-        st = abi.HotRuns(a[0].data_ptr() + 4 * k * cp, a[1].data_ptr() + 4 * k * cp, a[2].data_ptr() + 4 * k * cr,
-                         a[3].data_ptr() + 4 * k * cr, a[4].data_ptr() + 4 * k * cr,
-                         h["counts_host"].data_ptr() + 8 * k, cp, cr)
-        return st
+        vals = []
+        for arrs, cp, cr in self.hot["sides"]:
+            vals += [arrs[0].data_ptr() + 4 * k * cp, arrs[1].data_ptr() + 4 * k * cp, arrs[2].data_ptr() + 4 * k * cr,
+                     arrs[3].data_ptr() + 4 * k * cr, arrs[4].data_ptr() + 4 * k * cr]
+        (_, cp0, cr0), (_, cp1, cr1) = self.hot["sides"]
+        return abi.HotRuns(*vals, self.hot["counts_host"].data_ptr() + 16 * k, cp0, cr0, cp1, cr1)
 
     def validate(self):
         """nn.Embedding raises IndexError for out-of-range ids; so does the plan (one sync)."""
