@@ -243,6 +243,19 @@ int32_t wr_embloss_sumsq(const float *user_tab, const float *item_tab, int32_t D
                          const int64_t *n, int64_t B, float *sq3, void *workspace, int64_t workspace_bytes,
                          void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K10  Full-ranking evaluation — BaseRunner.interface + evaluate_method (src/helpers/BaseRunner.py:218-258, 50-92) over
+ *      full_predict (src/models/general/BPRMF.py:82-91), without materialising the [n, n_items] score matrix:
+ *   rank[i] = 1 + #{ j not in mask(eval_user[i]) : <user_mat[eval_user[i]], item_tab[j]>  >  target_score[i] }
+ *   target_score[i] = <user_mat[eval_user[i]], item_tab[eval_target[i]]>
+ * mask_ptr int64 [n_user_rows+1] / mask_idx int32 (ascending per user): the user's train + dev + test items, which the
+ * reference sets to -inf (BaseRunner.py:246-255); both NULL = no masking (--test_all 0).  Scores are computed on the matrix
+ * cores with v_mfma_f32_32x32x2_f32 (exact fp32 k-ordered fma chain).  rank: int32 [n]; target_score: fp32 [n] (output).
+ * --------------------------------------------------------------------------------------------------- */
+int32_t wr_rank_eval(const float *user_mat, int64_t n_user_rows, const float *item_tab, int64_t n_items, int32_t D,
+                     const int64_t *eval_user, const int64_t *eval_target, int64_t n, const int64_t *mask_ptr,
+                     const int32_t *mask_idx, int32_t *rank, float *target_score, void *stream);
+
 /* Backward of EmbLoss for one planned batch: grad_user[u,:] += m_u * w/(B*sqrt(sq3[0])) * user_tab[u,:] for a user with m_u
  * triplets in the batch; grad_item[r,:] += (m_pos * w/(B*sqrt(sq3[1])) + m_neg * w/(B*sqrt(sq3[2]))) * item_tab[r,:].
  * tu / oc_item / oc_src are the plan arrays of that batch (oc_item must hold plain row ids), sq3 the device output of

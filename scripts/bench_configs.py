@@ -142,8 +142,23 @@ def ml100k_dropin_case():
              runner=rname, optimizer=opt, epoch_s=t, triplets_per_s=66016 / t)
 
 
+def eval_case():
+    for nU, nI, n, D in ((943, 1574, 8252, 64), (100_000, 100_000, 100_000, 64), (200_000, 1_000_000, 20_000, 64)):
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        U = torch.randn(nU, D, generator=g, device=dev); I = torch.randn(nI, D, generator=g, device=dev)
+        eu = torch.randint(0, nU, (n,), generator=g, device=dev); et = torch.randint(0, nI, (n,), generator=g, device=dev)
+        per = 50
+        ptr = torch.arange(0, (nU + 1) * per, per, device=dev, dtype=torch.int64)
+        idx = torch.sort(torch.randint(0, nI, (nU, per), generator=g, device=dev, dtype=torch.int32), dim=1)[0].reshape(-1).contiguous()
+        hip_ops.rank_eval(U, I, eu, et, ptr, idx)
+        t = ev_time(lambda k: hip_ops.rank_eval(U, I, eu, et, ptr, idx), 5)
+        flops = 2.0 * n * nI * D
+        emit(case="K10 full-ranking evaluation (wr_rank_eval, MFMA f32 32x32x2 score tiles + mask + count)", eval_rows=n,
+             items=nI, D=D, ms=t * 1e3, TFLOPs=flops / t / 1e12, mfma_f32_peak_frac=flops / t / 157.3e12)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c4", "c3", "c5", "c1"]
+    which = sys.argv[1:] or ["c2", "c4", "c3", "c5", "c1", "eval"]
     if "c2" in which:
         for B, NB in ((2048, 256), (16384, 128), (65536, 64), (262144, 16)):
             bprmf_case("C2 BPRMF 1Mx1M D=64 SGD l2=0", 1_000_000, 1_000_000, 64, B, NB)
@@ -158,3 +173,5 @@ if __name__ == "__main__":
         sasrec_embedding_case()
     if "c1" in which:
         ml100k_dropin_case()
+    if "eval" in which:
+        eval_case()

@@ -173,6 +173,10 @@ def make_bprmf(general_model_cls):
             user_e = hip_ops.gather_rows(self.user_embeddings.weight.data, feed_dict["user_id"].to(dev))
             return torch.matmul(user_e, self.item_embeddings.weight.data.t())
 
+        def eval_factors(self):
+            """(user matrix, item matrix) whose inner products are the ranking scores (full_predict, BPRMF.py:82-91)."""
+            return self.user_embeddings.weight.data, self.item_embeddings.weight.data
+
         # ------------------------------------------------------------------ native epoch (used by HipRunner)
         @torch.no_grad()
         def train_epoch(self, u, p, n, batch_size, lr, l2=0.0, optimizer="SGD", chunk=64):

@@ -1,0 +1,154 @@
+// wr_eval.hip — full-ranking evaluation without the [n_eval, n_items] host matrix.
+//
+// Reference: BaseRunner.interface + evaluate_method (src/helpers/BaseRunner.py:218-258, 50-92) with
+// BPRMF/LightGCN.full_predict (src/models/general/BPRMF.py:82-91): scores = U[user] @ I^T for every item, the user's
+// train/dev/test items set to -inf (BaseRunner.py:246-255), rank of the ground-truth = its position in the descending
+// order.  Only the rank is needed by every metric (HR/NDCG/RECALL/PRECISION@k), and
+//     rank_i = 1 + #{ j not masked for user_i : score(i, j) > score(i, target_i) }.
+// This is the one GEMM-shaped piece of the path, so it runs on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32
+// accumulate = a k-ordered fmaf chain, MI355X_MICROARCH.md "Matrix cores"), one 32x32 score tile per wave per item tile,
+// compared against the target score (computed with the same k-ordered chain, so the target's own column can never count)
+// and counted in registers.  A workgroup = 4 waves = 128 evaluation rows sharing each 32-item tile through LDS.
+#include "wr_common.h"
+
+namespace wr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kEvalRows = 128;   // evaluation rows per workgroup (32 per wave)
+constexpr int kEvalChunk = 2048; // items per workgroup along grid.y
+
+// score of the ground-truth item, as the k-ordered fmaf chain the MFMA accumulates
+__global__ __launch_bounds__(kBlock) void eval_target_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
+                                                              const int64_t *__restrict__ eu, const int64_t *__restrict__ et,
+                                                              int64_t n, float *__restrict__ tscore) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float *a = U + eu[i] * (int64_t)D, *b = I + et[i] * (int64_t)D;
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s = fmaf(a[k], b[k], s);
+    tscore[i] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void eval_rank_kernel(const float *__restrict__ U, const float *__restrict__ I, int D,
+                                                            int64_t n_items, const int64_t *__restrict__ eu,
+                                                            const float *__restrict__ tscore, int64_t n,
+                                                            const int64_t *__restrict__ mask_ptr, const int *__restrict__ mask_idx,
+                                                            int *__restrict__ rank_cnt) {
+    extern __shared__ float lds[];
+    const int ldw = D + 1;                       // padded row: conflict-free column reads
+    float *ue = lds;                             // [kEvalRows][ldw]
+    float *it = lds + kEvalRows * ldw;           // [32][ldw]
+    unsigned *rowmask = reinterpret_cast<unsigned *>(it + 32 * ldw);   // [kEvalRows]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t e0 = (int64_t)blockIdx.x * kEvalRows;
+    const int64_t c0 = (int64_t)blockIdx.y * kEvalChunk;
+    // stage the evaluation users' rows
+    for (int idx = threadIdx.x; idx < kEvalRows * D; idx += kBlock) {
+        const int r = idx / D, k = idx - r * D;
+        const int64_t e = e0 + r;
+        ue[r * ldw + k] = (e < n) ? U[eu[e] * (int64_t)D + k] : 0.f;
+    }
+    // per evaluation row (threads 0..127): cursor into the user's ascending mask list, positioned at this chunk
+    int64_t cur = 0, cend = 0;
+    if (threadIdx.x < kEvalRows && mask_ptr != nullptr && e0 + threadIdx.x < n) {
+        const int64_t uu = eu[e0 + threadIdx.x];
+        int64_t lo = mask_ptr[uu], hi = mask_ptr[uu + 1];
+        cend = hi;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)mask_idx[mid] < c0) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+    }
+    // this lane's 16 accumulator rows inside its wave's 32-row slab and their target scores
+    float trow[16];
+    int cnt[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int64_t e = e0 + wave * 32 + row;
+        trow[reg] = (e < n) ? tscore[e] : 3.4e38f;   // rows past the end never count
+        cnt[reg] = 0;
+    }
+    const int col = lane & 31, half = lane >> 5;
+    const float *arow = ue + (wave * 32 + col) * ldw + half;   // A[i = lane&31][k = lane>>5]
+    const float *brow = it + col * ldw + half;                  // B[k = lane>>5][j = lane&31]
+    for (int64_t j0 = c0; j0 < c0 + kEvalChunk && j0 < n_items; j0 += 32) {
+        __syncthreads();                                        // previous tile fully consumed (and ue staged)
+        for (int idx = threadIdx.x; idx < 32 * D; idx += kBlock) {
+            const int r = idx / D, k = idx - r * D;
+            it[r * ldw + k] = (j0 + r < n_items) ? I[(j0 + r) * (int64_t)D + k] : 0.f;
+        }
+        if (threadIdx.x < kEvalRows) {                          // which of the tile's 32 items are masked for this row
+            unsigned m = 0;
+            while (cur < cend && (int64_t)mask_idx[cur] < j0 + 32) {
+                if ((int64_t)mask_idx[cur] >= j0) m |= 1u << (unsigned)(mask_idx[cur] - j0);
+                ++cur;
+            }
+            rowmask[threadIdx.x] = m;
+        }
+        __syncthreads();
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k0 = 0; k0 < D; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k0], brow[k0], acc, 0, 0, 0);
+        const bool col_ok = j0 + col < n_items;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const bool masked = (rowmask[wave * 32 + row] >> col) & 1u;
+            cnt[reg] += (col_ok && !masked && acc[reg] > trow[reg]) ? 1 : 0;
+        }
+    }
+    // sum over the 32 item columns (lanes of one half), one integer atomic per row and workgroup
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        int v = cnt[reg];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        const int64_t e = e0 + wave * 32 + row;
+        if (col == 0 && e < n && v) atomicAdd(&rank_cnt[e], v);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void eval_finish_kernel(int *__restrict__ rank, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) rank[i] += 1;
+}
+
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" {
+
+int32_t wr_rank_eval(const float *user_mat, int64_t n_user_rows, const float *item_tab, int64_t n_items, int32_t D,
+                     const int64_t *eval_user, const int64_t *eval_target, int64_t n, const int64_t *mask_ptr,
+                     const int32_t *mask_idx, int32_t *rank, float *target_score, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_mat, n_user_rows, D, "user_mat")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    WR_REQUIRE(eval_user && eval_target && rank && target_score, WR_E_NULL, "rank_eval: NULL argument");
+    WR_REQUIRE((mask_ptr == nullptr) == (mask_idx == nullptr), WR_E_NULL, "rank_eval: mask_ptr and mask_idx go together");
+    WR_REQUIRE(n >= 0 && n < (int64_t(1) << 31), WR_E_SHAPE, "rank_eval: n out of range");
+    WR_REQUIRE(D <= 256, WR_E_RANGE, "rank_eval supports D <= 256 (LDS staging); got %d", D);
+    if (n == 0) return WR_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    WR_HIP(hipMemsetAsync(rank, 0, (size_t)n * 4, stream));
+    hipLaunchKernelGGL(eval_target_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, user_mat, item_tab,
+                       D, eval_user, eval_target, n, target_score);
+    WR_LAUNCH_CHECK("eval_target_kernel");
+    const size_t lds = ((size_t)(kEvalRows + 32) * (D + 1) + kEvalRows) * 4;
+    const dim3 grid((unsigned)((n + kEvalRows - 1) / kEvalRows), (unsigned)((n_items + kEvalChunk - 1) / kEvalChunk));
+    if (lds > 64 * 1024)
+        WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    hipLaunchKernelGGL(eval_rank_kernel, grid, dim3(kBlock), lds, stream, user_mat, item_tab, D, n_items, eval_user, target_score,
+                       n, mask_ptr, mask_idx, rank);
+    WR_LAUNCH_CHECK("eval_rank_kernel");
+    hipLaunchKernelGGL(eval_finish_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rank, n);
+    WR_LAUNCH_CHECK("eval_finish_kernel");
+    return WR_OK;
+}
+
+}  // extern "C"

@@ -339,6 +339,25 @@ def clicked_csr(train_clicked_set, n_users, device):
     return torch.from_numpy(ptr).to(device), torch.from_numpy(idx).to(device)
 
 
+# ----------------------------------------------------------------------------------------------- evaluation
+def rank_eval(user_mat, item_tab, eval_user, eval_target, mask_ptr=None, mask_idx=None):
+    """Rank of the ground-truth item among all (unmasked) items for every evaluation row (reference
+    BaseRunner.interface + evaluate_method); returns (rank int32 [n], target_score fp32 [n])."""
+    _req(user_mat, torch.float32, "user_mat", 2)
+    _req(item_tab, torch.float32, "item_tab", 2)
+    eu, et = _idx64(eval_user.reshape(-1), "eval_user"), _idx64(eval_target.reshape(-1), "eval_target")
+    if mask_ptr is not None:
+        _req(mask_ptr, torch.int64, "mask_ptr", 1)
+        _req(mask_idx, torch.int32, "mask_idx", 1)
+    n = eu.numel()
+    rank = torch.empty(n, dtype=torch.int32, device=user_mat.device)
+    tsc = torch.empty(n, dtype=torch.float32, device=user_mat.device)
+    abi.check(abi.lib().wr_rank_eval(_p(user_mat), user_mat.shape[0], _p(item_tab), item_tab.shape[0], user_mat.shape[1],
+                                     _p(eu), _p(et), n, _p(mask_ptr), _p(mask_idx), _p(rank), _p(tsc), _stream()),
+              "wr_rank_eval")
+    return rank, tsc
+
+
 # ----------------------------------------------------------------------------------------------- optimizers
 def sgd_dense(tab, grad, lr, l2=0.0, stamp=None, step_id=0):
     abi.check(abi.lib().wr_sgd_dense(_p(_req(tab, torch.float32, "tab", 2)), tab.shape[0], tab.shape[1],

@@ -198,6 +198,11 @@ def make_lightgcn(general_model_cls):
             u, p, n = self._batch(feed_dict)
             return _LightGcnLoss.apply(self.user_embedding.weight, self.item_embedding.weight, self, u, p, n)
 
+        def eval_factors(self):
+            """propagated (user, item) matrices: their inner products are the ranking scores (LightGCN.py:177-187)"""
+            Ua, Ia = self.forward()
+            return Ua.contiguous(), Ia.contiguous()
+
         def full_predict(self, feed_dict):
             dev = self.user_embedding.weight.device
             Ua, Ia = self.forward()

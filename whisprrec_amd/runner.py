@@ -194,8 +194,14 @@ class BaseRunner(object):
         return "(" + format_metric(self.evaluate(dataset, self.topk, self.metrics)) + ")"
 
 
+def _metrics_from_ranks(gt_rank, topk, metrics):
+    return BaseRunner.metrics_from_ranks(gt_rank, topk, metrics)
+
+
 def make_hip_runner(base_runner_cls):
     class HipRunner(base_runner_cls):
+        metrics_from_ranks = staticmethod(_metrics_from_ranks)   # the reference's BaseRunner has no such helper
+
         @staticmethod
         def parse_runner_args(parser):
             parser.add_argument("--device_epoch_prep", type=int, default=0,
@@ -226,6 +232,32 @@ def make_hip_runner(base_runner_cls):
             if int(err.item()) == 1:
                 raise IndexError("user id out of range in the training frame")
             return users[order], items[order], neg[order]
+
+        def evaluate(self, dataset, topks, metrics):
+            """Full-ranking evaluation on the device when the model exposes its factor matrices (``eval_factors``): ranks
+            from wr_rank_eval (MFMA score tiles + on-the-fly masking + counting), no [n_eval, n_items] matrix, no Python
+            loop over rows (reference BaseRunner.py:218-258).  Otherwise the inherited host path."""
+            model = dataset.model
+            if not hasattr(model, "eval_factors") or model.eval_factors()[0].shape[1] > 256:
+                return base_runner_cls.evaluate(self, dataset, topks, metrics)
+            from . import hip_ops
+            model.eval()
+            user_mat, item_mat = model.eval_factors()
+            dev = user_mat.device
+            cache = getattr(self, "_mask_cache", None)
+            if cache is None or cache[0] is not dataset.corpus or cache[1] != bool(model.test_all):
+                if model.test_all:
+                    corpus = dataset.corpus
+                    merged = {u: corpus.train_clicked_set.get(u, set()) | corpus.residual_clicked_set.get(u, set())
+                              for u in set(corpus.train_clicked_set) | set(corpus.residual_clicked_set)}
+                    ptr, idx = hip_ops.clicked_csr(merged, user_mat.shape[0], dev)
+                else:
+                    ptr = idx = None
+                cache = self._mask_cache = (dataset.corpus, bool(model.test_all), ptr, idx)
+            eu = torch.from_numpy(np.ascontiguousarray(dataset.data["user_id"])).to(dev)
+            et = torch.from_numpy(np.ascontiguousarray(dataset.data["item_id"])).to(dev)
+            rank, _ = hip_ops.rank_eval(user_mat.contiguous(), item_mat.contiguous(), eu, et, cache[2], cache[3])
+            return self.metrics_from_ranks(rank.cpu().numpy().astype(np.int64), topks, metrics)
 
         def fit(self, dataset, epoch=-1):
             model = dataset.model
