@@ -95,6 +95,47 @@ def cpu_baseline(args, seconds):
             "host_cpus": os.cpu_count()}
 
 
+def cpu_torch_sequence(args, seconds):
+    """The aten-op sequence the reference issues on its CPU path — BPRMF.predict (src/models/general/BPRMF.py:69-80) +
+    BPRLoss (src/utils/loss.py:38) + loss.backward() + torch.optim.SGD.step() (src/helpers/BaseRunner.py:196-199), dense
+    gradients and all — restated with stock PyTorch CPU ops on the box's host cores (the reference's own files do not
+    travel to the GPU box).  Same table shapes, batch size and id distribution; bounded to ~`seconds`."""
+    torch.manual_seed(3407)
+    ue = torch.nn.Embedding(args.users, args.emb)
+    ie = torch.nn.Embedding(args.items, args.emb)
+    torch.nn.init.xavier_normal_(ue.weight.data)
+    torch.nn.init.xavier_normal_(ie.weight.data)
+    opt = torch.optim.SGD(list(ue.parameters()) + list(ie.parameters()), lr=args.lr, weight_decay=0)
+    g = torch.Generator().manual_seed(3407)
+    batches = [(torch.randint(0, args.users, (args.batch,), generator=g), torch.randint(0, args.items, (args.batch,), generator=g),
+                torch.randint(1, args.items, (args.batch,), generator=g)) for _ in range(4)]
+
+    def step(k):
+        u, p, n = batches[k % len(batches)]
+        opt.zero_grad()
+        user_e, pos_e, neg_e = ue(u), ie(p), ie(n)
+        pos = torch.mul(user_e, pos_e).sum(dim=1)
+        neg = torch.mul(user_e, neg_e).sum(dim=1)
+        loss = -torch.log(1e-10 + torch.sigmoid(pos - neg)).mean()
+        loss.backward()
+        opt.step()
+        return loss.detach().cpu().data.numpy()
+
+    step(0)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        step(k)
+        k += 1
+        if time.perf_counter() - t0 >= seconds and k >= 2:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": k * args.batch / dt, "unit": "triplets/s", "cores": torch.get_num_threads(),
+            "kind": "torch-cpu aten sequence of the reference step (dense gradients, torch.optim.SGD)",
+            "sample": "%d steps of B=%d on %dx%d tables, D=%d, %.1f s" % (k, args.batch, args.users, args.items, args.emb, dt),
+            "host_cpus": os.cpu_count()}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -249,6 +290,7 @@ def main():
            "roofline": roofline}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        out["cpu_baseline_torch"] = cpu_torch_sequence(args, max(4.0, args.cpu_seconds / 2))
     print(json.dumps(out))
 
 
