@@ -85,7 +85,7 @@ int32_t wr_bprmf_plan_build_i32(const int32_t *u, const int32_t *p, const int32_
 
 /* Hand-written builder producing bit-identical plan arrays: bucket scatter + per-bucket LDS bitonic sort (one HBM
  * round trip per pair instead of the radix sort's four).  Applies when wr_bprmf_plan_fast_workspace_bytes(...) > 0
- * (batch sizes up to ~250 K).  flags: int32[2] on device, caller-zeroed; flags[0] = index out of range (as err_flag
+ * (batch sizes up to ~1 M, any table size).  flags: int32[2] on device, caller-zeroed; flags[0] = index out of range (as err_flag
  * above), flags[1] = a bucket overflowed (heavily skewed ids) -> the plan is INVALID and the caller must rebuild it
  * with wr_bprmf_plan_build_*.  Asynchronous like every other call; the caller reads the flags after the stream work. */
 int64_t wr_bprmf_plan_fast_workspace_bytes(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items);

@@ -15,17 +15,18 @@
 //   F3 item scatter : same tiling over the batch's [positives | negatives] occurrences:
 //                     (item<<32 | side<<31 | sorted index) appended to bucket (batch, item >> shift_i)
 //   F4 item sort    : like F2; writes oc_item/oc_src, flags rows with several occurrences in tp/tn
-// Buckets have a fixed capacity (2x the mean + 64); if any bucket overflows (skewed ids) flags[1] is set and the
+// 256 buckets per batch (1024 for batches beyond 128 K), any table size.  Buckets have a fixed capacity (2x the mean + 64); if any bucket overflows (skewed ids) flags[1] is set and the
 // caller must rebuild with the generic builder — never a wrong plan.  Ties are impossible (composites are unique), so
 // the unstable bucket placement does not leak into the result.
 #include "wr_common.h"
 
 namespace wr {
 
-constexpr int kBuckets = 256;    // row-range buckets per batch
+constexpr int kMaxBuckets = 1024;  // row-range buckets per batch: 256 up to B = 128 K, 1024 beyond
 constexpr int kMaxCap = 4096;    // largest bucket handled in LDS (2 x 32 KiB of 8-byte composites + counters)
 
 struct FastLayout {
+    int nbk;                  // buckets per batch (power of two)
     unsigned user_bits, item_bits, shift_u, shift_i;
     int cap_u, cap_i;         // bucket capacities (entries)
     int64_t nb;
@@ -44,17 +45,18 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
     L.nb = (n + B - 1) / B;
     L.user_bits = bits_for_rows(n_users);
     L.item_bits = bits_for_rows(n_items);
-    L.shift_u = L.user_bits > 8 ? L.user_bits - 8 : 0;
-    L.shift_i = L.item_bits > 8 ? L.item_bits - 8 : 0;
-    const int64_t cu = 2 * ((B + kBuckets - 1) / kBuckets) + 64;
-    const int64_t ci = 2 * ((2 * B + kBuckets - 1) / kBuckets) + 64;
+    L.nbk = B > 131072 ? 1024 : 256;
+    const unsigned bbits = L.nbk == 1024 ? 10 : 8;
+    L.shift_u = L.user_bits > bbits ? L.user_bits - bbits : 0;
+    L.shift_i = L.item_bits > bbits ? L.item_bits - bbits : 0;
+    const int64_t cu = 2 * ((B + L.nbk - 1) / L.nbk) + 64;
+    const int64_t ci = 2 * ((2 * B + L.nbk - 1) / L.nbk) + 64;
     if (cu > kMaxCap || ci > kMaxCap) return false;
-    if (L.shift_u > 12 || L.shift_i > 12) return false;  // 1 << shift LDS counters per bucket: tables up to 2^20 rows
     L.cap_u = (int)cu;
     L.cap_i = (int)ci;
-    L.cnt_bytes = align_up(2 * L.nb * kBuckets * 4, 256);
-    L.ubuf_bytes = align_up(L.nb * kBuckets * (int64_t)L.cap_u * 8, 256);
-    L.ibuf_bytes = align_up(L.nb * kBuckets * (int64_t)L.cap_i * 8, 256);
+    L.cnt_bytes = align_up(2 * L.nb * L.nbk * 4, 256);
+    L.ubuf_bytes = align_up(L.nb * L.nbk * (int64_t)L.cap_u * 8, 256);
+    L.ibuf_bytes = align_up(L.nb * L.nbk * (int64_t)L.cap_i * 8, 256);
     L.total = L.cnt_bytes + L.ubuf_bytes + L.ibuf_bytes;
     return true;
 }
@@ -65,11 +67,12 @@ constexpr int kMaxGroup = 32;     // longest run of equal rows a single thread o
 // Reserve bucket slots for a tile: ranks inside the tile come from LDS atomics, one global atomic per non-empty
 // (tile, bucket) reserves the range.  Placement order inside a bucket is arbitrary; the bucket sort fixes it.
 template <int PER_THREAD, typename KeyFn>
-__device__ __forceinline__ void tile_scatter(int n_local, int *__restrict__ cnt_global, unsigned long long *__restrict__ buf,
-                                             int cap, int *__restrict__ flags, KeyFn key_of) {
-    __shared__ int hist[kBuckets];
-    __shared__ int base[kBuckets];
-    for (int j = threadIdx.x; j < kBuckets; j += kBlock) hist[j] = 0;
+__device__ __forceinline__ void tile_scatter(int n_local, int nbk, int *__restrict__ cnt_global,
+                                             unsigned long long *__restrict__ buf, int cap, int *__restrict__ flags,
+                                             KeyFn key_of) {
+    __shared__ int hist[kMaxBuckets];
+    __shared__ int base[kMaxBuckets];
+    for (int j = threadIdx.x; j < nbk; j += kBlock) hist[j] = 0;
     __syncthreads();
     unsigned long long key[PER_THREAD];
     int bucket[PER_THREAD], rank[PER_THREAD];
@@ -83,7 +86,7 @@ __device__ __forceinline__ void tile_scatter(int n_local, int *__restrict__ cnt_
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < kBuckets; j += kBlock) base[j] = hist[j] ? atomicAdd(&cnt_global[j], hist[j]) : 0;
+    for (int j = threadIdx.x; j < nbk; j += kBlock) base[j] = hist[j] ? atomicAdd(&cnt_global[j], hist[j]) : 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
@@ -97,14 +100,15 @@ __device__ __forceinline__ void tile_scatter(int n_local, int *__restrict__ cnt_
 
 template <typename Idx>
 __global__ __launch_bounds__(kBlock) void fast_user_scatter(const Idx *__restrict__ u, int64_t n, int64_t B, int tiles_per_batch,
-                                                             int64_t n_users, unsigned shift_u, int cap_u, int *__restrict__ cnt_u,
+                                                             int nbk, int64_t n_users, unsigned shift_u, int cap_u,
+                                                             int *__restrict__ cnt_u,
                                                              unsigned long long *__restrict__ ubuf, int *__restrict__ flags) {
     const int64_t b = blockIdx.x / tiles_per_batch;
     const int tile = blockIdx.x % tiles_per_batch;
     const int64_t lo = b * B + (int64_t)tile * kTile;
     const int64_t batch_end = (b * B + B < n) ? (b * B + B) : n;
     const int n_local = (int)((lo + kTile <= batch_end) ? kTile : (batch_end > lo ? batch_end - lo : 0));
-    tile_scatter<kTile / kBlock>(n_local, cnt_u + b * kBuckets, ubuf + b * kBuckets * (int64_t)cap_u, cap_u, flags,
+    tile_scatter<kTile / kBlock>(n_local, nbk, cnt_u + b * nbk, ubuf + b * nbk * (int64_t)cap_u, cap_u, flags,
                                  [&](int e, int &bucket) {
                                      const int64_t i = lo + e;
                                      int64_t uu = (int64_t)u[i];
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(kBlock) void fast_user_scatter(const Idx *__restric
 // Item occurrences of a tile of user-sorted triplets: composite (item, side, sorted index) — positives before negatives
 // for equal items, then by sorted triplet index: the order a stable sort of [positives | negatives] gives.
 __global__ __launch_bounds__(kBlock) void fast_item_scatter(const int *__restrict__ tp, const int *__restrict__ tn, int64_t n,
-                                                             int64_t B, int tiles_per_batch, int64_t n_items, unsigned shift_i,
-                                                             int cap_i,
+                                                             int64_t B, int tiles_per_batch, int nbk, int64_t n_items,
+                                                             unsigned shift_i, int cap_i,
                                                              int *__restrict__ cnt_i, unsigned long long *__restrict__ ibuf,
                                                              int *__restrict__ flags) {
     const int64_t b = blockIdx.x / tiles_per_batch;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void fast_item_scatter(const int *__restric
     const int64_t Bb = ((b * B + B < n) ? B : (n - b * B));
     const int64_t lo2 = (int64_t)tile * kTile;            // offset into the batch's 2*Bb occurrences: [pos | neg]
     const int n_local = (int)((lo2 + kTile <= 2 * Bb) ? kTile : (2 * Bb > lo2 ? 2 * Bb - lo2 : 0));
-    tile_scatter<kTile / kBlock>(n_local, cnt_i + b * kBuckets, ibuf + b * kBuckets * (int64_t)cap_i, cap_i, flags,
+    tile_scatter<kTile / kBlock>(n_local, nbk, cnt_i + b * nbk, ibuf + b * nbk * (int64_t)cap_i, cap_i, flags,
                                  [&](int e, int &bucket) {
                                      const int64_t o = lo2 + e;
                                      const int side = o >= Bb;
@@ -231,7 +235,8 @@ __device__ __forceinline__ void bucket_sort_lds(const unsigned long long *__rest
 
 template <typename Idx>
 __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__ p, const Idx *__restrict__ nn, int64_t n,
-                                                          int64_t B, int64_t n_items, int cap_u, unsigned shift_u, unsigned bin_bits,
+                                                          int64_t B, int nbk, int64_t n_items, int cap_u, unsigned shift_u,
+                                                          unsigned bin_bits,
                                                           const int *__restrict__ cnt_u, const unsigned long long *__restrict__ ubuf,
                                                           int *__restrict__ tu, int *__restrict__ tp, int *__restrict__ tn,
                                                           int *__restrict__ torig, int *__restrict__ flags) {
@@ -240,10 +245,10 @@ __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__
     __shared__ int wave_tot[kBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_u;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_u);
-    const int64_t b = blockIdx.x / kBuckets;
-    const int bucket = blockIdx.x % kBuckets;
+    const int64_t b = blockIdx.x / nbk;
+    const int bucket = blockIdx.x % nbk;
     const int count = min(cnt_u[blockIdx.x], cap_u);
-    const int prefix = bucket_prefix(cnt_u + b * kBuckets, bucket, cap_u, scratch);
+    const int prefix = bucket_prefix(cnt_u + b * nbk, bucket, cap_u, scratch);
     if (count == 0) return;
     const unsigned long long *src = ubuf + (int64_t)blockIdx.x * cap_u;
     for (int j = threadIdx.x; j < count; j += kBlock) kin[j] = src[j];
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, int cap_i, unsigned shift_i, unsigned bin_bits,
+__global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, int nbk, int cap_i, unsigned shift_i,
+                                                          unsigned bin_bits,
                                                           const int *__restrict__ cnt_i, const unsigned long long *__restrict__ ibuf,
                                                           int *__restrict__ oc_item, int *__restrict__ oc_src, int *__restrict__ tp,
                                                           int *__restrict__ tn, int *__restrict__ flags) {
@@ -275,10 +281,10 @@ __global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, i
     __shared__ int wave_tot[kBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_i;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_i);
-    const int64_t b = blockIdx.x / kBuckets;
-    const int bucket = blockIdx.x % kBuckets;
+    const int64_t b = blockIdx.x / nbk;
+    const int bucket = blockIdx.x % nbk;
     const int count = min(cnt_i[blockIdx.x], cap_i);
-    const int prefix = bucket_prefix(cnt_i + b * kBuckets, bucket, cap_i, scratch);
+    const int prefix = bucket_prefix(cnt_i + b * nbk, bucket, cap_i, scratch);
     if (count == 0) return;
     const unsigned long long *src = ibuf + (int64_t)blockIdx.x * cap_i;
     for (int j = threadIdx.x; j < count; j += kBlock) kin[j] = src[j];
@@ -316,14 +322,14 @@ static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char *ws = reinterpret_cast<char *>(workspace);
     int *cnt_u = reinterpret_cast<int *>(ws);
-    int *cnt_i = cnt_u + L.nb * kBuckets;
+    int *cnt_i = cnt_u + L.nb * L.nbk;
     unsigned long long *ubuf = reinterpret_cast<unsigned long long *>(ws + L.cnt_bytes);
     unsigned long long *ibuf = reinterpret_cast<unsigned long long *>(ws + L.cnt_bytes + L.ubuf_bytes);
-    WR_HIP(hipMemsetAsync(cnt_u, 0, (size_t)(2 * L.nb * kBuckets * 4), stream));
+    WR_HIP(hipMemsetAsync(cnt_u, 0, (size_t)(2 * L.nb * L.nbk * 4), stream));
     const int tiles_u = (int)((B + kTile - 1) / kTile), tiles_i = (int)((2 * B + kTile - 1) / kTile);
-    const unsigned gb = (unsigned)(L.nb * kBuckets);
+    const unsigned gb = (unsigned)(L.nb * L.nbk);
     hipLaunchKernelGGL((fast_user_scatter<Idx>), dim3((unsigned)(L.nb * tiles_u)), dim3(kBlock), 0, stream, u, n, B, tiles_u,
-                       n_users, L.shift_u, L.cap_u, cnt_u, ubuf, flags);
+                       L.nbk, n_users, L.shift_u, L.cap_u, cnt_u, ubuf, flags);
     WR_LAUNCH_CHECK("fast_user_scatter");
     // bins per bucket: about one composite per bin (twice the mean bucket population, power of two), never more
     // bins than distinct low-bit patterns
@@ -335,13 +341,13 @@ static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_
     const unsigned bb_u = bins_for(L.cap_u, L.shift_u), bb_i = bins_for(L.cap_i, L.shift_i);
     const size_t lds_u = (size_t)L.cap_u * 16 + ((size_t)4 << bb_u);
     const size_t lds_i = (size_t)L.cap_i * 16 + ((size_t)4 << bb_i);
-    hipLaunchKernelGGL((fast_user_sort<Idx>), dim3(gb), dim3(kBlock), lds_u, stream, p, nn, n, B, n_items, L.cap_u, L.shift_u,
-                       bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags);
+    hipLaunchKernelGGL((fast_user_sort<Idx>), dim3(gb), dim3(kBlock), lds_u, stream, p, nn, n, B, L.nbk, n_items, L.cap_u,
+                       L.shift_u, bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags);
     WR_LAUNCH_CHECK("fast_user_sort");
     hipLaunchKernelGGL(fast_item_scatter, dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B, tiles_i,
-                       n_items, L.shift_i, L.cap_i, cnt_i, ibuf, flags);
+                       L.nbk, n_items, L.shift_i, L.cap_i, cnt_i, ibuf, flags);
     WR_LAUNCH_CHECK("fast_item_scatter");
-    hipLaunchKernelGGL(fast_item_sort, dim3(gb), dim3(kBlock), lds_i, stream, n, B, L.cap_i, L.shift_i, bb_i, cnt_i, ibuf,
+    hipLaunchKernelGGL(fast_item_sort, dim3(gb), dim3(kBlock), lds_i, stream, n, B, L.nbk, L.cap_i, L.shift_i, bb_i, cnt_i, ibuf,
                        oc_item, oc_src, tp, tn, flags);
     WR_LAUNCH_CHECK("fast_item_sort");
     return WR_OK;
