@@ -143,3 +143,34 @@ def test_save_load_roundtrip(g2, tmp_path):
         model.user_embeddings.weight.zero_()
     model.load_model()
     assert np.array_equal(model.user_embeddings.weight.detach().cpu().numpy(), g2["sgd_U0"])
+
+
+@pytest.mark.parametrize("model_name", ["BPRMF", "LightGCN"])
+def test_full_train_loop_with_eval_and_checkpoint(g2, tmp_path, model_name, caplog):
+    """The whole main.py flow after the reader (main.py:66-84): model -> datasets -> runner.train (fit, evaluate on dev, save best,
+    early-stop bookkeeping, reload best) -> print_res on test, with HipRunner and its device evaluation."""
+    import logging
+    from whisprrec_amd import runner
+    from whisprrec_amd.bprmf import BPRMF
+    from whisprrec_amd.lightgcn import LightGCN
+    cls = {"BPRMF": BPRMF, "LightGCN": LightGCN}[model_name]
+    args = _args(model_path=str(tmp_path / "ckpt" / "m.pt"), epoch=3, lr=0.5 if model_name == "BPRMF" else 0.05, gcn_layers=2,
+                 reg_weight=1e-5, device_epoch_prep=0, random_seed=3407)
+    seed_all(3407)
+    corpus = ml100k_corpus(g2)
+    rng = np.random.RandomState(0)
+    for phase in ("dev", "test"):
+        uu = rng.randint(0, 943, 800); ii = rng.randint(0, 1574, 800)
+        corpus.data_df[phase] = {"user_id": uu, "item_id": ii}
+        for a, b in zip(uu.tolist(), ii.tolist()):
+            corpus.residual_clicked_set[a].add(b)
+    model = cls(args, corpus).to(args.device)
+    data = {ph: cls.Dataset(model, corpus, ph) for ph in ("train", "dev", "test")}
+    r = runner.HipRunner(args)
+    with caplog.at_level(logging.INFO):
+        r.train(data)
+    lines = [rec.getMessage() for rec in caplog.records if rec.getMessage().startswith("Epoch")]
+    assert len(lines) == 3 and all("loss=" in l and "dev=(" in l for l in lines) and any(l.rstrip().endswith("*") for l in lines)
+    assert (tmp_path / "ckpt" / "m.pt").exists()
+    res = r.print_res(data["test"])
+    assert res.startswith("(") and "NDCG@10" in res and "HR@20" in res

@@ -27,6 +27,46 @@ HipRunner.__name__ = "HipRunner"
 """
 
 
+LIGHTGCN_STUB = """from models.BaseModel import GeneralModel
+from whisprrec_amd.lightgcn import bind
+
+LightGCNHip = bind(GeneralModel)
+LightGCNHip.__name__ = "LightGCNHip"
+"""
+SASREC_STUB = """from models.BaseModel import SequentialModel
+from whisprrec_amd.sasrec import bind
+
+SASRecHip = bind(SequentialModel)
+SASRecHip.__name__ = "SASRecHip"
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference tree not present on this machine")
+@pytest.mark.parametrize("model,stub,where,nparams,extra", [
+    ("LightGCNHip", LIGHTGCN_STUB, ("models", "general"), 161088, ["--gcn_layers", "2"]),
+    ("SASRecHip", SASREC_STUB, ("models", "sequential"), None, ["--emb_size", "64", "--num_layers", "1", "--num_heads", "4"]),
+])
+def test_other_model_stubs_drop_into_reference_main(tmp_path, model, stub, where, nparams, extra):
+    """LightGCN and SASRec stubs: discovered by name, flags chained, reader (SeqReader for SASRec) and model built by the
+    reference's main.py; then the first HIP call must refuse the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    shutil.copytree(os.path.join(REF, "src"), tmp_path / "src")
+    shutil.copytree(os.path.join(REF, "data", "ml-100k"), tmp_path / "data" / "ml-100k")
+    (tmp_path / "src" / where[0] / where[1] / (model + ".py")).write_text(stub)
+    env = dict(os.environ, PYTHONPATH=ROOT, PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "main.py", "--model_name", model, "--optimizer", "SGD", "--lr", "0.01", "--dataset", "ml-100k",
+           "--path", str(tmp_path / "data") + "/", "--log_file", str(tmp_path / "log.txt"), "--model_path",
+           str(tmp_path / "m.pt"), "--num_workers", "0", "--gpu", "", "--epoch", "1"] + extra
+    res = subprocess.run(cmd, cwd=tmp_path / "src", env=env, capture_output=True, text=True, timeout=900)
+    out = res.stdout + res.stderr
+    assert "#params:" in out
+    if nparams is not None:
+        assert "#params: %d" % nparams in out
+    assert res.returncode != 0 and "WhisprRecHipError" in out and "no CPU fallback" in out
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference tree not present on this machine")
 @pytest.mark.parametrize("runner", ["HipRunner", "BaseRunner"])
 def test_stubs_drop_into_reference_main(tmp_path, runner):
