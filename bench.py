@@ -43,6 +43,11 @@ def parse():
     ap.add_argument("--no-phase-events", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--plan-builder", default="auto", choices=["auto", "generic", "fast"])
+    ap.add_argument("--interactions", type=int, default=100_000_000, help="interactions per epoch (sets the rotation period)")
+    ap.add_argument("--shard-mode", default="rotate", choices=["rotate", "alltoall"],
+                    help="N>1: 'rotate' = stratified schedule, item blocks move round the ring (whisprrec_amd/rotating.py); "
+                         "'alltoall' = per-step row exchange (whisprrec_amd/sharded.py)")
+    ap.add_argument("--parts", type=int, default=2, help="rotate mode: parts per item block (overlap of transfer and compute)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even with one rank (testing)")
     return ap.parse_args()
 
@@ -150,6 +155,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        if args.shard_mode == "rotate":
+            from whisprrec_amd import rotating
+            return rotating.bench_main(args, rank, world, local_rank)
         from whisprrec_amd import sharded
         return sharded.bench_main(args, rank, world, local_rank)
 

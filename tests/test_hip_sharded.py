@@ -88,3 +88,35 @@ def test_plan_slots_equals_generic_slotify(pg):
         order = lo + np.argsort(u_loc.cpu().numpy()[lo:hi], kind="stable")
         assert np.array_equal(tu[lo:hi], u_loc.cpu().numpy()[order])
         assert np.array_equal(tp[lo:hi], sp.cpu().numpy()[order]) and np.array_equal(tn[lo:hi], sn.cpu().numpy()[order])
+
+
+def test_rotating_world1_matches_oracle(pg):
+    """stratified schedule with one rank: the ring send is a self-copy through RCCL P2P, the local arithmetic is the
+    single-GPU run path on the held block (whisprrec_amd/rotating.py)"""
+    from whisprrec_amd.rotating import RotatingBprmf
+    dev = pg
+    rng = np.random.RandomState(21)
+    nU, nI, D, B, lr, parts = 3000, 2001, 64, 4096, 0.3, 2
+    U = (rng.standard_normal((nU, D)) * 0.3).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) * 0.3).astype(np.float32)
+    m = RotatingBprmf(nU, nI, D, dev, parts=parts)
+    m.load_full(torch.from_numpy(U), torch.from_numpy(I))
+    Uo, Io = U.copy(), I.copy()
+    ref, got = [], []
+    for sub in range(3):
+        per_part = [2, 3]
+        us, ps, ns = [], [], []
+        for k in range(parts):
+            lo, hi = m.part_range(m.held, k)
+            cnt = per_part[k] * B
+            us.append(rng.randint(0, nU, cnt)); ps.append(rng.randint(lo, hi, cnt)); ns.append(rng.randint(max(lo, 1), hi, cnt))
+        u, p, n = np.concatenate(us), np.concatenate(ps), np.concatenate(ns)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        got.append(m.global_losses(m.run_subepoch(t(u), t(p), t(n), per_part, B, lr)).cpu().numpy())
+        for k in range(sum(per_part)):
+            sl = slice(k * B, (k + 1) * B)
+            ref.append(oracle.bprmf_step_sgd(Uo, Io, u[sl], p[sl], n[sl], lr, 0.0))
+    Uf, If = m.gather_full()
+    assert rel_err(np.concatenate(got), np.asarray(ref)) < 1e-5
+    assert rel_err(Uf.cpu().numpy(), Uo) < 1e-5
+    assert rel_err(If.cpu().numpy(), Io) < 1e-5

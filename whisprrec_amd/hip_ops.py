@@ -208,6 +208,18 @@ class BatchPlan:
     def batch_len(self, k):
         return min(self.batch_size, self.n_triplets - k * self.batch_size)
 
+    def record_stream(self, stream):
+        """A plan built on a side stream and consumed on `stream`: tell the caching allocator, so that dropping the plan
+        while its steps are still queued does not hand the arrays to the next build."""
+        ts = [self.tu, self.tp, self.tn, self.oc_item, self.oc_src, self.meta]
+        if self.torig is not None:
+            ts.append(self.torig)
+        if self.hot is not None:
+            for arrs, _, _ in self.hot["sides"]:
+                ts += arrs
+        for t in ts:
+            t.record_stream(stream)
+
 
 class BprmfTables:
     """The two embedding tables plus the scratch the step kernels need.  Tables are plain fp32 tensors

@@ -1,0 +1,321 @@
+"""Stratified multi-GPU BPRMF: user rows fixed per rank, item-row blocks ROTATING around the ring of GPUs.
+
+Why a second multi-GPU mode.  The all-to-all mode of ``sharded.py`` moves two item rows and two gradient rows per triplet
+over xGMI (≈450 B each way per triplet at D=64): with ≈50–60 GB/s per point-to-point link that is several times the
+HBM time of the step itself.  xGMI is point-to-point, so the MI355X-first layout moves SHARDS, not rows:
+
+  * users are partitioned over the G ranks (owner = u % G) and never move;
+  * items are partitioned into G blocks (block = i % G, local index i // G); at sub-epoch r rank g HOLDS block (g + r) % G
+    and trains only on the stratum (users of g) x (items of the held block) — positives AND negatives from that block;
+  * the G local batches of one step touch disjoint user rows and disjoint item rows, so their union is one exact
+    batch-synchronous SGD step over the global batch (same semantics as BaseRunner.fit, reference
+    src/helpers/BaseRunner.py:196-199) with NO per-step communication — each rank simply runs the single-GPU fused step;
+  * after the stratum the block moves to rank g-1 (ring send/recv over one xGMI link): per epoch every block visits every
+    rank once, (G-1)/G of the item table crosses each link once per epoch instead of ≈1 KB per triplet.
+This is the stratified SGD schedule of DSGD (Gemulla et al., KDD 2011) applied to BPR triplets.  What changes with
+respect to the reference's sampling: the negative of a triplet is drawn from the positive's block (a fixed pseudo-random
+1/G subset of the items, i % G) instead of from all items, and batches are drawn per stratum.
+
+Overlap.  Each block is split into ``parts`` contiguous row ranges; a stratum is trained part by part and a part is sent on
+a side stream as soon as its last step is enqueued, while the next part trains — with 2 parts the transfer of one half
+hides behind the compute of the other.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .sharded import n_local_rows
+
+
+class HipLocal:
+    """Local training of one stratum with the single-GPU fused path.  A stratum is a list of segments (one per part of the
+    held block: its row range of the block as the item table, indices relative to that range).  Batches are planned
+    ``chunk`` at a time on a side stream, one chunk ahead of the steps (a plan depends only on the indices, never on the
+    tables) — across segment boundaries too — and a segment's steps are issued from native code, so the part can be handed
+    to the ring as soon as they are queued."""
+
+    def __init__(self, chunk=64):
+        from . import hip_ops
+        self.ops = hip_ops
+        self.chunk = int(chunk)
+        self.plan_stream = None
+
+    def plan(self, U, segments, batch):
+        """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order"""
+        if self.plan_stream is None:
+            self.plan_stream = torch.cuda.Stream(device=U.device)
+        B = int(batch)
+        todo = []                                                           # (segment, first batch, n batches) in run order
+        segs = []
+        for k, (rows, u, p, n) in enumerate(segments):
+            nb = (u.numel() + B - 1) // B
+            segs.append({"tabs": self.ops.BprmfTables(U, rows) if nb else None, "u": u, "p": p, "n": n, "nb": nb})
+            todo += [(k, f, min(self.chunk, nb - f)) for f in range(0, nb, self.chunk)]
+        h = {"segs": segs, "B": B, "todo": todo, "at": 0, "tag": 0, "next": None}
+        self.plan_stream.wait_stream(torch.cuda.current_stream(U.device))   # the index tensors are ready
+        self._prefetch(h)
+        return h
+
+    def _prefetch(self, h):
+        """enqueue the plan of the next chunk on the side stream"""
+        if h["at"] >= len(h["todo"]):
+            h["next"] = None
+            return
+        k, first, c = h["todo"][h["at"]]
+        h["at"] += 1
+        sg, B = h["segs"][k], h["B"]
+        lo, hi = first * B, min(sg["u"].numel(), (first + c) * B)
+        with torch.cuda.stream(self.plan_stream):
+            plan = self.ops.BatchPlan(sg["u"][lo:hi], sg["p"][lo:hi], sg["n"][lo:hi], B, sg["tabs"].U.shape[0],
+                                      sg["tabs"].I.shape[0], validate=False, ws_tag="rot%d" % h["tag"])
+            ready = torch.cuda.Event()
+            ready.record(self.plan_stream)
+        h["tag"] ^= 1
+        h["next"] = (k, first, plan, ready)
+
+    def run(self, handle, seg, lr, losses):
+        """all steps of segment `seg` (segments must be run in order); losses: one slot per step"""
+        h = handle
+        sg = h["segs"][seg]
+        if sg["nb"] == 0:
+            return
+        main = torch.cuda.current_stream(sg["tabs"].U.device)
+        pos = 0
+        while pos < sg["nb"]:
+            k, first, plan, ready = h["next"]
+            assert k == seg and first == pos, "segments must be run in order"
+            main.wait_event(ready)
+            plan.record_stream(main)
+            sg["tabs"].run_sgd(plan, 0, plan.n_batches, lr, losses=losses[pos:pos + plan.n_batches])
+            pos += plan.n_batches
+            self._prefetch(h)                                               # steps are queued: build the next plan beside them
+
+
+class RotatingBprmf:
+    def __init__(self, n_users, n_items, emb_size, device, parts=2, local=None, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n_users, self.n_items, self.D = int(n_users), int(n_items), int(emb_size)
+        self.device, self.parts = device, max(1, int(parts))
+        self.local = local if local is not None else HipLocal()
+        self.U = torch.zeros(n_local_rows(self.n_users, self.rank, self.world), self.D, device=device)
+        self.cap = (self.n_items + self.world - 1) // self.world          # rows of the largest item block
+        self.held = self.rank                                               # block currently held
+        self.I = torch.zeros(self.cap, self.D, device=device)              # held block (rows beyond its size unused)
+        self.I_in = torch.zeros(self.cap, self.D, device=device)           # landing buffer for the next block
+        self.comm_stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        self._pending = []                                                  # (work handles, event) of parts in flight
+
+    # ------------------------------------------------------------------ layout helpers
+    def block_rows(self, block):
+        return n_local_rows(self.n_items, block, self.world)
+
+    def part_range(self, block, part):
+        """contiguous local-row range [lo, hi) of part `part` of `block`"""
+        n = self.block_rows(block)
+        per = (n + self.parts - 1) // self.parts
+        return min(n, part * per), min(n, (part + 1) * per)
+
+    def load_full(self, U_full, I_full):
+        self.U.copy_(U_full[self.rank::self.world].to(self.device))
+        blk = I_full[self.held::self.world].to(self.device)
+        self.I[:blk.shape[0]].copy_(blk)
+
+    def init_xavier(self, seed):
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed * 1000 + self.rank)
+        self.U.normal_(0.0, math.sqrt(2.0 / (self.n_users + self.D)), generator=g)
+        self.I.normal_(0.0, math.sqrt(2.0 / (self.n_items + self.D)), generator=g)
+
+    def gather_full(self):
+        """Re-assemble the reference's checkpoint layout (user table, item table) on every rank."""
+        G, D = self.world, self.D
+        capu = (self.n_users + G - 1) // G
+        pu = torch.zeros(capu, D, device=self.device)
+        pu[:self.U.shape[0]] = self.U
+        us = [torch.empty_like(pu) for _ in range(G)]
+        dist.all_gather(us, pu, group=self.group)
+        U_full = torch.stack(us, dim=1).reshape(capu * G, D)[:self.n_users]
+        held = torch.tensor([self.held], device=self.device)
+        hs = [torch.empty_like(held) for _ in range(G)]
+        dist.all_gather(hs, held, group=self.group)
+        bs = [torch.empty_like(self.I) for _ in range(G)]
+        dist.all_gather(bs, self.I.contiguous(), group=self.group)
+        by_block = [None] * G
+        for r in range(G):
+            by_block[int(hs[r].item())] = bs[r]
+        I_full = torch.stack(by_block, dim=1).reshape(self.cap * G, D)[:self.n_items]
+        return U_full, I_full
+
+    # ------------------------------------------------------------------ ring rotation
+    def _send_part(self, part):
+        """enqueue: part `part` of the held block -> rank-1, same part of the next block <- rank+1 (side stream)"""
+        G = self.world
+        if G == 1:
+            return
+        lo, hi = self.part_range(self.held, part)
+        nxt = (self.held + 1) % G
+        lo2, hi2 = self.part_range(nxt, part)
+        dst, src = (self.rank - 1) % G, (self.rank + 1) % G
+        send_buf, recv_buf = self.I[lo:hi], self.I_in[lo2:hi2]
+        ops = []
+        if hi > lo:
+            ops.append(dist.P2POp(dist.isend, send_buf, dst, group=self.group))
+        if hi2 > lo2:
+            ops.append(dist.P2POp(dist.irecv, recv_buf, src, group=self.group))
+        if not ops:
+            return
+        if self.comm_stream is not None:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))          # the part's last step is enqueued
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(done)
+                works = dist.batch_isend_irecv(ops)
+                for w in works:
+                    w.wait()                                              # comm stream waits for the transfer
+                ev = torch.cuda.Event()
+                ev.record(self.comm_stream)
+            self._pending.append(ev)
+        else:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def _finish_rotation(self):
+        """all parts of the next block have landed: make it the held block"""
+        if self.world == 1:
+            return
+        if self.comm_stream is not None:
+            for ev in self._pending:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+        self._pending = []
+        self.I, self.I_in = self.I_in, self.I
+        self.held = (self.held + 1) % self.world
+
+    # ------------------------------------------------------------------ training
+    def run_subepoch(self, u, p, n, steps_per_part, batch, lr):
+        """One stratum: u, p, n are LOCAL indices in batch order (u rows of the user shard, p and n rows of the held block);
+        the first steps_per_part[0] batches use items of part 0 only, the next steps_per_part[1] batches items of part 1, ...
+        As soon as the steps of a part are enqueued the part is handed to the ring.  Every rank must pass the same
+        steps_per_part.  Returns the per-step local losses (mean over ranks = loss of the global batch)."""
+        nb = int(sum(steps_per_part))
+        losses = torch.zeros(nb, dtype=torch.float32, device=self.device)
+        # the global batch is the union of the G local batches: its mean loss has 1/(G*B) coefficients.  The local kernels
+        # use 1/B, and the local batches touch disjoint rows, so dividing the learning rate by G gives the same update.
+        lr = lr / self.world
+        B = int(batch)
+        segments, first = [], 0
+        per_part = [int(steps_per_part[k]) if k < len(steps_per_part) else 0 for k in range(self.parts)]
+        for k, st in enumerate(per_part):
+            lo, hi = self.part_range(self.held, k)
+            sl = slice(first * B, min(u.numel(), (first + st) * B))
+            segments.append((self.I[lo:hi], u[sl], p[sl] - lo, n[sl] - lo))
+            first += st
+        handle = self.local.plan(self.U, segments, B)
+        first = 0
+        for k, st in enumerate(per_part):
+            if st > 0:
+                self.local.run(handle, k, lr, losses[first:first + st])
+                first += st
+            self._send_part(k)
+        self._finish_rotation()
+        return losses
+
+    def global_losses(self, local_losses):
+        out = local_losses.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out / self.world
+
+
+def stratum_steps(n_interactions, world, batch):
+    """steps per (rank, sub-epoch) stratum when an epoch of n_interactions is spread over world^2 strata"""
+    return max(1, int(round(n_interactions / float(world * world * batch))))
+
+
+# ---------------------------------------------------------------------------------------------------- bench (N > 1)
+def bench_main(args, rank, world, local_rank):
+    """bench.py --gpus N (N > 1): weak scaling, batch args.batch per GPU, stratified schedule.  The block rotation happens as
+    often as a full epoch of args.interactions interactions would require (every stratum_steps steps), inside the timed
+    region."""
+    import json
+    import os
+    import time
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=dev)
+    B, D, K, W = args.batch, args.emb, args.steps, args.warmup
+    S = stratum_steps(args.interactions, world, B)
+    model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts)
+    model.init_xavier(3407)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3407 * 7919 + rank)
+
+    def synth_subepoch(held, steps):
+        """uniform users of this rank, positives and negatives uniform inside each part of block `held` (item 0, which the
+        reference never draws as a negative, is local row 0 of block 0); batches of part 0 first, then part 1, ..."""
+        per_part = [steps // model.parts + (1 if k < steps % model.parts else 0) for k in range(model.parts)]
+        us, ps, ns = [], [], []
+        for k, st in enumerate(per_part):
+            lo, hi = model.part_range(held, k)
+            cnt = st * B
+            us.append(torch.randint(0, model.U.shape[0], (cnt,), generator=g, device=dev, dtype=torch.int32))
+            ps.append(torch.randint(lo, max(hi, lo + 1), (cnt,), generator=g, device=dev, dtype=torch.int32))
+            first = lo + 1 if (held == 0 and lo == 0) else lo
+            ns.append(torch.randint(first, max(hi, first + 1), (cnt,), generator=g, device=dev, dtype=torch.int32))
+        return torch.cat(us), torch.cat(ps), torch.cat(ns), per_part
+
+    def make_schedule(count, held0):
+        """(held block, data) for every stratum of `count` steps — generated BEFORE the timed region, like the N=1 bench"""
+        sched, done, held = [], 0, held0
+        while done < count:
+            st = min(S, count - done)
+            sched.append(synth_subepoch(held, st))
+            held = (held + 1) % world
+            done += st
+        return sched, held
+
+    def run_schedule(sched):
+        return torch.cat([model.run_subepoch(u, p, n, per_part, B, args.lr) for (u, p, n, per_part) in sched])
+
+    warm, held_after = make_schedule(W, model.held)
+    timed, _ = make_schedule(K, held_after)
+    torch.cuda.synchronize()
+
+    run_schedule(warm)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    local_losses = run_schedule(timed)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    losses = model.global_losses(local_losses)
+    dt = float(dt.item())
+    if rank == 0:
+        lv = losses.cpu().numpy()
+        assert np.all(np.isfinite(lv)), "non-finite loss"
+        value = world * K * B / dt
+        step_bytes = (6 * D * 4 + 12) * B          # per GPU, upper bound (no in-batch duplicates)
+        block_mb = model.cap * D * 4 / 1e6
+        out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K,
+               "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BPRMF emb_size=%d, synthetic %d users x %d items (uniform ids), batch %d per GPU "
+                                      "(global %d), SGD l2=0; user rows sharded over %d GPUs, item-row blocks rotating "
+                                      "round the ring every %d steps (stratified schedule of a %d-interaction epoch), plan "
+                                      "build and rotation inside the timed region" %
+                                      (D, args.users, args.items, B, B * world, world, S, args.interactions),
+                          "batch_per_gpu": B, "global_batch": B * world, "emb_size": D, "optimizer": "SGD", "l2": 0.0,
+                          "lr": args.lr, "parallelism": "stratified-rotation x%d" % world, "steps_per_stratum": S,
+                          "block_MB": block_mb, "parts": model.parts},
+               "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
+               "roofline": {"bound": "hbm", "achieved": step_bytes * K / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                            "frac": step_bytes * K / dt / 1e9 / 8000.0, "traffic": None,
+                            "kernel": "whole step per GPU incl. block rotation (per-kernel numbers: N=1 run)"}}
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
