@@ -190,6 +190,36 @@ int32_t wr_adam_dense(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_r
                       float beta2, float eps, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K5 (lazy, exact)  The same optimizers without the table passes.  torch.optim.Adam / SGD(weight_decay) move every
+ * row at every step (BaseRunner.py:120-124,199); between two batches that contain it a row's trajectory depends on
+ * the row alone, so it is replayed when the row is next needed: last_step[r] = number of the last optimizer step
+ * applied to row r (0 = none).  Same element arithmetic, order and per-step bias corrections as wr_adam_dense /
+ * wr_sgd_dense: the tables come out bit-identical to the dense kernels'.
+ *   step t of a batch:  wr_*_rows_lazy(grad = NULL) on the batch's rows  ->  gradients (wr_bprmf_grads / the fused SGD
+ *   step)  ->  wr_adam_rows_lazy(grad) ;  before evaluation / checkpoint: wr_*_catchup_all.
+ * keys: row ids of one batch with equal ids adjacent (the plan's tu / oc_item arrays); each distinct row is done once.
+ * consts: device array, consts[2s] = lr/(1-beta1^s), consts[2s+1] = 1/sqrt(1-beta2^s) for s < n_consts (fill a host
+ * copy with wr_adam_consts — the expressions wr_adam_dense evaluates on the host).
+ * --------------------------------------------------------------------------------------------------- */
+int32_t wr_adam_consts(int64_t first_step, int64_t n_steps, float lr, float beta1, float beta2, float *consts_host);
+/* grad == NULL: replay the rows up to step adam_step-1.  grad != NULL ([n_rows, D], rows of the batch valid): replay
+ * up to adam_step-1 if still needed, then apply step adam_step with the gradient row. */
+int32_t wr_adam_rows_lazy(float *tab, float *exp_avg, float *exp_avg_sq, int32_t *last_step, int64_t n_rows, int32_t D,
+                          const int32_t *keys, int64_t n_keys, const float *grad, int64_t adam_step, const float *consts,
+                          int64_t n_consts, float l2, float beta1, float beta2, float eps, void *stream);
+/* every row up to and including step adam_step (zero gradients) */
+int32_t wr_adam_catchup_all(float *tab, float *exp_avg, float *exp_avg_sq, int32_t *last_step, int64_t n_rows, int32_t D,
+                            int64_t adam_step, const float *consts, int64_t n_consts, float l2, float beta1, float beta2,
+                            float eps, void *stream);
+/* SGD weight decay: replay w <- w - lr*l2*w on the batch's rows up to step-1 and mark them as done for `step` (the fused
+ * step wr_bprmf_step_sgd applies step `step` itself, decay included, to exactly these rows).  lr and l2 must not have
+ * changed since the rows' last step (call wr_sgd_catchup_all before changing them). */
+int32_t wr_sgd_rows_lazy(float *tab, int32_t *last_step, int64_t n_rows, int32_t D, const int32_t *keys, int64_t n_keys,
+                         int64_t step, float lr, float l2, void *stream);
+int32_t wr_sgd_catchup_all(float *tab, int32_t *last_step, int64_t n_rows, int32_t D, int64_t step, float lr, float l2,
+                           void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K9  nn.Embedding forward / embedding_dense_backward with padding_idx —
  *     src/models/sequential/SASRec.py:60,84,105-106; also the row-exchange primitive of the
  *     row-sharded multi-GPU step.

@@ -40,13 +40,20 @@ def tables(nU, nI, D, seed=1):
     return (torch.randn(nU, D, generator=g, device=dev) * 0.01, torch.randn(nI, D, generator=g, device=dev) * 0.01)
 
 
-def bprmf_case(name, nU, nI, D, B, NB, opt="SGD", l2=0.0, zipf=0.0):
+def bprmf_case(name, nU, nI, D, B, NB, opt="SGD", l2=0.0, zipf=0.0, lazy=False):
     U, I = tables(nU, nI, D)
     u, p, n = synth(nU, nI, NB * B, zipf)
     tabs = hip_ops.BprmfTables(U, I)
     t0 = time.perf_counter(); plan = hip_ops.BatchPlan(u, p, n, B, nU, nI); torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
     t0 = time.perf_counter(); plan = hip_ops.BatchPlan(u, p, n, B, nU, nI); torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
-    if opt == "SGD" and l2 == 0.0:
+    if lazy:
+        st = hip_ops.LazyOptimizerState(tabs, opt, 1e-3 if opt == "Adam" else 0.05, l2)
+        for k in range(NB):                                   # first pass: rows reach their steady-state replay lengths
+            st.step(plan, k)
+        t = ev_time(lambda k: st.step(plan, k), NB)
+        t_flush = ev_time(lambda k: st.flush(), 1)
+        name += " [exact lazy rows; flush of all rows after %d steps: %.0f us]" % (2 * NB, t_flush * 1e6)
+    elif opt == "SGD" and l2 == 0.0:
         tabs.run_sgd(plan, 0, min(NB, 4), 0.05)
         t = ev_time(lambda k: tabs.run_sgd(plan, 0, NB, 0.05), 1) / NB
     elif opt == "SGD":
@@ -165,6 +172,11 @@ if __name__ == "__main__":
         bprmf_case("C2 SGD l2=1e-6 (dense weight decay)", 1_000_000, 1_000_000, 64, 65536, 16, l2=1e-6)
         bprmf_case("C2 Adam (dense, reference default optimizer)", 1_000_000, 1_000_000, 64, 65536, 16, opt="Adam")
         bprmf_case("C2 Zipf(1.0) items", 1_000_000, 1_000_000, 64, 65536, 64, zipf=1.0)
+    if "lazy" in which:
+        bprmf_case("C2 SGD l2=1e-6", 1_000_000, 1_000_000, 64, 65536, 64, l2=1e-6, lazy=True)
+        bprmf_case("C2 Adam", 1_000_000, 1_000_000, 64, 65536, 64, opt="Adam", lazy=True)
+        bprmf_case("C2 Adam Zipf(1.0) items", 1_000_000, 1_000_000, 64, 65536, 64, opt="Adam", zipf=1.0, lazy=True)
+        bprmf_case("C2 Adam B=2048", 1_000_000, 1_000_000, 64, 2048, 256, opt="Adam", lazy=True)
     if "c4" in which:
         bprmf_case("C4 shapes on ONE GPU: 10Mx10M D=128 SGD l2=0", 10_000_000, 10_000_000, 128, 65536, 32)
     if "c3" in which:

@@ -72,24 +72,48 @@ def test_hip_runner_device_epoch_prep(g2):
     assert losses[-1] < losses[0] - 1e-4 and all(np.isfinite(losses))
 
 
-def test_hip_runner_adam_default_optimizer(g2):
-    """reference default optimizer (BaseRunner.py:36), README learning rate"""
+@pytest.mark.parametrize("lazy", [0, 1])
+def test_hip_runner_adam_default_optimizer(g2, lazy):
+    """reference default optimizer (BaseRunner.py:36), README learning rate; --lazy_optimizer 1 = exact lazy rows, read
+    through state_dict() (which brings all rows up to date)"""
     from whisprrec_amd import runner
-    args, corpus, model, ds = _setup(g2, optimizer="Adam", lr=1e-3, epoch=1)
+    args, corpus, model, ds = _setup(g2, optimizer="Adam", lr=1e-3, epoch=1, lazy_optimizer=lazy)
     r = runner.HipRunner(args)
     mean = r.fit(ds, epoch=1)
+    assert (model.optimizer.lazy_state is not None) == bool(lazy)
+    sd = model.state_dict()
     assert abs(mean - g2["adam_epoch_mean"][0]) / g2["adam_epoch_mean"][0] < TOL
-    assert rel_err(model.user_embeddings.weight.detach().cpu().numpy(), g2["adam_Uend"]) < 1e-4
-    assert rel_err(model.item_embeddings.weight.detach().cpu().numpy(), g2["adam_Iend"]) < 1e-4
+    assert rel_err(sd["user_embeddings.weight"].cpu().numpy(), g2["adam_Uend"]) < 1e-4
+    assert rel_err(sd["item_embeddings.weight"].cpu().numpy(), g2["adam_Iend"]) < 1e-4
 
 
-def test_reference_runner_loop_adam(g2):
+@pytest.mark.parametrize("lazy", [0, 1])
+def test_reference_runner_loop_adam(g2, lazy):
     from whisprrec_amd import runner
-    args, corpus, model, ds = _setup(g2, optimizer="Adam", lr=1e-3, epoch=1)
+    args, corpus, model, ds = _setup(g2, optimizer="Adam", lr=1e-3, epoch=1, lazy_optimizer=lazy)
     r = runner.BaseRunner(args)
     mean = r.fit(ds, epoch=1)
+    model.eval()                                     # what evaluate() does first (BaseRunner.py:229): flushes lazy rows
     assert abs(mean - g2["adam_epoch_mean"][0]) / g2["adam_epoch_mean"][0] < TOL
     assert rel_err(model.user_embeddings.weight.detach().cpu().numpy(), g2["adam_Uend"]) < 1e-4
+
+
+def test_lazy_and_dense_runs_are_bit_identical(g2):
+    """two epochs with evaluation in between, SGD with weight decay and Adam with weight decay: same losses, same tables"""
+    from whisprrec_amd import runner
+    for opt, lr in (("SGD", 0.5), ("Adam", 1e-3)):
+        out = []
+        for lazy in (0, 1):
+            args, corpus, model, ds = _setup(g2, optimizer=opt, lr=lr, l2=1e-4, lazy_optimizer=lazy)
+            r = runner.HipRunner(args)
+            means = []
+            for ep in (1, 2):
+                means.append(r.fit(ds, epoch=ep))
+                model.eval(); model.train()
+            sd = model.state_dict()
+            out.append((means, sd["user_embeddings.weight"].clone(), sd["item_embeddings.weight"].clone()))
+        assert out[0][0] == out[1][0]
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
 
 
 def test_torch_optimizer_on_dense_grads(g1):

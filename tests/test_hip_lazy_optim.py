@@ -1,0 +1,84 @@
+"""Exact lazy optimizers (wr_adam_rows_lazy / wr_sgd_rows_lazy / wr_*_catchup_all, whisprrec_amd/csrc/wr_lazy.hip): after
+flush() the tables must hold the SAME BITS as the dense torch.optim semantics kernels (wr_adam_dense, fused SGD step +
+wr_sgd_decay_untouched), which tests/test_hip_bprmf.py pins to the reference's goldens (BaseRunner.py:120-124,199)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(nU, nI, D, B, steps, seed, zipf=False):
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    U = torch.randn(nU, D, generator=g, device=dev) * 0.1
+    I = torch.randn(nI, D, generator=g, device=dev) * 0.1
+    rng = np.random.RandomState(seed)
+    u = rng.randint(0, nU, steps * B)
+    p = np.minimum((rng.pareto(1.0, steps * B) * 3).astype(np.int64), nI - 1) if zipf else rng.randint(0, nI, steps * B)
+    n = rng.randint(1, nI, steps * B)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    plan = hip_ops.BatchPlan(t(u), t(p), t(n), B, nU, nI)
+    return hip_ops, U, I, plan
+
+
+@pytest.mark.parametrize("l2", [0.0, 1e-3])
+@pytest.mark.parametrize("D,zipf", [(64, False), (32, True), (128, False), (20, False)])
+def test_lazy_adam_bit_identical_to_dense(l2, D, zipf):
+    nU, nI, B, steps, lr = 3000, 2500, 256, 24, 1e-2
+    hip_ops, U, I, plan = _setup(nU, nI, D, B, steps, 7 + D, zipf)
+    # dense (what FusedOptimizer did before)
+    Ud, Id = U.clone(), I.clone()
+    td = hip_ops.BprmfTables(Ud, Id)
+    z = torch.zeros_like
+    gU, gI, mU, vU, mI, vI = z(Ud), z(Id), z(Ud), z(Ud), z(Id), z(Id)
+    dense_loss = []
+    for k in range(steps):
+        loss, sid = td.grads(plan, k, gU, gI)
+        dense_loss.append(loss.clone())
+        hip_ops.adam_dense(Ud, mU, vU, gU, k + 1, lr, l2, stamp=td.stamp_u, step_id=sid)
+        hip_ops.adam_dense(Id, mI, vI, gI, k + 1, lr, l2, stamp=td.stamp_i, step_id=sid)
+    # lazy
+    Ul, Il = U.clone(), I.clone()
+    tl = hip_ops.BprmfTables(Ul, Il)
+    st = hip_ops.LazyOptimizerState(tl, "Adam", lr, l2)
+    lazy_loss = []
+    for k in range(steps):
+        lazy_loss.append(st.step(plan, k).clone())
+        if k == steps // 2:
+            st.flush()                                    # a flush in the middle (evaluation) must change nothing
+    assert not torch.equal(Ul, Ud)                        # untouched rows are behind until the flush
+    st.flush()
+    assert torch.equal(torch.stack(lazy_loss), torch.stack(dense_loss))
+    for a, b in ((Ul, Ud), (Il, Id), (st.m_u, mU), (st.v_u, vU), (st.m_i, mI), (st.v_i, vI)):
+        assert torch.equal(a, b)
+    assert int(st.last_u.min()) == steps and int(st.last_i.min()) == steps
+
+
+@pytest.mark.parametrize("D", [64, 24])
+def test_lazy_sgd_weight_decay_bit_identical_to_dense(D):
+    nU, nI, B, steps, lr, l2 = 4000, 1500, 512, 20, 0.1, 1e-2
+    hip_ops, U, I, plan = _setup(nU, nI, D, B, steps, 3 + D, True)
+    Ud, Id = U.clone(), I.clone()
+    td = hip_ops.BprmfTables(Ud, Id)
+    dense_loss = [td.step_sgd(plan, k, lr, l2).clone() for k in range(steps)]
+    Ul, Il = U.clone(), I.clone()
+    st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ul, Il), "SGD", lr, l2)
+    lazy_loss = [st.step(plan, k).clone() for k in range(steps)]
+    st.flush()
+    assert torch.equal(torch.stack(lazy_loss), torch.stack(dense_loss))
+    assert torch.equal(Ul, Ud) and torch.equal(Il, Id)
+
+
+def test_lazy_adam_consts_table_grows():
+    nU, nI, D, B, steps = 300, 200, 16, 32, 3
+    hip_ops, U, I, plan = _setup(nU, nI, D, B, steps, 1)
+    st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(U, I), "Adam", 1e-3, 0.0)
+    st.t = st.n_consts - 2                                # pretend many steps were taken (rows replay them: all-zero moments)
+    st.last_u.fill_(st.t); st.last_i.fill_(st.t); st.flushed_at = st.t
+    n0 = st.n_consts
+    for k in range(steps):
+        st.step(plan, k)
+    st.flush()
+    assert st.n_consts == 2 * n0 and torch.isfinite(U).all()

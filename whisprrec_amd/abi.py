@@ -46,6 +46,13 @@ SIGNATURES = {
     "wr_sgd_dense": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_f32, c_f32, c_vp]),
     "wr_adam_dense": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32,
                               c_f32, c_vp]),
+    "wr_adam_consts": (c_i32, [c_i64, c_i64, c_f32, c_f32, c_f32, c_vp]),
+    "wr_adam_rows_lazy": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,
+                                  c_f32, c_f32, c_vp]),
+    "wr_adam_catchup_all": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
+                                    c_vp]),
+    "wr_sgd_rows_lazy": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_i64, c_f32, c_f32, c_vp]),
+    "wr_sgd_catchup_all": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_f32, c_vp]),
     "wr_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "wr_scatter_add_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "wr_scatter_add_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_i64, c_vp]),

@@ -25,15 +25,24 @@ from . import hip_ops, host
 
 class FusedOptimizer:
     """Duck-types what BaseRunner.fit needs from ``model.optimizer`` (``zero_grad``/``step``) and applies
-    torch.optim.SGD / torch.optim.Adam semantics (reference BaseRunner.py:120-124) inside the HIP step."""
+    torch.optim.SGD / torch.optim.Adam semantics (reference BaseRunner.py:120-124) inside the HIP step.
 
-    def __init__(self, model, name, lr, l2):
+    Both optimizers are DENSE in the reference whenever they carry state or weight decay: Adam moves every row at every
+    step, SGD with ``--l2`` shrinks every row.  ``lazy`` selects how that is computed: 0 = table passes every step
+    (wr_adam_dense / wr_sgd_decay_untouched), 1 = exact lazy rows (hip_ops.LazyOptimizerState: a row is replayed when a
+    batch needs it, all rows in ``flush()``; same bits, no table passes), -1 = lazy when the tables hold at least 8 rows
+    per batch row and 65536 rows in all."""
+
+    def __init__(self, model, name, lr, l2, lazy=-1):
         if name not in ("SGD", "Adam"):
             raise ValueError("FusedOptimizer supports SGD and Adam, got %r" % name)
         self.model, self.name, self.lr, self.l2 = model, name, float(lr), float(l2)
         self.betas, self.eps = (0.9, 0.999), 1e-8
         self.adam_step = 0
         self.state = None
+        self.lazy = int(lazy)
+        self.lazy_state = None
+        self._lazy_decided = None
 
     def zero_grad(self, set_to_none=True):
         self.model._pending = None
@@ -47,6 +56,35 @@ class FusedOptimizer:
                           "mI": z(m.item_embeddings.weight), "vI": z(m.item_embeddings.weight)}
         return self.state
 
+    def _use_lazy(self, tabs, batch):
+        """decided at the first step and kept: the two representations of the optimizer state are not mixed"""
+        if self._lazy_decided is None:
+            rows = tabs.U.shape[0] + tabs.I.shape[0]
+            stateful = self.name == "Adam" or self.l2 != 0.0
+            self._lazy_decided = stateful and (self.lazy == 1 or (self.lazy == -1 and rows >= 65536 and rows >= 8 * batch))
+        return self._lazy_decided
+
+    @torch.no_grad()
+    def step_batch(self, tabs, plan, k, loss_out=None):
+        """zero_grad / predict / backward / optimizer.step of BaseRunner.py:196-199 on batch k of the plan"""
+        if self._use_lazy(tabs, plan.batch_size):
+            if self.lazy_state is None:
+                self.lazy_state = hip_ops.LazyOptimizerState(tabs, self.name, self.lr, self.l2, self.betas, self.eps)
+            elif self.lazy_state.tabs.U.data_ptr() != tabs.U.data_ptr() or self.lazy_state.tabs.I.data_ptr() != tabs.I.data_ptr():
+                raise RuntimeError("the embedding tables were re-allocated after optimizer steps had been taken")
+            self.adam_step += 1
+            return self.lazy_state.step(plan, k, loss_out=loss_out)
+        if self.name == "SGD":
+            return tabs.step_sgd(plan, k, self.lr, self.l2, loss_out=loss_out)
+        st = self._adam_state()
+        self.adam_step += 1
+        loss, sid = tabs.grads(plan, k, st["gU"], st["gI"], loss_out=loss_out)
+        hip_ops.adam_dense(tabs.U, st["mU"], st["vU"], st["gU"], self.adam_step, self.lr, self.l2, self.betas[0],
+                           self.betas[1], self.eps, stamp=tabs.stamp_u, step_id=sid)
+        hip_ops.adam_dense(tabs.I, st["mI"], st["vI"], st["gI"], self.adam_step, self.lr, self.l2, self.betas[0],
+                           self.betas[1], self.eps, stamp=tabs.stamp_i, step_id=sid)
+        return loss
+
     @torch.no_grad()
     def step(self):
         m = self.model
@@ -56,16 +94,13 @@ class FusedOptimizer:
         m._pending = None
         tabs = m._tables()
         plan = hip_ops.BatchPlan(u, p, n, u.numel(), m.user_num, m.item_num)
-        if self.name == "SGD":
-            tabs.step_sgd(plan, 0, self.lr, self.l2, loss_out=loss_buf)
-        else:
-            st = self._adam_state()
-            self.adam_step += 1
-            _, sid = tabs.grads(plan, 0, st["gU"], st["gI"], loss_out=loss_buf)
-            hip_ops.adam_dense(tabs.U, st["mU"], st["vU"], st["gU"], self.adam_step, self.lr, self.l2, self.betas[0],
-                               self.betas[1], self.eps, stamp=tabs.stamp_u, step_id=sid)
-            hip_ops.adam_dense(tabs.I, st["mI"], st["vI"], st["gI"], self.adam_step, self.lr, self.l2, self.betas[0],
-                               self.betas[1], self.eps, stamp=tabs.stamp_i, step_id=sid)
+        self.step_batch(tabs, plan, 0, loss_out=loss_buf)
+
+    def flush(self):
+        """bring every row up to the current step (no-op for the dense representation); called by the model before
+        anything but a training step reads the tables"""
+        if self.lazy_state is not None:
+            self.lazy_state.flush()
 
 
 class _DeferredBprLoss(torch.autograd.Function):
@@ -119,6 +154,8 @@ def make_bprmf(general_model_cls):
             parser.add_argument("--embedding_size", type=int, default=64, help="Size of embedding vectors.")
             parser.add_argument("--fused", type=int, default=1,
                                 help="1: loss value is produced by the fused step at optimizer.step(); 0: eagerly in predict().")
+            parser.add_argument("--lazy_optimizer", type=int, default=-1,
+                                help="Adam / SGD with --l2: 1 = exact lazy row updates, 0 = dense table passes, -1 = by table size.")
             return general_model_cls.parse_model_args(parser)
 
         def __init__(self, args, corpus):
@@ -138,7 +175,8 @@ def make_bprmf(general_model_cls):
             self._tabs = None
             name = getattr(args, "optimizer", None)
             if name in ("SGD", "Adam") and hasattr(args, "lr"):
-                self.optimizer = FusedOptimizer(self, name, args.lr, getattr(args, "l2", 0.0))
+                self.optimizer = FusedOptimizer(self, name, args.lr, getattr(args, "l2", 0.0),
+                                                getattr(args, "lazy_optimizer", -1))
 
         # ------------------------------------------------------------------ plumbing
         def _tables(self):
@@ -151,8 +189,28 @@ def make_bprmf(general_model_cls):
             dev = self.user_embeddings.weight.device
             return tuple(feed_dict[k].to(dev).reshape(-1) for k in ("user_id", "pos_item", "neg_items"))
 
+        def _sync_tables(self):
+            """lazy optimizer rows -> current (a no-op otherwise); every reader of the tables outside a step calls it"""
+            opt = getattr(self, "optimizer", None)
+            if isinstance(opt, FusedOptimizer):
+                opt.flush()
+
+        def train(self, mode=True):
+            if not mode:
+                self._sync_tables()           # model.eval() precedes every evaluation (BaseRunner.py:229)
+            return super().train(mode)
+
+        def state_dict(self, *a, **kw):
+            self._sync_tables()               # save_model (BaseModel.py:48-53)
+            return super().state_dict(*a, **kw)
+
+        def load_state_dict(self, *a, **kw):
+            self._sync_tables()               # load_model (BaseModel.py:55-59): pending replays belong to the old weights
+            return super().load_state_dict(*a, **kw)
+
         # ------------------------------------------------------------------ reference surface
         def forward(self, user, item):
+            self._sync_tables()
             return (hip_ops.gather_rows(self.user_embeddings.weight.data, user),
                     hip_ops.gather_rows(self.item_embeddings.weight.data, item))
 
@@ -169,12 +227,14 @@ def make_bprmf(general_model_cls):
 
         def full_predict(self, feed_dict):
             """scores[B, n_items] = U[user] @ I^T (BPRMF.py:82-91).  Evaluation only: a plain GEMM, left to rocBLAS."""
+            self._sync_tables()
             dev = self.user_embeddings.weight.device
             user_e = hip_ops.gather_rows(self.user_embeddings.weight.data, feed_dict["user_id"].to(dev))
             return torch.matmul(user_e, self.item_embeddings.weight.data.t())
 
         def eval_factors(self):
             """(user matrix, item matrix) whose inner products are the ranking scores (full_predict, BPRMF.py:82-91)."""
+            self._sync_tables()
             return self.user_embeddings.weight.data, self.item_embeddings.weight.data
 
         # ------------------------------------------------------------------ native epoch (used by HipRunner)
@@ -194,20 +254,13 @@ def make_bprmf(general_model_cls):
                 plan = hip_ops.BatchPlan(u[lo:hi], p[lo:hi], n[lo:hi], batch_size, self.user_num, self.item_num)
                 if optimizer == "SGD" and l2 == 0.0:
                     tabs.run_sgd(plan, 0, c, lr, losses=losses[done:done + c])
-                elif optimizer == "SGD":
+                elif optimizer in ("SGD", "Adam"):
+                    if opt is None or opt.name != optimizer or opt.lr != float(lr) or opt.l2 != float(l2):
+                        if opt is not None and opt.adam_step > 0 and opt.name == optimizer:
+                            raise ValueError("lr / l2 changed after optimizer steps had been taken")
+                        opt = self.optimizer = FusedOptimizer(self, optimizer, lr, l2, getattr(opt, "lazy", -1))
                     for k in range(c):
-                        tabs.step_sgd(plan, k, lr, l2, loss_out=losses[done + k])
-                elif optimizer == "Adam":
-                    if opt is None or opt.name != "Adam":
-                        opt = self.optimizer = FusedOptimizer(self, "Adam", lr, l2)
-                    st = opt._adam_state()
-                    for k in range(c):
-                        opt.adam_step += 1
-                        _, sid = tabs.grads(plan, k, st["gU"], st["gI"], loss_out=losses[done + k])
-                        hip_ops.adam_dense(tabs.U, st["mU"], st["vU"], st["gU"], opt.adam_step, lr, l2, stamp=tabs.stamp_u,
-                                           step_id=sid)
-                        hip_ops.adam_dense(tabs.I, st["mI"], st["vI"], st["gI"], opt.adam_step, lr, l2, stamp=tabs.stamp_i,
-                                           step_id=sid)
+                        opt.step_batch(tabs, plan, k, loss_out=losses[done + k])
                 else:
                     raise ValueError("train_epoch supports SGD and Adam; use BaseRunner.fit for %r" % optimizer)
                 done += c

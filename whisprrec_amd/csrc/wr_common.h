@@ -179,4 +179,32 @@ static inline int32_t check_table(const void *tab, int64_t n_rows, int32_t D, co
     return WR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ optimizers
+// One element of torch.optim.Adam's single-tensor step (amsgrad off) — shared by the dense pass (wr_rows.hip) and the
+// lazy row replay (wr_lazy.hip), which must produce the same bits.  The two divisions and the square root of the
+// reference formula use the hardware v_rcp_f32 / v_sqrt_f32 (1 ulp) and a host-side 1/sqrt(bias_correction2): the lazy
+// replay is ALU-bound on exactly this function, and IEEE-rounded fdiv/fsqrt expansions cost 2.3x as many issue slots for
+// a difference far below the 1e-5 parity tolerance (the update term is off by <= 3 ulp, the weight by lr * that).
+template <bool L2 = true>
+__device__ __forceinline__ void adam_elem(float &w, float &m, float &v, float g, float l2, float b1, float b2, float eps,
+                                          float step_size, float inv_bc2_sqrt) {
+    if (L2 && l2 != 0.f) g = fmaf(l2, w, g);   // L2 = false: the caller knows l2 == 0
+    m = m + (1.0f - b1) * (g - m);         // exp_avg.lerp_(grad, 1-beta1)
+    v = b2 * v + (1.0f - b2) * g * g;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2_sqrt + eps;   // sqrt(v)/sqrt(bias_correction2) + eps
+    w = w - step_size * (m * __builtin_amdgcn_rcpf(denom));               // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+// Host side of the same step: step_size = lr/(1-beta1^t), 1/sqrt(1-beta2^t), in double as torch computes the bias
+// corrections for a python-number step, rounded to fp32 once.
+static inline void adam_step_consts(int64_t t, float lr, float beta1, float beta2, float *step_size, float *inv_bc2_sqrt) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    *step_size = t == 0 ? 0.f : (float)((double)lr / bc1);
+    *inv_bc2_sqrt = t == 0 ? 1.f : (float)(1.0 / sqrt(bc2));
+}
+
+// torch.optim.SGD with weight_decay and a zero gradient: g' = 0 + l2*w ; w -= lr*g'
+__device__ __forceinline__ float sgd_decay_elem(float w, float lr, float l2) { return w - lr * (l2 * w); }
+
 }  // namespace wr

@@ -1,0 +1,270 @@
+// wr_lazy.hip — exact lazy evaluation of the dense optimizers of BaseRunner.py:120-124 on big tables.
+//
+// torch.optim.Adam / SGD(weight_decay) move EVERY row of the tables at every step (reference src/helpers/BaseRunner.py:199:
+// a row without gradient still gets its moments decayed and its weights moved by the old momentum / shrunk by l2).  The
+// dense kernels of wr_rows.hip do that literally: 7 table passes per step, ~0.7 ms at 1M x 1M x 64 whatever the batch size.
+// A row's trajectory between two batches that contain it depends on nothing but the row itself, so it can be replayed
+// later: every row carries the number of the last optimizer step applied to it, and
+//   * before a batch's gradients are computed, the rows of THAT batch are brought up to step t-1 by replaying the missed
+//     zero-gradient steps element by element (same arithmetic, same order, same per-step bias corrections: same bits);
+//   * after the gradients are known, step t is applied to those rows only;
+//   * before anything else reads the tables (evaluation, checkpoint), all rows are brought up to date in one pass.
+// The replay costs ALU work (one adam_elem per element per missed step) but no memory traffic.
+//
+// One wave per row (lane-strided elements): rows of one wave replay the same number of steps, so there is no divergence.
+#include "wr_common.h"
+
+namespace wr {
+
+constexpr int kWave = 64;
+
+// R = rows a wave has in flight: their loads are issued together, the replays run one after the other (each at full lane
+// use, no divergence).  4 for big batches (memory-level parallelism), 1 for small ones (more waves to spread the replays).
+constexpr int kRowsPerWave = 4;
+constexpr int64_t kSmallBatchKeys = 32768;
+
+// Adam: bring each row from step last[row] to step `upto` (zero gradient), then, if grad != nullptr, apply step upto+1
+// with the row's gradient.  consts[2s], consts[2s+1] = step_size and 1/sqrt(bias_correction2) of step s.
+// rows[j] < 0: nothing to do for slot j.  All arguments are wave-uniform.
+template <bool L2, int R>
+__device__ __forceinline__ void adam_rows(float *__restrict__ w, float *__restrict__ m, float *__restrict__ v,
+                                          int *__restrict__ last, const int64_t (&rows_in)[R], int D, int upto,
+                                          const float *__restrict__ grad, const float *__restrict__ consts, float l2, float b1,
+                                          float b2, float eps, int lane) {
+    const float2 *__restrict__ c2 = reinterpret_cast<const float2 *>(consts);
+    int64_t rows[R];
+    int from[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) from[j] = rows_in[j] >= 0 ? last[rows_in[j]] : 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        from[j] = __builtin_amdgcn_readfirstlane(from[j]);
+        rows[j] = (rows_in[j] >= 0 && (from[j] < upto || grad != nullptr)) ? rows_in[j] : -1;
+    }
+    for (int e = lane; e < D; e += kWave) {
+        float ww[R], mm[R], vv[R], gg[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (rows[j] < 0) continue;
+            const int64_t at = rows[j] * (int64_t)D + e;
+            ww[j] = w[at]; mm[j] = m[at]; vv[j] = v[at];
+            gg[j] = grad != nullptr ? grad[at] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (rows[j] < 0) continue;
+            int s = from[j] + 1;
+            for (; s + 3 <= upto; s += 4) {   // four steps per trip: their (wave-uniform) constants are fetched together
+                const float2 k0 = c2[s], k1 = c2[s + 1], k2 = c2[s + 2], k3 = c2[s + 3];
+                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k0.x, k0.y);
+                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k1.x, k1.y);
+                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k2.x, k2.y);
+                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k3.x, k3.y);
+            }
+            for (; s <= upto; ++s) adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, c2[s].x, c2[s].y);
+            if (grad != nullptr) adam_elem<L2>(ww[j], mm[j], vv[j], gg[j], l2, b1, b2, eps, c2[upto + 1].x, c2[upto + 1].y);
+            const int64_t at = rows[j] * (int64_t)D + e;
+            w[at] = ww[j]; m[at] = mm[j]; v[at] = vv[j];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (rows[j] >= 0) last[rows[j]] = grad != nullptr ? upto + 1 : upto;
+    }
+}
+
+// keys: row ids of one batch, equal ids adjacent (the plan's tu / oc_item arrays).  A wave takes kRowsPerWave consecutive
+// keys; the first key of a run stands for the row.
+template <int R>
+__device__ __forceinline__ void head_rows(const int *__restrict__ keys, int64_t n_keys, int64_t n_rows, int64_t k0,
+                                          int64_t (&rows)[R]) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int64_t k = k0 + j;
+        int key = -1;
+        if (k < n_keys) {
+            key = keys[k];
+            if (k > 0 && keys[k - 1] == key) key = -1;
+            if (key >= n_rows) key = -1;   // plans are validated by the caller; never touch memory outside the table
+        }
+        rows[j] = __builtin_amdgcn_readfirstlane(key);
+    }
+}
+
+template <bool L2, int R>
+__global__ __launch_bounds__(kBlock) void adam_lazy_rows_kernel(float *__restrict__ w, float *__restrict__ m,
+                                                                 float *__restrict__ v, int *__restrict__ last,
+                                                                 int64_t n_rows, int D, const int *__restrict__ keys,
+                                                                 int64_t n_keys, const float *__restrict__ grad, int upto,
+                                                                 const float *__restrict__ consts, float l2, float b1,
+                                                                 float b2, float eps) {
+    const int64_t k0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * R;
+    if (k0 >= n_keys) return;
+    int64_t rows[R];
+    head_rows<R>(keys, n_keys, n_rows, k0, rows);
+    adam_rows<L2, R>(w, m, v, last, rows, D, upto, grad, consts, l2, b1, b2, eps, threadIdx.x % kWave);
+}
+
+template <bool L2>
+__global__ __launch_bounds__(kBlock) void adam_catchup_all_kernel(float *__restrict__ w, float *__restrict__ m,
+                                                                   float *__restrict__ v, int *__restrict__ last,
+                                                                   int64_t n_rows, int D, int upto,
+                                                                   const float *__restrict__ consts, float l2, float b1,
+                                                                   float b2, float eps) {
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * kRowsPerWave;
+    for (int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * kRowsPerWave; r0 < n_rows; r0 += stride) {
+        int64_t rows[kRowsPerWave];
+#pragma unroll
+        for (int j = 0; j < kRowsPerWave; ++j) rows[j] = r0 + j < n_rows ? r0 + j : -1;
+        adam_rows<L2, kRowsPerWave>(w, m, v, last, rows, D, upto, nullptr, consts, l2, b1, b2, eps, threadIdx.x % kWave);
+    }
+}
+
+// SGD with weight decay: bring each row to step `upto` (zero gradient) and mark it as being at step `mark`.
+template <int R>
+__device__ __forceinline__ void sgd_rows(float *__restrict__ w, int *__restrict__ last, const int64_t (&rows_in)[R], int D,
+                                         int upto, int mark, float lr, float l2, int lane) {
+    int64_t rows[R];
+    int from[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) from[j] = rows_in[j] >= 0 ? last[rows_in[j]] : 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        from[j] = __builtin_amdgcn_readfirstlane(from[j]);
+        rows[j] = (rows_in[j] >= 0 && from[j] < mark) ? rows_in[j] : -1;
+    }
+    for (int e = lane; e < D; e += kWave) {
+        float ww[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (rows[j] >= 0 && from[j] < upto) ww[j] = w[rows[j] * (int64_t)D + e];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (rows[j] < 0 || from[j] >= upto) continue;
+            for (int s = from[j]; s < upto; ++s) ww[j] = sgd_decay_elem(ww[j], lr, l2);
+            w[rows[j] * (int64_t)D + e] = ww[j];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (rows[j] >= 0) last[rows[j]] = mark;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void sgd_lazy_rows_kernel(float *__restrict__ w, int *__restrict__ last, int64_t n_rows,
+                                                                int D, const int *__restrict__ keys, int64_t n_keys, int upto,
+                                                                int mark, float lr, float l2) {
+    const int64_t k0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * R;
+    if (k0 >= n_keys) return;
+    int64_t rows[R];
+    head_rows<R>(keys, n_keys, n_rows, k0, rows);
+    sgd_rows<R>(w, last, rows, D, upto, mark, lr, l2, threadIdx.x % kWave);
+}
+
+__global__ __launch_bounds__(kBlock) void sgd_catchup_all_kernel(float *__restrict__ w, int *__restrict__ last, int64_t n_rows,
+                                                                  int D, int upto, float lr, float l2) {
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * kRowsPerWave;
+    for (int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * kRowsPerWave; r0 < n_rows; r0 += stride) {
+        int64_t rows[kRowsPerWave];
+#pragma unroll
+        for (int j = 0; j < kRowsPerWave; ++j) rows[j] = r0 + j < n_rows ? r0 + j : -1;
+        sgd_rows<kRowsPerWave>(w, last, rows, D, upto, upto, lr, l2, threadIdx.x % kWave);
+    }
+}
+
+static inline unsigned rows_grid(int64_t n, int R) {
+    const int64_t per = kBlock / kWave * R;
+    const int64_t g = (n + per - 1) / per;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+static inline unsigned all_grid(int64_t n_rows) {
+    const int64_t per = kBlock / kWave * kRowsPerWave;
+    const int64_t g = (n_rows + per - 1) / per, cap = 256 * 32;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" {
+
+int32_t wr_adam_consts(int64_t first_step, int64_t n_steps, float lr, float beta1, float beta2, float *consts_host) {
+    WR_REQUIRE(consts_host != nullptr && first_step >= 0 && n_steps >= 0, WR_E_NULL, "wr_adam_consts: bad arguments");
+    for (int64_t s = first_step; s < first_step + n_steps; ++s)   // the expressions wr_adam_dense evaluates
+        adam_step_consts(s, lr, beta1, beta2, &consts_host[2 * (s - first_step)], &consts_host[2 * (s - first_step) + 1]);
+    return WR_OK;
+}
+
+int32_t wr_adam_rows_lazy(float *tab, float *exp_avg, float *exp_avg_sq, int32_t *last_step, int64_t n_rows, int32_t D,
+                          const int32_t *keys, int64_t n_keys, const float *grad, int64_t adam_step, const float *consts,
+                          int64_t n_consts, float l2, float beta1, float beta2, float eps, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg, n_rows, D, "exp_avg")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg_sq, n_rows, D, "exp_avg_sq")) != WR_OK) return rc;
+    WR_REQUIRE(last_step != nullptr && consts != nullptr, WR_E_NULL, "last_step / consts is NULL");
+    WR_REQUIRE(adam_step >= 1 && adam_step < n_consts && adam_step < INT32_MAX, WR_E_RANGE,
+               "adam_step %lld outside the consts table (%lld entries)", (long long)adam_step, (long long)n_consts);
+    WR_REQUIRE(n_keys >= 0 && (n_keys == 0 || keys != nullptr), WR_E_NULL, "keys is NULL");
+    if (n_keys == 0) return WR_OK;
+    const bool small = n_keys < kSmallBatchKeys;
+    auto kern = small ? (l2 != 0.f ? adam_lazy_rows_kernel<true, 1> : adam_lazy_rows_kernel<false, 1>)
+                      : (l2 != 0.f ? adam_lazy_rows_kernel<true, kRowsPerWave> : adam_lazy_rows_kernel<false, kRowsPerWave>);
+    hipLaunchKernelGGL(kern, dim3(rows_grid(n_keys, small ? 1 : kRowsPerWave)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream_),
+                       tab, exp_avg, exp_avg_sq, last_step, n_rows, D, keys, n_keys, grad, (int)(adam_step - 1), consts, l2,
+                       beta1, beta2, eps);
+    WR_LAUNCH_CHECK("adam_lazy_rows_kernel");
+    return WR_OK;
+}
+
+int32_t wr_adam_catchup_all(float *tab, float *exp_avg, float *exp_avg_sq, int32_t *last_step, int64_t n_rows, int32_t D,
+                            int64_t adam_step, const float *consts, int64_t n_consts, float l2, float beta1, float beta2,
+                            float eps, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg, n_rows, D, "exp_avg")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg_sq, n_rows, D, "exp_avg_sq")) != WR_OK) return rc;
+    WR_REQUIRE(last_step != nullptr && consts != nullptr, WR_E_NULL, "last_step / consts is NULL");
+    WR_REQUIRE(adam_step >= 0 && adam_step < n_consts && adam_step < INT32_MAX, WR_E_RANGE,
+               "adam_step %lld outside the consts table (%lld entries)", (long long)adam_step, (long long)n_consts);
+    hipLaunchKernelGGL(l2 != 0.f ? adam_catchup_all_kernel<true> : adam_catchup_all_kernel<false>, dim3(all_grid(n_rows)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream_), tab, exp_avg, exp_avg_sq, last_step, n_rows, D, (int)adam_step,
+                       consts, l2, beta1, beta2, eps);
+    WR_LAUNCH_CHECK("adam_catchup_all_kernel");
+    return WR_OK;
+}
+
+int32_t wr_sgd_rows_lazy(float *tab, int32_t *last_step, int64_t n_rows, int32_t D, const int32_t *keys, int64_t n_keys,
+                         int64_t step, float lr, float l2, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    WR_REQUIRE(last_step != nullptr, WR_E_NULL, "last_step is NULL");
+    WR_REQUIRE(step >= 1 && step < INT32_MAX, WR_E_RANGE, "step must be >= 1");
+    WR_REQUIRE(n_keys >= 0 && (n_keys == 0 || keys != nullptr), WR_E_NULL, "keys is NULL");
+    if (n_keys == 0) return WR_OK;
+    const bool small = n_keys < kSmallBatchKeys;
+    hipLaunchKernelGGL(small ? sgd_lazy_rows_kernel<1> : sgd_lazy_rows_kernel<kRowsPerWave>,
+                       dim3(rows_grid(n_keys, small ? 1 : kRowsPerWave)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream_),
+                       tab, last_step, n_rows, D, keys, n_keys, (int)(step - 1), (int)step, lr, l2);
+    WR_LAUNCH_CHECK("sgd_lazy_rows_kernel");
+    return WR_OK;
+}
+
+int32_t wr_sgd_catchup_all(float *tab, int32_t *last_step, int64_t n_rows, int32_t D, int64_t step, float lr, float l2,
+                           void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    WR_REQUIRE(last_step != nullptr, WR_E_NULL, "last_step is NULL");
+    WR_REQUIRE(step >= 0 && step < INT32_MAX, WR_E_RANGE, "step must be >= 0");
+    hipLaunchKernelGGL(sgd_catchup_all_kernel, dim3(all_grid(n_rows)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream_), tab, last_step, n_rows, D, (int)step, lr, l2);
+    WR_LAUNCH_CHECK("sgd_catchup_all_kernel");
+    return WR_OK;
+}
+
+}  // extern "C"

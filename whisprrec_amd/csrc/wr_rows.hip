@@ -121,15 +121,6 @@ __global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float4 *__restrict__ 
     }
 }
 
-__device__ __forceinline__ void adam_elem(float &w, float &m, float &v, float g, float l2, float b1, float b2, float eps,
-                                          float step_size, float bc2_sqrt) {
-    if (l2 != 0.f) g = fmaf(l2, w, g);
-    m = m + (1.0f - b1) * (g - m);         // exp_avg.lerp_(grad, 1-beta1)
-    v = b2 * v + (1.0f - b2) * g * g;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    w = w - step_size * (m / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
-}
-
 __global__ __launch_bounds__(kBlock) void adam_dense_kernel(float4 *__restrict__ w, float4 *__restrict__ m,
                                                              float4 *__restrict__ v, const float4 *__restrict__ g, int64_t n4,
                                                              int D4, const int *__restrict__ stamp, int step_id, float l2,
@@ -496,11 +487,8 @@ int32_t wr_adam_dense(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_r
     if ((rc = check_table(exp_avg_sq, n_rows, D, "exp_avg_sq")) != WR_OK) return rc;
     if ((rc = check_table(grad, n_rows, D, "grad")) != WR_OK) return rc;
     WR_REQUIRE(adam_step >= 1, WR_E_RANGE, "adam_step must be >= 1");
-    // bias corrections in double, as torch computes them on the host for a python-number step
-    const double bc1 = 1.0 - pow((double)beta1, (double)adam_step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)adam_step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    float step_size, bc2_sqrt;   // bc2_sqrt holds 1/sqrt(bias_correction2)
+    adam_step_consts(adam_step, lr, beta1, beta2, &step_size, &bc2_sqrt);
     const int64_t n4 = n_rows * (D / 4);
     hipLaunchKernelGGL(adam_dense_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream_),
                        reinterpret_cast<float4 *>(tab), reinterpret_cast<float4 *>(exp_avg),

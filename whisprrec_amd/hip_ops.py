@@ -251,8 +251,9 @@ class BprmfTables:
         return (plan.tu.data_ptr() + 4 * off, plan.tp.data_ptr() + 4 * off, plan.tn.data_ptr() + 4 * off,
                 plan.oc_item.data_ptr() + 8 * off, plan.oc_src.data_ptr() + 8 * off, plan.batch_len(k))
 
-    def step_sgd(self, plan, k, lr, l2=0.0, loss_out=None):
-        """One BaseRunner.fit iteration (zero_grad/predict/backward/SGD.step, BaseRunner.py:196-199) on batch k."""
+    def step_sgd(self, plan, k, lr, l2=0.0, loss_out=None, decay_untouched=True):
+        """One BaseRunner.fit iteration (zero_grad/predict/backward/SGD.step, BaseRunner.py:196-199) on batch k.
+        decay_untouched=False leaves the weight decay of the rows outside the batch to LazyOptimizerState."""
         L = abi.lib()
         tu, tp, tn, oi, os_, B = self._plan_ptrs(plan, k)
         ws = self._ws(plan.batch_size)
@@ -267,7 +268,7 @@ class BprmfTables:
                                       os_, B, lr, l2, _p(su), _p(si), self.step_id, _p(loss_out),
                                       ctypes.addressof(hot) if hot is not None else None, _p(ws), ws.numel(),
                                       _stream()), "wr_bprmf_step_sgd")
-        if l2 != 0.0:  # dense weight decay on the rows the batch did not touch (torch.optim.SGD semantics)
+        if l2 != 0.0 and decay_untouched:  # dense weight decay on the rows the batch did not touch (torch.optim.SGD semantics)
             abi.check(L.wr_sgd_decay_untouched(_p(self.U), self.U.shape[0], self.D, _p(su), self.step_id, lr, l2,
                                                _stream()), "wr_sgd_decay_untouched")
             abi.check(L.wr_sgd_decay_untouched(_p(self.I), self.I.shape[0], self.D, _p(si), self.step_id, lr, l2,
@@ -384,6 +385,76 @@ def adam_dense(tab, exp_avg, exp_avg_sq, grad, adam_step, lr, l2=0.0, beta1=0.9,
     abi.check(abi.lib().wr_adam_dense(_p(tab), _p(exp_avg), _p(exp_avg_sq), tab.shape[0], tab.shape[1], _p(grad),
                                       _p(stamp), step_id, adam_step, lr, l2, beta1, beta2, eps, _stream()),
               "wr_adam_dense")
+
+
+class LazyOptimizerState:
+    """Exact lazy evaluation of torch.optim.Adam / SGD(weight_decay) on the two BPRMF tables (include/whisprrec_hip.h,
+    "K5 (lazy, exact)"): per row the number of the last optimizer step applied to it; rows are replayed when a batch
+    needs them and all together in ``flush()`` — call it before anything else reads the tables.  Bit-identical to the
+    dense kernels (wr_adam_dense / wr_sgd_dense), without their table passes."""
+
+    def __init__(self, tabs, name, lr, l2, betas=(0.9, 0.999), eps=1e-8):
+        if name not in ("SGD", "Adam"):
+            raise ValueError(name)
+        self.tabs, self.name, self.lr, self.l2, self.betas, self.eps = tabs, name, float(lr), float(l2), betas, float(eps)
+        dev = tabs.dev
+        self.t = 0                                                       # optimizer steps taken
+        self.flushed_at = 0
+        self.last_u = torch.zeros(tabs.U.shape[0], dtype=torch.int32, device=dev)
+        self.last_i = torch.zeros(tabs.I.shape[0], dtype=torch.int32, device=dev)
+        if name == "Adam":
+            z = torch.zeros_like
+            self.m_u, self.v_u, self.m_i, self.v_i = z(tabs.U), z(tabs.U), z(tabs.I), z(tabs.I)
+            self.g_u, self.g_i = torch.empty_like(tabs.U), torch.empty_like(tabs.I)   # only the batch's rows are ever read
+            self.consts = None
+            self._grow_consts(4096)
+
+    def _grow_consts(self, n):
+        host = torch.empty(2 * n, dtype=torch.float32)
+        abi.check(abi.lib().wr_adam_consts(0, n, self.lr, self.betas[0], self.betas[1], host.data_ptr()), "wr_adam_consts")
+        self.consts = host.to(self.tabs.dev)
+        self.n_consts = n
+
+    def _adam_rows(self, tab, m, v, last, keys_ptr, n_keys, grad):
+        abi.check(abi.lib().wr_adam_rows_lazy(_p(tab), _p(m), _p(v), _p(last), tab.shape[0], tab.shape[1], keys_ptr, n_keys,
+                                              _p(grad), self.t, _p(self.consts), self.n_consts, self.l2, self.betas[0],
+                                              self.betas[1], self.eps, _stream()), "wr_adam_rows_lazy")
+
+    def step(self, plan, k, loss_out=None):
+        """optimizer step on batch k of the plan (gradient computation included); returns the loss tensor"""
+        tabs = self.tabs
+        self.t += 1
+        tu, _, _, oi, _, B = tabs._plan_ptrs(plan, k)
+        if self.name == "Adam":
+            if self.t >= self.n_consts:
+                self._grow_consts(2 * self.n_consts)
+            self._adam_rows(tabs.U, self.m_u, self.v_u, self.last_u, tu, B, None)       # the batch's rows up to t-1
+            self._adam_rows(tabs.I, self.m_i, self.v_i, self.last_i, oi, 2 * B, None)
+            loss, _ = tabs.grads(plan, k, self.g_u, self.g_i, loss_out=loss_out)
+            self._adam_rows(tabs.U, self.m_u, self.v_u, self.last_u, tu, B, self.g_u)   # step t on those rows
+            self._adam_rows(tabs.I, self.m_i, self.v_i, self.last_i, oi, 2 * B, self.g_i)
+            return loss
+        L = abi.lib()
+        for tab, last, keys, n in ((tabs.U, self.last_u, tu, B), (tabs.I, self.last_i, oi, 2 * B)):
+            abi.check(L.wr_sgd_rows_lazy(_p(tab), _p(last), tab.shape[0], tab.shape[1], keys, n, self.t, self.lr, self.l2,
+                                         _stream()), "wr_sgd_rows_lazy")
+        return tabs.step_sgd(plan, k, self.lr, self.l2, loss_out=loss_out, decay_untouched=False)
+
+    def flush(self):
+        """every row up to the current step: the tables are then what the dense optimizer would hold"""
+        if self.flushed_at == self.t:
+            return
+        L, tabs = abi.lib(), self.tabs
+        if self.name == "Adam":
+            for tab, m, v, last in ((tabs.U, self.m_u, self.v_u, self.last_u), (tabs.I, self.m_i, self.v_i, self.last_i)):
+                abi.check(L.wr_adam_catchup_all(_p(tab), _p(m), _p(v), _p(last), tab.shape[0], tab.shape[1], self.t,
+                                                _p(self.consts), self.n_consts, self.l2, self.betas[0], self.betas[1],
+                                                self.eps, _stream()), "wr_adam_catchup_all")
+        else:
+            for tab, last in ((tabs.U, self.last_u), (tabs.I, self.last_i)):
+                abi.check(L.wr_sgd_catchup_all(_p(tab), _p(last), tab.shape[0], tab.shape[1], self.t, self.lr, self.l2,
+                                               _stream()), "wr_sgd_catchup_all")
+        self.flushed_at = self.t
 
 
 # ----------------------------------------------------------------------------------------------- rows
