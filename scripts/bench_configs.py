@@ -75,6 +75,38 @@ def bprmf_case(name, nU, nI, D, B, NB, opt="SGD", l2=0.0, zipf=0.0, lazy=False):
     torch.cuda.empty_cache()
 
 
+def c2_epoch_case(n_inter=100_000_000, nU=1_000_000, nI=1_000_000, D=64, B=65536):
+    """whole epoch at C2 scale, everything on the device: negatives (wr_sample_negatives against the per-user clicked
+    lists), shuffle, batch plans, steps ('epoch-level throughput incl. shuffle + negative sampling')"""
+    g = torch.Generator(device=dev); g.manual_seed(3407)
+    users = torch.randint(0, nU, (n_inter,), generator=g, device=dev, dtype=torch.int32)
+    items = torch.randint(0, nI, (n_inter,), generator=g, device=dev, dtype=torch.int32)
+    t0 = time.perf_counter(); ptr, idx = hip_ops.clicked_csr_from_pairs(users, items, nU, nI); torch.cuda.synchronize()
+    t_csr = time.perf_counter() - t0
+    U, I = tables(nU, nI, D)
+    tabs = hip_ops.BprmfTables(U, I)
+    pipe = hip_ops.PipelinedSgd(64)
+    nb = (n_inter + B - 1) // B
+    res = {}
+    for epoch in (1, 2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        neg, err = hip_ops.sample_negatives(users, nU, nI, ptr, idx, 3407, epoch)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        g.manual_seed(3407 * 1000003 + epoch)
+        order = torch.randperm(n_inter, device=dev, generator=g)
+        u, p, n = users[order], items[order], neg[order]
+        del order
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        pipe.run(pipe.plan(U, [(I, u, p, n)], B), 0, 0.05, losses)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        res = dict(sample_ms=(t1 - t0) * 1e3, shuffle_ms=(t2 - t1) * 1e3, plan_and_steps_ms=(t3 - t2) * 1e3,
+                   epoch_ms=(t3 - t0) * 1e3, loss_mean=float(losses.mean()))
+        del u, p, n, neg
+    emit(case="C2 whole epoch on the device: sampler + shuffle + plans + %d steps (1Mx1M, D=64, B=65536, %d interactions)" % (nb, n_inter),
+         clicked_csr_build_once_ms=t_csr * 1e3, triplets_per_s_epoch=n_inter / (res["epoch_ms"] * 1e-3), **res)
+
+
 def lightgcn_case():
     from whisprrec_amd.lightgcn import LightGCN
     rng = np.random.RandomState(0)
@@ -165,13 +197,17 @@ def eval_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c4", "c3", "c5", "c1", "eval"]
+    which = sys.argv[1:] or ["c2", "c2big", "lazy", "c2epoch", "c4", "c3", "c5", "c1", "eval"]
     if "c2" in which:
         for B, NB in ((2048, 256), (16384, 128), (65536, 64), (262144, 16)):
             bprmf_case("C2 BPRMF 1Mx1M D=64 SGD l2=0", 1_000_000, 1_000_000, 64, B, NB)
         bprmf_case("C2 SGD l2=1e-6 (dense weight decay)", 1_000_000, 1_000_000, 64, 65536, 16, l2=1e-6)
         bprmf_case("C2 Adam (dense, reference default optimizer)", 1_000_000, 1_000_000, 64, 65536, 16, opt="Adam")
         bprmf_case("C2 Zipf(1.0) items", 1_000_000, 1_000_000, 64, 65536, 64, zipf=1.0)
+    if "c2big" in which:
+        bprmf_case("C2 BPRMF 1Mx1M D=64 SGD l2=0", 1_000_000, 1_000_000, 64, 1048576, 8)
+    if "c2epoch" in which:
+        c2_epoch_case()
     if "lazy" in which:
         bprmf_case("C2 SGD l2=1e-6", 1_000_000, 1_000_000, 64, 65536, 64, l2=1e-6, lazy=True)
         bprmf_case("C2 Adam", 1_000_000, 1_000_000, 64, 65536, 64, opt="Adam", lazy=True)

@@ -247,14 +247,19 @@ def make_bprmf(general_model_cls):
             nb = (N + batch_size - 1) // batch_size
             losses = torch.empty(nb, dtype=torch.float32, device=u.device)
             opt = self.optimizer if isinstance(self.optimizer, FusedOptimizer) else None
+            if optimizer == "SGD" and l2 == 0.0:
+                # stateless update: plans built on a side stream one chunk ahead of the steps, steps issued natively
+                if getattr(self, "_pipe", None) is None:
+                    self._pipe = hip_ops.PipelinedSgd(chunk)
+                handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size)
+                self._pipe.run(handle, 0, lr, losses)
+                return losses
             done = 0
             while done < nb:
                 c = min(chunk, nb - done)
                 lo, hi = done * batch_size, min(N, (done + c) * batch_size)
                 plan = hip_ops.BatchPlan(u[lo:hi], p[lo:hi], n[lo:hi], batch_size, self.user_num, self.item_num)
-                if optimizer == "SGD" and l2 == 0.0:
-                    tabs.run_sgd(plan, 0, c, lr, losses=losses[done:done + c])
-                elif optimizer in ("SGD", "Adam"):
+                if optimizer in ("SGD", "Adam"):
                     if opt is None or opt.name != optimizer or opt.lr != float(lr) or opt.l2 != float(l2):
                         if opt is not None and opt.adam_step > 0 and opt.name == optimizer:
                             raise ValueError("lr / l2 changed after optimizer steps had been taken")

@@ -338,6 +338,16 @@ def sample_negatives(users, n_users, n_items, clicked_ptr, clicked_idx, seed, ep
     return neg, err
 
 
+def clicked_csr_from_pairs(users, items, n_users, n_items):
+    """device (user, item) interaction pairs -> device CSR of each user's distinct items, ascending (the layout
+    wr_sample_negatives and wr_rank_eval take).  One-off setup: torch sort/unique glue."""
+    key = torch.unique(users.to(torch.int64) * int(n_items) + items.to(torch.int64))      # sorted, distinct
+    uu = torch.div(key, int(n_items), rounding_mode="floor")
+    ptr = torch.zeros(n_users + 1, dtype=torch.int64, device=users.device)
+    ptr[1:] = torch.cumsum(torch.bincount(uu, minlength=n_users), 0)
+    return ptr, (key - uu * int(n_items)).to(torch.int32)
+
+
 def clicked_csr(train_clicked_set, n_users, device):
     """train_clicked_set (dict user -> set of items, reference BaseReader.py:35-46) -> device CSR with ascending items."""
     import numpy as np
@@ -385,6 +395,71 @@ def adam_dense(tab, exp_avg, exp_avg_sq, grad, adam_step, lr, l2=0.0, beta1=0.9,
     abi.check(abi.lib().wr_adam_dense(_p(tab), _p(exp_avg), _p(exp_avg_sq), tab.shape[0], tab.shape[1], _p(grad),
                                       _p(stamp), step_id, adam_step, lr, l2, beta1, beta2, eps, _stream()),
               "wr_adam_dense")
+
+
+class PipelinedSgd:
+    """Plain-SGD training over pre-ordered triplets with the plan build off the critical path.  The work is a list of
+    segments (item table view + indices; one segment for a whole epoch on one GPU, one per part of the held block in the
+    stratified multi-GPU schedule).  Batches are planned ``chunk`` at a time on a side stream, one chunk ahead of the steps
+    (a plan depends only on the indices, never on the tables) — across segment boundaries too — and a segment's steps are
+    issued from native code (wr_bprmf_run_sgd)."""
+
+    def __init__(self, chunk=64):
+        import sys
+        self.ops = sys.modules[__name__]
+        self.chunk = int(chunk)
+        self.plan_stream = None
+
+    def plan(self, U, segments, batch):
+        """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order"""
+        if self.plan_stream is None:
+            self.plan_stream = torch.cuda.Stream(device=U.device)
+        B = int(batch)
+        todo = []                                                           # (segment, first batch, n batches) in run order
+        segs = []
+        for k, (rows, u, p, n) in enumerate(segments):
+            nb = (u.numel() + B - 1) // B
+            segs.append({"tabs": self.ops.BprmfTables(U, rows) if nb else None, "u": u, "p": p, "n": n, "nb": nb})
+            todo += [(k, f, min(self.chunk, nb - f)) for f in range(0, nb, self.chunk)]
+        h = {"segs": segs, "B": B, "todo": todo, "at": 0, "tag": 0, "next": None}
+        self.plan_stream.wait_stream(torch.cuda.current_stream(U.device))   # the index tensors are ready
+        self._prefetch(h)
+        return h
+
+    def _prefetch(self, h):
+        """enqueue the plan of the next chunk on the side stream"""
+        if h["at"] >= len(h["todo"]):
+            h["next"] = None
+            return
+        k, first, c = h["todo"][h["at"]]
+        h["at"] += 1
+        sg, B = h["segs"][k], h["B"]
+        lo, hi = first * B, min(sg["u"].numel(), (first + c) * B)
+        with torch.cuda.stream(self.plan_stream):
+            plan = self.ops.BatchPlan(sg["u"][lo:hi], sg["p"][lo:hi], sg["n"][lo:hi], B, sg["tabs"].U.shape[0],
+                                      sg["tabs"].I.shape[0], validate=False, ws_tag="rot%d" % h["tag"])
+            ready = torch.cuda.Event()
+            ready.record(self.plan_stream)
+        h["tag"] ^= 1
+        h["next"] = (k, first, plan, ready)
+
+    def run(self, handle, seg, lr, losses):
+        """all steps of segment `seg` (segments must be run in order); losses: one slot per step"""
+        h = handle
+        sg = h["segs"][seg]
+        if sg["nb"] == 0:
+            return
+        main = torch.cuda.current_stream(sg["tabs"].U.device)
+        pos = 0
+        while pos < sg["nb"]:
+            k, first, plan, ready = h["next"]
+            assert k == seg and first == pos, "segments must be run in order"
+            main.wait_event(ready)
+            plan.validate()                                                 # flags came back with the hot-run counts: no sync
+            plan.record_stream(main)
+            sg["tabs"].run_sgd(plan, 0, plan.n_batches, lr, losses=losses[pos:pos + plan.n_batches])
+            pos += plan.n_batches
+            self._prefetch(h)                                               # steps are queued: build the next plan beside them
 
 
 class LazyOptimizerState:

@@ -29,68 +29,10 @@ import torch.distributed as dist
 from .sharded import n_local_rows
 
 
-class HipLocal:
-    """Local training of one stratum with the single-GPU fused path.  A stratum is a list of segments (one per part of the
-    held block: its row range of the block as the item table, indices relative to that range).  Batches are planned
-    ``chunk`` at a time on a side stream, one chunk ahead of the steps (a plan depends only on the indices, never on the
-    tables) — across segment boundaries too — and a segment's steps are issued from native code, so the part can be handed
-    to the ring as soon as they are queued."""
-
-    def __init__(self, chunk=64):
-        from . import hip_ops
-        self.ops = hip_ops
-        self.chunk = int(chunk)
-        self.plan_stream = None
-
-    def plan(self, U, segments, batch):
-        """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order"""
-        if self.plan_stream is None:
-            self.plan_stream = torch.cuda.Stream(device=U.device)
-        B = int(batch)
-        todo = []                                                           # (segment, first batch, n batches) in run order
-        segs = []
-        for k, (rows, u, p, n) in enumerate(segments):
-            nb = (u.numel() + B - 1) // B
-            segs.append({"tabs": self.ops.BprmfTables(U, rows) if nb else None, "u": u, "p": p, "n": n, "nb": nb})
-            todo += [(k, f, min(self.chunk, nb - f)) for f in range(0, nb, self.chunk)]
-        h = {"segs": segs, "B": B, "todo": todo, "at": 0, "tag": 0, "next": None}
-        self.plan_stream.wait_stream(torch.cuda.current_stream(U.device))   # the index tensors are ready
-        self._prefetch(h)
-        return h
-
-    def _prefetch(self, h):
-        """enqueue the plan of the next chunk on the side stream"""
-        if h["at"] >= len(h["todo"]):
-            h["next"] = None
-            return
-        k, first, c = h["todo"][h["at"]]
-        h["at"] += 1
-        sg, B = h["segs"][k], h["B"]
-        lo, hi = first * B, min(sg["u"].numel(), (first + c) * B)
-        with torch.cuda.stream(self.plan_stream):
-            plan = self.ops.BatchPlan(sg["u"][lo:hi], sg["p"][lo:hi], sg["n"][lo:hi], B, sg["tabs"].U.shape[0],
-                                      sg["tabs"].I.shape[0], validate=False, ws_tag="rot%d" % h["tag"])
-            ready = torch.cuda.Event()
-            ready.record(self.plan_stream)
-        h["tag"] ^= 1
-        h["next"] = (k, first, plan, ready)
-
-    def run(self, handle, seg, lr, losses):
-        """all steps of segment `seg` (segments must be run in order); losses: one slot per step"""
-        h = handle
-        sg = h["segs"][seg]
-        if sg["nb"] == 0:
-            return
-        main = torch.cuda.current_stream(sg["tabs"].U.device)
-        pos = 0
-        while pos < sg["nb"]:
-            k, first, plan, ready = h["next"]
-            assert k == seg and first == pos, "segments must be run in order"
-            main.wait_event(ready)
-            plan.record_stream(main)
-            sg["tabs"].run_sgd(plan, 0, plan.n_batches, lr, losses=losses[pos:pos + plan.n_batches])
-            pos += plan.n_batches
-            self._prefetch(h)                                               # steps are queued: build the next plan beside them
+def HipLocal(chunk=64):
+    """local training of one stratum = the single-GPU pipelined run (hip_ops.PipelinedSgd)"""
+    from . import hip_ops
+    return hip_ops.PipelinedSgd(chunk)
 
 
 class RotatingBprmf:
