@@ -17,6 +17,8 @@ Reference entry points exercised (paths relative to /root/reference):
   G4  src/models/general/LightGCN.py:54-175 (adjacency, forward, predict, grads)
   G5  src/models/sequential/SASRec.py:84,105-106 (item-embedding gather / scatter with padding_idx=0)
   G6  src/helpers/BaseRunner.py:50-92 (evaluate_method)
+  G7  src/models/general/SGL.py:67-79 + src/utils/augmentor.py:33-111 (graph views from Python's `random` stream),
+      SGL.py:148-246 (three propagations, sum-BPR + EmbLoss + InfoNCE, grads), per view type ED / ND / RW
 """
 import argparse
 import os
@@ -382,9 +384,65 @@ def g6_eval():
     save("g6_eval", predictions=pred, keys=np.asarray(keys), values=np.asarray([res[k] for k in keys], dtype=np.float64))
 
 
+def g7_sgl():
+    import random
+    from models.general.SGL import SGL
+    rng = np.random.RandomState(9)
+    nU, nI, D, B, L = 41, 59, 32, 192, 2
+    clicked = {}
+    for u in range(nU):
+        if u == 6:
+            continue  # isolated user
+        k = rng.randint(2, 14)
+        clicked[u] = set(int(x) for x in rng.choice(np.arange(1, nI), size=k, replace=False))
+    clicked[1] = set(range(1, nI, 2))  # a heavy row
+    corpus = _Corpus(nU, nI, clicked)
+    ptr, idx = [0], []
+    for uid in range(nU):
+        idx += sorted(clicked.get(uid, ()))
+        ptr.append(len(idx))
+    u = rng.randint(0, nU, size=B).astype(np.int64)
+    p = rng.randint(0, nI, size=B).astype(np.int64)
+    n = rng.randint(1, nI, size=B).astype(np.int64)
+    u[:20] = 1
+    p[:8] = 3
+    n[8:16] = 3
+    out = dict(clicked_ptr=np.asarray(ptr, dtype=np.int32), clicked_idx=np.asarray(idx, dtype=np.int32), u=u, p=p, n=n,
+               shape=np.asarray([nU, nI, D, L], dtype=np.int64))
+    fd = {"user_id": torch.from_numpy(u), "pos_item": torch.from_numpy(p), "neg_items": torch.from_numpy(n)}
+    for vtype, ratio in (("ED", 0.25), ("ND", 0.2), ("RW", 0.1)):
+        torch.manual_seed(3407)
+        hp = dict(embedding_size=D, gcn_layers=L, type=vtype, reg_weight=1e-4, ssl_tau=0.2, ssl_weight=0.05, drop_ratio=ratio)
+        model = SGL(_args(**hp), corpus)
+        with torch.no_grad():
+            model.user_embedding.weight.mul_(6.0)
+            model.item_embedding.weight.mul_(6.0)
+        random.seed(2024)
+        model.graph_construction()          # SGL.Dataset.actions_before_epoch (SGL.py:262)
+        t = vtype.lower()
+        out[t + "_hp"] = np.asarray([1e-4, 0.2, 0.05, ratio], dtype=np.float64)
+        out[t + "_U0"] = model.user_embedding.weight.detach().numpy().copy()
+        out[t + "_I0"] = model.item_embedding.weight.detach().numpy().copy()
+        for k, g in ((0, model.train_graph), (1, model.sub_graph1), (2, model.sub_graph2)):
+            if isinstance(g, list):
+                continue                    # RW: graph_construction leaves [] (no propagation at all)
+            nz = g.nonzero(as_tuple=False)
+            out[f"{t}_g{k}_row"] = nz[:, 0].numpy().astype(np.int32)
+            out[f"{t}_g{k}_col"] = nz[:, 1].numpy().astype(np.int32)
+            out[f"{t}_g{k}_val"] = g[nz[:, 0], nz[:, 1]].numpy().astype(np.float32)
+        loss = model.predict(fd)
+        loss.backward()
+        out[t + "_loss"] = loss.detach().numpy().reshape(1).astype(np.float32)
+        out[t + "_gU"] = model.user_embedding.weight.grad.numpy().copy()
+        out[t + "_gI"] = model.item_embedding.weight.grad.numpy().copy()
+        with torch.no_grad():
+            out[t + "_full"] = model.full_predict({"user_id": torch.from_numpy(u[:16])}).numpy().copy()
+    save("g7_sgl", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     torch.set_num_threads(4)
     for w in which:
         {"g1": g1_bprmf_step, "g2": g2_ml100k_curve, "g3": g3_sampler, "g4": g4_lightgcn,
-         "g5": g5_sasrec_emb, "g6": g6_eval}[w]()
+         "g5": g5_sasrec_emb, "g6": g6_eval, "g7": g7_sgl}[w]()

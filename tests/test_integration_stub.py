@@ -33,6 +33,12 @@ from whisprrec_amd.lightgcn import bind
 LightGCNHip = bind(GeneralModel)
 LightGCNHip.__name__ = "LightGCNHip"
 """
+SGL_STUB = """from models.BaseModel import GeneralModel
+from whisprrec_amd.sgl import bind
+
+SGLHip = bind(GeneralModel)
+SGLHip.__name__ = "SGLHip"
+"""
 SASREC_STUB = """from models.BaseModel import SequentialModel
 from whisprrec_amd.sasrec import bind
 
@@ -44,6 +50,7 @@ SASRecHip.__name__ = "SASRecHip"
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference tree not present on this machine")
 @pytest.mark.parametrize("model,stub,where,nparams,extra", [
     ("LightGCNHip", LIGHTGCN_STUB, ("models", "general"), 161088, ["--gcn_layers", "2"]),
+    ("SGLHip", SGL_STUB, ("models", "general"), 161088, ["--gcn_layers", "2", "--type", "ED"]),
     ("SASRecHip", SASREC_STUB, ("models", "sequential"), None, ["--emb_size", "64", "--num_layers", "1", "--num_heads", "4"]),
 ])
 def test_other_model_stubs_drop_into_reference_main(tmp_path, model, stub, where, nparams, extra):

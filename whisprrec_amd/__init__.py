@@ -7,8 +7,10 @@ Layout:
   host.py      host-side mirror of the reference's BaseModel / GeneralModel / Dataset contract
   bprmf.py     BPRMF drop-in model (reference src/models/general/BPRMF.py)
   lightgcn.py  LightGCN drop-in model (reference src/models/general/LightGCN.py)
+  sgl.py       SGL drop-in model: graph views on CSR + three propagations (reference src/models/general/SGL.py, utils/augmentor.py)
   sasrec.py    SASRec with its item-embedding gather/scatter on the HIP kernels (reference src/models/sequential/SASRec.py)
   runner.py    HipRunner: BaseRunner-compatible runner that drives the fused step
-  sharded.py   row-sharded multi-GPU step (RCCL all-to-all over xGMI)
+  rotating.py  multi-GPU, stratified schedule: user rows fixed, item blocks rotate round the xGMI ring (default for N > 1)
+  sharded.py   multi-GPU, row-sharded step with RCCL all-to-all of item rows and gradient rows
 """
 __version__ = "0.1.0"
