@@ -175,7 +175,7 @@ def main():
     u, p, n = synth_triplets((K + W) * B, args.users, args.items, dev, 3407, args.zipf)
     torch.cuda.synchronize()
 
-    plan_stream = torch.cuda.Stream(device=dev)
+    plan_stream = hip_ops.side_stream(dev)   # high priority: its own hardware queue, never serialised behind the steps
     main_stream = torch.cuda.current_stream(dev)
 
     def build_plan(first_step, c, tag):

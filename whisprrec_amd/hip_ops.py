@@ -64,6 +64,15 @@ def workspace(device, tag):
     return _WS[key]
 
 
+def side_stream(device):
+    """A stream for work that must OVERLAP the step kernels (plan builds, ring transfers).  HIP spreads the streams of
+    one priority round-robin over a few hardware queues, and two streams that land on the same queue run one after the
+    other (seen in a kernel trace: plan stream and main stream both on queue 4, every plan build waiting for the step
+    kernels to drain).  A high-priority stream has its own queue, and the small kernels it carries should not wait behind
+    the whole-GPU step kernels anyway."""
+    return torch.cuda.Stream(device=device, priority=-1)
+
+
 def device_info():
     n_cu, wave = ctypes.c_int32(0), ctypes.c_int32(0)
     arch = ctypes.create_string_buffer(64)
@@ -413,7 +422,7 @@ class PipelinedSgd:
     def plan(self, U, segments, batch):
         """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order"""
         if self.plan_stream is None:
-            self.plan_stream = torch.cuda.Stream(device=U.device)
+            self.plan_stream = side_stream(U.device)
         B = int(batch)
         todo = []                                                           # (segment, first batch, n batches) in run order
         segs = []

@@ -47,7 +47,8 @@ class RotatingBprmf:
         self.held = self.rank                                               # block currently held
         self.I = torch.zeros(self.cap, self.D, device=device)              # held block (rows beyond its size unused)
         self.I_in = torch.zeros(self.cap, self.D, device=device)           # landing buffer for the next block
-        self.comm_stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        from .hip_ops import side_stream
+        self.comm_stream = side_stream(device) if device.type == "cuda" else None
         self._pending = []                                                  # (work handles, event) of parts in flight
 
     # ------------------------------------------------------------------ layout helpers
