@@ -297,6 +297,15 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_hot_combine(float *__restri
 }
 
 // ----------------------------------------------------------------------------------------------- item phase
+#ifndef WR_ITEM_TILE
+#define WR_ITEM_TILE 64
+#endif
+// Sorted occurrences per workgroup (its teams share the tile's runs).  A/B on MI355X (scripts/ab_step.py), steps only,
+// tile 256 / 128 / 64 / 32: 1M x 1M tables 27.6-29.2 / 26.9-27.5 / 26.6-27.6 / 28.2 us; 125K x 62.5K (the per-GPU stratum
+// of the 8-GPU schedule, almost every item row shared) 33.7 / 31.0 / 29.7 / 30.0 us: with 256 a team walks ~5 runs one
+// after the other (two dependent round trips each), with 64 one or two.
+constexpr int kItemTile = WR_ITEM_TILE;
+static_assert(kItemTile <= kBlock && kItemTile >= 32, "item tile");
 template <int T, int NV, bool FULL, int MODE>
 __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I, int D, const int *__restrict__ oc_item,
                                                             const int *__restrict__ oc_src, int B2,
@@ -306,31 +315,26 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             float loss_denom, float *__restrict__ loss_out, int skip_hot,
                                                             const unsigned long long *__restrict__ hot_loss) {
     __shared__ float scratch[kBlock / 64];
-    __shared__ int heads[kBlock];
-    __shared__ int item_tile[kBlock + 8];  // oc_item of this tile plus up to 8 entries beyond it
-    __shared__ int src_tile[kBlock + 8];
+    __shared__ int heads[kItemTile];
+    __shared__ int item_tile[kItemTile + 8];  // oc_item of this tile plus up to 8 entries beyond it
+    __shared__ int src_tile[kItemTile + 8];
     __shared__ int n_heads;
     constexpr int TEAMS = kBlock / T;
     constexpr int kAhead = 8;
     const int lane = threadIdx.x % T;
-    const int tile0 = blockIdx.x * kBlock;
+    const int tile0 = blockIdx.x * kItemTile;
     // 1) one THREAD per sorted occurrence: stage the tile's (item, source) pairs in LDS, find the heads of runs
     //    of >= 2 equal item rows and compact them (single-occurrence rows were finished by the user phase; the
     //    order of the list is irrelevant: every run is an independent row).  One global round trip.
     if (threadIdx.x == 0) n_heads = 0;
-    {
-        const int q = tile0 + threadIdx.x;
-        item_tile[threadIdx.x] = (q < B2) ? oc_item[q] : -1;
-        src_tile[threadIdx.x] = (q < B2) ? oc_src[q] : 0;
-        if (threadIdx.x < kAhead) {
-            const int qa = tile0 + kBlock + threadIdx.x;
-            item_tile[kBlock + threadIdx.x] = (qa < B2) ? oc_item[qa] : -1;
-            src_tile[kBlock + threadIdx.x] = (qa < B2) ? oc_src[qa] : 0;
-        }
+    for (int i = threadIdx.x; i < kItemTile + kAhead; i += kBlock) {   // the tile plus kAhead entries beyond it
+        const int q = tile0 + i;
+        item_tile[i] = (q < B2) ? oc_item[q] : -1;
+        src_tile[i] = (q < B2) ? oc_src[q] : 0;
     }
     const int prev_item = (threadIdx.x == 0) ? ((tile0 > 0 && tile0 < B2) ? oc_item[tile0 - 1] : -1) : 0;
     __syncthreads();
-    {
+    if (threadIdx.x < kItemTile) {
         const int r = item_tile[threadIdx.x];
         if (r >= 0) {
             const int before = (threadIdx.x == 0) ? prev_item : item_tile[threadIdx.x - 1];
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
             for (;;) {
                 const int q = tile0 + j;
                 if (q >= B2) break;
-                const bool in_lds = j < kBlock + kAhead;
+                const bool in_lds = j < kItemTile + kAhead;
                 const int it = in_lds ? item_tile[j] : oc_item[q];
                 if (it != r) break;
                 const int src = in_lds ? src_tile[j] : oc_src[q];
@@ -578,7 +582,7 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     // A/B-tested on MI355X and is ~4 % slower — the kernel is bound by the memory system's random 256-B row rate, not by
     // bytes in flight.
     const dim3 gridA((unsigned)n_blocks_for(B, D));
-    const dim3 gridB((unsigned)((2 * B + kBlock - 1) / kBlock));  // item phase: one thread per occurrence
+    const dim3 gridB((unsigned)((2 * B + kItemTile - 1) / kItemTile));  // item phase: one thread per occurrence
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[0]), stream));
 #define WR_CALL_USER(T_, NV_, FULL_)                                                                                      \
     do {                                                                                                                  \

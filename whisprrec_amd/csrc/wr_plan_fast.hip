@@ -157,10 +157,15 @@ __device__ __forceinline__ int pow2_ceil(int x) {
     return p;
 }
 
+#ifndef WR_SORT_BLOCK
+#define WR_SORT_BLOCK 256
+#endif
+constexpr int kSortBlock = WR_SORT_BLOCK;   // threads of a bucket-sort workgroup (one bucket each)
+
 // exclusive prefix of this bucket's count inside its batch (sum of the counts of the buckets before it)
 __device__ __forceinline__ int bucket_prefix(const int *__restrict__ cnt_batch, int bucket, int cap, int *scratch) {
     int a = 0;
-    for (int j = threadIdx.x; j < bucket; j += kBlock) a += min(cnt_batch[j], cap);
+    for (int j = threadIdx.x; j < bucket; j += kSortBlock) a += min(cnt_batch[j], cap);
     __syncthreads();
     if (threadIdx.x == 0) scratch[0] = 0;
     __syncthreads();
@@ -179,12 +184,12 @@ __device__ __forceinline__ void bucket_sort_lds(const unsigned long long *__rest
     const int nbin = 1 << bin_bits;
     const unsigned down = low_bits - bin_bits;
     const unsigned mask = (unsigned)nbin - 1u;
-    for (int j = threadIdx.x; j < nbin; j += kBlock) cnt[j] = 0;
+    for (int j = threadIdx.x; j < nbin; j += kSortBlock) cnt[j] = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < count; j += kBlock) atomicAdd(&cnt[((unsigned)(kin[j] >> 32) >> down) & mask], 1);
+    for (int j = threadIdx.x; j < count; j += kSortBlock) atomicAdd(&cnt[((unsigned)(kin[j] >> 32) >> down) & mask], 1);
     __syncthreads();
     // exclusive scan of cnt[0..nbin): thread t owns counters [t*per, (t+1)*per)
-    const int per = (nbin + kBlock - 1) / kBlock;
+    const int per = (nbin + kSortBlock - 1) / kSortBlock;
     const int c0 = threadIdx.x * per;
     int local = 0;
     for (int j = 0; j < per; ++j)
@@ -206,13 +211,13 @@ __device__ __forceinline__ void bucket_sort_lds(const unsigned long long *__rest
             run += c;
         }
     __syncthreads();
-    for (int j = threadIdx.x; j < count; j += kBlock) {
+    for (int j = threadIdx.x; j < count; j += kSortBlock) {
         const unsigned long long kv = kin[j];
         out[atomicAdd(&cnt[((unsigned)(kv >> 32) >> down) & mask], 1)] = kv;
     }
     __syncthreads();
     // after placement cnt[b] is the END of bin b; its start is the end of bin b-1
-    for (int bin = threadIdx.x; bin < nbin; bin += kBlock) {
+    for (int bin = threadIdx.x; bin < nbin; bin += kSortBlock) {
         const int r = bin ? cnt[bin - 1] : 0;
         const int m = cnt[bin] - r;
         if (m < 2) continue;
@@ -234,7 +239,7 @@ __device__ __forceinline__ void bucket_sort_lds(const unsigned long long *__rest
 }
 
 template <typename Idx>
-__global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__ p, const Idx *__restrict__ nn, int64_t n,
+__global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restrict__ p, const Idx *__restrict__ nn, int64_t n,
                                                           int64_t B, int nbk, int64_t n_items, int cap_u, unsigned shift_u,
                                                           unsigned bin_bits,
                                                           const int *__restrict__ cnt_u, const unsigned long long *__restrict__ ubuf,
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__
                                                           int *__restrict__ torig, int *__restrict__ flags) {
     extern __shared__ unsigned long long lds[];  // kin[cap] | out[cap] | cnt[1<<shift] (ints)
     __shared__ int scratch[1];
-    __shared__ int wave_tot[kBlock / 64];
+    __shared__ int wave_tot[kSortBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_u;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_u);
     const int64_t b = blockIdx.x / nbk;
@@ -251,10 +256,10 @@ __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__
     const int prefix = bucket_prefix(cnt_u + b * nbk, bucket, cap_u, scratch);
     if (count == 0) return;
     const unsigned long long *src = ubuf + (int64_t)blockIdx.x * cap_u;
-    for (int j = threadIdx.x; j < count; j += kBlock) kin[j] = src[j];
+    for (int j = threadIdx.x; j < count; j += kSortBlock) kin[j] = src[j];
     __syncthreads();
     bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_u, bin_bits, flags);
-    for (int r = threadIdx.x; r < count; r += kBlock) {
+    for (int r = threadIdx.x; r < count; r += kSortBlock) {
         const unsigned long long kv = out[r];
         const uint32_t orig = (uint32_t)kv;
         const int64_t t = b * B + prefix + r;  // position in the user-sorted batch
@@ -271,14 +276,14 @@ __global__ __launch_bounds__(kBlock) void fast_user_sort(const Idx *__restrict__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, int nbk, int cap_i, unsigned shift_i,
+__global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t B, int nbk, int cap_i, unsigned shift_i,
                                                           unsigned bin_bits,
                                                           const int *__restrict__ cnt_i, const unsigned long long *__restrict__ ibuf,
                                                           int *__restrict__ oc_item, int *__restrict__ oc_src, int *__restrict__ tp,
                                                           int *__restrict__ tn, int *__restrict__ flags) {
     extern __shared__ unsigned long long lds[];
     __shared__ int scratch[1];
-    __shared__ int wave_tot[kBlock / 64];
+    __shared__ int wave_tot[kSortBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_i;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_i);
     const int64_t b = blockIdx.x / nbk;
@@ -287,11 +292,11 @@ __global__ __launch_bounds__(kBlock) void fast_item_sort(int64_t n, int64_t B, i
     const int prefix = bucket_prefix(cnt_i + b * nbk, bucket, cap_i, scratch);
     if (count == 0) return;
     const unsigned long long *src = ibuf + (int64_t)blockIdx.x * cap_i;
-    for (int j = threadIdx.x; j < count; j += kBlock) kin[j] = src[j];
+    for (int j = threadIdx.x; j < count; j += kSortBlock) kin[j] = src[j];
     __syncthreads();
     bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_i, bin_bits, flags);
     const int64_t base = 2 * b * B + prefix;
-    for (int r = threadIdx.x; r < count; r += kBlock) {
+    for (int r = threadIdx.x; r < count; r += kSortBlock) {
         const unsigned long long kv = out[r];
         const int item = (int)(kv >> 32);
         const uint32_t lo = (uint32_t)kv;
@@ -341,13 +346,13 @@ static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_
     const unsigned bb_u = bins_for(L.cap_u, L.shift_u), bb_i = bins_for(L.cap_i, L.shift_i);
     const size_t lds_u = (size_t)L.cap_u * 16 + ((size_t)4 << bb_u);
     const size_t lds_i = (size_t)L.cap_i * 16 + ((size_t)4 << bb_i);
-    hipLaunchKernelGGL((fast_user_sort<Idx>), dim3(gb), dim3(kBlock), lds_u, stream, p, nn, n, B, L.nbk, n_items, L.cap_u,
+    hipLaunchKernelGGL((fast_user_sort<Idx>), dim3(gb), dim3(kSortBlock), lds_u, stream, p, nn, n, B, L.nbk, n_items, L.cap_u,
                        L.shift_u, bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags);
     WR_LAUNCH_CHECK("fast_user_sort");
     hipLaunchKernelGGL(fast_item_scatter, dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B, tiles_i,
                        L.nbk, n_items, L.shift_i, L.cap_i, cnt_i, ibuf, flags);
     WR_LAUNCH_CHECK("fast_item_scatter");
-    hipLaunchKernelGGL(fast_item_sort, dim3(gb), dim3(kBlock), lds_i, stream, n, B, L.nbk, L.cap_i, L.shift_i, bb_i, cnt_i, ibuf,
+    hipLaunchKernelGGL(fast_item_sort, dim3(gb), dim3(kSortBlock), lds_i, stream, n, B, L.nbk, L.cap_i, L.shift_i, bb_i, cnt_i, ibuf,
                        oc_item, oc_src, tp, tn, flags);
     WR_LAUNCH_CHECK("fast_item_sort");
     return WR_OK;
