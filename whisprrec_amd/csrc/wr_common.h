@@ -179,6 +179,15 @@ static inline int32_t check_table(const void *tab, int64_t n_rows, int32_t D, co
     return WR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ XCD placement
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, each XCD has its own L2).  This bijective
+// remap hands every XCD a CONTIGUOUS range of logical ids, so workgroups that read the same lines (one batch's index
+// arrays in the plan kernels) fill one L2 instead of eight.  Speed only — never correctness.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned nwg) {
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------ optimizers
 // One element of torch.optim.Adam's single-tensor step (amsgrad off) — shared by the dense pass (wr_rows.hip) and the
 // lazy row replay (wr_lazy.hip), which must produce the same bits.  The two divisions and the square root of the

@@ -250,12 +250,14 @@ __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restri
     __shared__ int wave_tot[kSortBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_u;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_u);
-    const int64_t b = blockIdx.x / nbk;
-    const int bucket = blockIdx.x % nbk;
-    const int count = min(cnt_u[blockIdx.x], cap_u);
+    // the buckets of one batch gather p[] / n[] from the same 2 x 4B x B bytes: keep them on one XCD's L2
+    const unsigned lb = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int64_t b = lb / nbk;
+    const int bucket = lb % nbk;
+    const int count = min(cnt_u[lb], cap_u);
     const int prefix = bucket_prefix(cnt_u + b * nbk, bucket, cap_u, scratch);
     if (count == 0) return;
-    const unsigned long long *src = ubuf + (int64_t)blockIdx.x * cap_u;
+    const unsigned long long *src = ubuf + (int64_t)lb * cap_u;
     for (int j = threadIdx.x; j < count; j += kSortBlock) kin[j] = src[j];
     __syncthreads();
     bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_u, bin_bits, flags);
@@ -286,12 +288,14 @@ __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t 
     __shared__ int wave_tot[kSortBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_i;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_i);
-    const int64_t b = blockIdx.x / nbk;
-    const int bucket = blockIdx.x % nbk;
-    const int count = min(cnt_i[blockIdx.x], cap_i);
+    // the buckets of one batch set flag bits all over the batch's tp[] / tn[]: keep them on one XCD's L2
+    const unsigned lb = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int64_t b = lb / nbk;
+    const int bucket = lb % nbk;
+    const int count = min(cnt_i[lb], cap_i);
     const int prefix = bucket_prefix(cnt_i + b * nbk, bucket, cap_i, scratch);
     if (count == 0) return;
-    const unsigned long long *src = ibuf + (int64_t)blockIdx.x * cap_i;
+    const unsigned long long *src = ibuf + (int64_t)lb * cap_i;
     for (int j = threadIdx.x; j < count; j += kSortBlock) kin[j] = src[j];
     __syncthreads();
     bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_i, bin_bits, flags);
