@@ -20,7 +20,8 @@ def _mask_csr(rng, nU, nI, max_len):
     return ptr, np.concatenate(chunks) if chunks else np.zeros(1, np.int32)
 
 
-@pytest.mark.parametrize("D,nI,n", [(64, 1574, 700), (32, 5000, 300), (128, 333, 200), (64, 40, 130)])
+@pytest.mark.parametrize("D,nI,n", [(64, 1574, 700), (32, 5000, 300), (128, 333, 200), (64, 40, 130), (16, 2100, 257), (8, 777, 129),
+                                    (24, 500, 100), (64, 4133, 1000)])
 def test_ranks_match_oracle(D, nI, n):
     from whisprrec_amd import hip_ops
     dev = torch.device("cuda:0")

@@ -111,6 +111,159 @@ __global__ __launch_bounds__(kBlock) void eval_rank_kernel(const float *__restri
     }
 }
 
+// Same computation for D = 2*KS <= 64 with the A operand (this wave's 32 evaluation rows) held in KS registers for the
+// whole chunk, item tiles of 64 rows double-buffered in LDS (the next tile's global loads are in flight while the
+// current one feeds the matrix cores; one barrier per tile instead of two per 32 items), and one LDS read per MFMA.
+#ifndef WR_EVAL_TILE
+#define WR_EVAL_TILE 64
+#endif
+constexpr int kEvalTile = WR_EVAL_TILE;
+
+// 3 workgroups per CU (<= 168 VGPRs, no spill): A/B on MI355X 2 / 3 / 4 per CU = 101 / 111 / 86 TFLOP/s at 100K x 100K x 64.
+template <int KS>
+__global__ __launch_bounds__(kBlock, 3) void eval_rank_kernel_rega(const float *__restrict__ U, const float *__restrict__ I,
+                                                                 int64_t n_items, const int64_t *__restrict__ eu,
+                                                                 const float *__restrict__ tscore, int64_t n,
+                                                                 const int64_t *__restrict__ mask_ptr,
+                                                                 const int *__restrict__ mask_idx, int *__restrict__ rank_cnt) {
+    constexpr int D = 2 * KS, LDW = D + 1, D4 = D / 4;
+    constexpr int NLOAD = (kEvalTile * D4 + kBlock - 1) / kBlock;        // float4 loads per thread and tile
+    __shared__ float it[2][kEvalTile * LDW];
+    __shared__ unsigned rowmask[2][kEvalTile / 32][kEvalRows];
+    __shared__ unsigned anymask[2][kBlock / 64];   // does any row of slab w have a masked item in the tile?
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t e0 = (int64_t)blockIdx.x * kEvalRows;
+    const int64_t c0 = (int64_t)blockIdx.y * kEvalChunk;
+    const int64_t c1 = (c0 + kEvalChunk < n_items) ? c0 + kEvalChunk : n_items;
+    // A[i = lane&31][k = 2s + (lane>>5)] of this wave's slab
+    float a[KS];
+    {
+        const int64_t e = e0 + wave * 32 + col;
+        const float *urow = U + ((e < n) ? eu[e] : 0) * (int64_t)D + half;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = (e < n) ? urow[2 * s] : 0.f;
+    }
+    int64_t cur = 0, cend = 0;
+    if (threadIdx.x < kEvalRows && mask_ptr != nullptr && e0 + threadIdx.x < n) {
+        const int64_t uu = eu[e0 + threadIdx.x];
+        int64_t lo = mask_ptr[uu], hi = mask_ptr[uu + 1];
+        cend = hi;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)mask_idx[mid] < c0) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+    }
+    // the next masked item of this row waits in a register: a tile without masked items (almost all of them) costs no
+    // memory access on the way to the barrier
+    int nxt = (cur < cend) ? mask_idx[cur] : 0x7fffffff;
+    float trow[16];
+    int cnt[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        const int64_t e = e0 + wave * 32 + row;
+        trow[reg] = (e < n) ? tscore[e] : 3.4e38f;
+        cnt[reg] = 0;
+    }
+    float4 stage[NLOAD];
+    auto fetch = [&](int64_t j0) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int f = threadIdx.x + i * kBlock;
+            const int r = f / D4, k4 = f - r * D4;
+            stage[i] = (f < kEvalTile * D4 && j0 + r < n_items)
+                           ? reinterpret_cast<const float4 *>(I + (j0 + r) * (int64_t)D)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto deposit = [&](int buf, int64_t j0) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int f = threadIdx.x + i * kBlock;
+            if (f < kEvalTile * D4) {
+                const int r = f / D4, k4 = f - r * D4;
+                float *dst = &it[buf][r * LDW + 4 * k4];
+                dst[0] = stage[i].x; dst[1] = stage[i].y; dst[2] = stage[i].z; dst[3] = stage[i].w;
+            }
+        }
+        if (threadIdx.x < kEvalRows) {           // which of the tile's items are masked for this row
+            unsigned m[kEvalTile / 32];
+#pragma unroll
+            for (int c = 0; c < kEvalTile / 32; ++c) m[c] = 0;
+            while ((int64_t)nxt < j0 + kEvalTile) {
+                const int64_t d = (int64_t)nxt - j0;
+                if (d >= 0) m[d >> 5] |= 1u << (unsigned)(d & 31);
+                ++cur;
+                nxt = (cur < cend) ? mask_idx[cur] : 0x7fffffff;
+            }
+            unsigned any = 0;
+#pragma unroll
+            for (int c = 0; c < kEvalTile / 32; ++c) {
+                rowmask[buf][c][threadIdx.x] = m[c];
+                any |= m[c];
+            }
+            // rows 0..127 sit in waves 0 and 1: slab w = rows 32w..32w+31 = lanes 32(w&1).. of wave w>>1
+            const unsigned long long bal = __ballot(any != 0);
+            if (lane == 0) {
+                anymask[buf][2 * wave] = (unsigned)(bal & 0xffffffffull) != 0;
+                anymask[buf][2 * wave + 1] = (unsigned)(bal >> 32) != 0;
+            }
+        }
+    };
+    fetch(c0);
+    deposit(0, c0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t j0 = c0; j0 < c1; j0 += kEvalTile, buf ^= 1) {
+        const bool more = j0 + kEvalTile < c1;
+        if (more) fetch(j0 + kEvalTile);                        // global loads fly while the matrix cores work
+        {   // the tile's 32-item column blocks as independent accumulator chains: a dependent MFMA waits for its
+            // predecessor's result, an independent one issues right behind it
+            constexpr int C = kEvalTile / 32;
+            const float *bcol = &it[buf][col * LDW + half];          // B[k = 2s + (lane>>5)][j = lane&31] of block 0
+            f32x16 acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bcol[c * 32 * LDW + 2 * s], acc[c], 0, 0, 0);
+            }
+            if (anymask[buf][wave] == 0 && j0 + kEvalTile <= n_items) {   // wave-uniform: nothing masked, tile inside the table
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) cnt[reg] += acc[c][reg] > trow[reg] ? 1 : 0;
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const bool ok = j0 + c * 32 + col < n_items;
+                        const bool m = (rowmask[buf][c][wave * 32 + row] >> col) & 1u;
+                        cnt[reg] += (ok && !m && acc[c][reg] > trow[reg]) ? 1 : 0;
+                    }
+                }
+            }
+        }
+        if (more) deposit(buf ^ 1, j0 + kEvalTile);             // the other buffer was last read one barrier ago
+        __syncthreads();
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        int v = cnt[reg];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        const int64_t e = e0 + wave * 32 + row;
+        if (col == 0 && e < n && v) atomicAdd(&rank_cnt[e], v);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void eval_finish_kernel(int *__restrict__ rank, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) rank[i] += 1;
@@ -138,13 +291,24 @@ int32_t wr_rank_eval(const float *user_mat, int64_t n_user_rows, const float *it
     hipLaunchKernelGGL(eval_target_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, user_mat, item_tab,
                        D, eval_user, eval_target, n, target_score);
     WR_LAUNCH_CHECK("eval_target_kernel");
-    const size_t lds = ((size_t)(kEvalRows + 32) * (D + 1) + kEvalRows) * 4;
     const dim3 grid((unsigned)((n + kEvalRows - 1) / kEvalRows), (unsigned)((n_items + kEvalChunk - 1) / kEvalChunk));
-    if (lds > 64 * 1024)
-        WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    hipLaunchKernelGGL(eval_rank_kernel, grid, dim3(kBlock), lds, stream, user_mat, item_tab, D, n_items, eval_user, target_score,
-                       n, mask_ptr, mask_idx, rank);
+    if (D == 64 || D == 32 || D == 16 || D == 8) {   // A operand in registers, double-buffered item tiles
+#define WR_EVAL_REGA(KS_)                                                                                             \
+    hipLaunchKernelGGL(eval_rank_kernel_rega<KS_>, grid, dim3(kBlock), 0, stream, user_mat, item_tab, n_items, eval_user, \
+                       target_score, n, mask_ptr, mask_idx, rank)
+        if (D == 64) WR_EVAL_REGA(32);
+        else if (D == 32) WR_EVAL_REGA(16);
+        else if (D == 16) WR_EVAL_REGA(8);
+        else WR_EVAL_REGA(4);
+#undef WR_EVAL_REGA
+    } else {
+        const size_t lds = ((size_t)(kEvalRows + 32) * (D + 1) + kEvalRows) * 4;
+        if (lds > 64 * 1024)
+            WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_rank_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(eval_rank_kernel, grid, dim3(kBlock), lds, stream, user_mat, item_tab, D, n_items, eval_user,
+                           target_score, n, mask_ptr, mask_idx, rank);
+    }
     WR_LAUNCH_CHECK("eval_rank_kernel");
     hipLaunchKernelGGL(eval_finish_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rank, n);
     WR_LAUNCH_CHECK("eval_finish_kernel");
