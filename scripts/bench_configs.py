@@ -107,6 +107,28 @@ def c2_epoch_case(n_inter=100_000_000, nU=1_000_000, nI=1_000_000, D=64, B=65536
          clicked_csr_build_once_ms=t_csr * 1e3, triplets_per_s_epoch=n_inter / (res["epoch_ms"] * 1e-3), **res)
 
 
+def c2_pcie_case(n_inter=50_000_000, nU=1_000_000, nI=1_000_000, D=64, B=65536):
+    """the boundary as the reference hands it over: the epoch's (u, p, n) as int64 HOST arrays (BaseModel.py:96-127 builds
+    int64 batches on the host); PCIe copy + plans + steps.  Reported beside the HBM-resident headline, never as it."""
+    U, I = tables(nU, nI, D)
+    pipe = hip_ops.PipelinedSgd(64)
+    nb = (n_inter + B - 1) // B
+    host = [torch.randint(0, hi, (n_inter,), dtype=torch.int64) for hi in (nU, nI, nI)]
+    for kind in ("pageable", "pinned"):
+        hs = [h.pin_memory() for h in host] if kind == "pinned" else host
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            d = [h.to(dev, non_blocking=True) for h in hs]
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            losses = torch.empty(nb, dtype=torch.float32, device=dev)
+            pipe.run(pipe.plan(U, [(I, d[0], d[1], d[2])], B), 0, 0.05, losses)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+        emit(case="C2 epoch from HOST int64 index arrays (%s): PCIe copy, then plans + %d steps" % (kind, nb), interactions=n_inter,
+             h2d_ms=(t1 - t0) * 1e3, h2d_GBs=3 * 8 * n_inter / (t1 - t0) / 1e9, plan_and_steps_ms=(t2 - t1) * 1e3,
+             triplets_per_s_pcie_inclusive=n_inter / (t2 - t0), triplets_per_s_hbm_resident=n_inter / (t2 - t1))
+        del d
+
+
 def lightgcn_case():
     from whisprrec_amd.lightgcn import LightGCN
     rng = np.random.RandomState(0)
@@ -197,7 +219,7 @@ def eval_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c2big", "lazy", "c2epoch", "c4", "c3", "c5", "c1", "eval"]
+    which = sys.argv[1:] or ["c2", "c2big", "lazy", "c2epoch", "c2pcie", "c4", "c3", "c5", "c1", "eval"]
     if "c2" in which:
         for B, NB in ((2048, 256), (16384, 128), (65536, 64), (262144, 16)):
             bprmf_case("C2 BPRMF 1Mx1M D=64 SGD l2=0", 1_000_000, 1_000_000, 64, B, NB)
@@ -208,6 +230,8 @@ if __name__ == "__main__":
         bprmf_case("C2 BPRMF 1Mx1M D=64 SGD l2=0", 1_000_000, 1_000_000, 64, 1048576, 8)
     if "c2epoch" in which:
         c2_epoch_case()
+    if "c2pcie" in which:
+        c2_pcie_case()
     if "lazy" in which:
         bprmf_case("C2 SGD l2=1e-6", 1_000_000, 1_000_000, 64, 65536, 64, l2=1e-6, lazy=True)
         bprmf_case("C2 Adam", 1_000_000, 1_000_000, 64, 65536, 64, opt="Adam", lazy=True)
