@@ -266,7 +266,7 @@ def test_ml100k_adam_curve_matches_reference_golden(ops, dev, g2):
     assert rel_err(tabs.I.cpu().numpy(), g2["adam_Iend"]) < 1e-4
 
 
-@pytest.mark.parametrize("D", [8, 32, 64, 96, 128, 256])
+@pytest.mark.parametrize("D", [4, 8, 32, 64, 96, 128, 256, 500, 1024])   # 4 and 1024: the smallest and largest supported rows
 def test_step_vs_oracle_embedding_sizes(ops, dev, D):
     rng = np.random.RandomState(100 + D)
     nU, nI, B = 203, 157, 2048   # heavy duplication: every row appears ~10x
