@@ -306,6 +306,51 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_hot_combine(float *__restri
 // after the other (two dependent round trips each), with 64 one or two.
 constexpr int kItemTile = WR_ITEM_TILE;
 static_assert(kItemTile <= kBlock && kItemTile >= 32, "item tile");
+// A piece = up to kHotPiece consecutive occurrences of ONE item row.  One workgroup per piece: team j sums occurrences
+// j, j+TEAMS, ... in that order, four stashed rows in flight at a time; the TEAMS partial rows are added in team order
+// through LDS.  Runs as extra workgroups of the item-phase launch (the pieces touch no table row).
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ void item_hot_piece(int piece, int D, const int *__restrict__ oc_src, const float *__restrict__ Z,
+                                               const int *__restrict__ piece_q, const int *__restrict__ piece_len,
+                                               float *__restrict__ hotP, float *__restrict__ rows) {
+    constexpr int TEAMS = kBlock / T;
+    constexpr int kFly = 4;
+    const int lane = threadIdx.x % T, team = threadIdx.x / T;
+    const int q0 = piece_q[piece], len = piece_len[piece];
+    Row<NV> g;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = team; k < len; k += kFly * TEAMS) {
+        int src[kFly];
+        Row<NV> z[kFly];
+#pragma unroll
+        for (int f = 0; f < kFly; ++f) src[f] = (k + f * TEAMS < len) ? oc_src[q0 + k + f * TEAMS] : -1;
+#pragma unroll
+        for (int f = 0; f < kFly; ++f)
+            if (src[f] >= 0) z[f] = load_row<T, NV, FULL>(Z, src[f] >> 1, D, lane);
+#pragma unroll
+        for (int f = 0; f < kFly; ++f) {
+            if (src[f] < 0) continue;
+            const float sgn = (src[f] & 1) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                g.v[c].x = fmaf(sgn, z[f].v[c].x, g.v[c].x); g.v[c].y = fmaf(sgn, z[f].v[c].y, g.v[c].y);
+                g.v[c].z = fmaf(sgn, z[f].v[c].z, g.v[c].z); g.v[c].w = fmaf(sgn, z[f].v[c].w, g.v[c].w);
+            }
+        }
+    }
+    store_row<T, NV, FULL>(rows, team, D, lane, g);
+    __syncthreads();
+    for (int c = threadIdx.x; c * 4 < D; c += kBlock) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < TEAMS; ++j) {
+            const float4 v = reinterpret_cast<const float4 *>(rows + (int64_t)j * D)[c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4 *>(hotP + (int64_t)piece * D)[c] = a;
+    }
+}
+
 template <int T, int NV, bool FULL, int MODE>
 __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I, int D, const int *__restrict__ oc_item,
                                                             const int *__restrict__ oc_src, int B2,
@@ -313,14 +358,21 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
                                                             const float *__restrict__ partials, int n_partials,
                                                             float loss_denom, float *__restrict__ loss_out, int skip_hot,
-                                                            const unsigned long long *__restrict__ hot_loss) {
+                                                            const unsigned long long *__restrict__ hot_loss, int n_tiles,
+                                                            const int *__restrict__ piece_q, const int *__restrict__ piece_len,
+                                                            float *__restrict__ hotP) {
+    extern __shared__ float piece_rows[];   // [TEAMS][D], only when the launch carries hot pieces
+    if ((int)blockIdx.x >= n_tiles) {       // extra workgroups: one hot piece each (independent of the tiles' rows)
+        item_hot_piece<T, NV, FULL>((int)blockIdx.x - n_tiles, D, oc_src, Z, piece_q, piece_len, hotP, piece_rows);
+        return;
+    }
     __shared__ float scratch[kBlock / 64];
     __shared__ int heads[kItemTile];
-    __shared__ int item_tile[kItemTile + 8];  // oc_item of this tile plus up to 8 entries beyond it
-    __shared__ int src_tile[kItemTile + 8];
+    constexpr int kAhead = kHotRun + 1;       // a run that starts in the tile is in LDS up to the entry that proves it hot
+    __shared__ int item_tile[kItemTile + kAhead];
+    __shared__ int src_tile[kItemTile + kAhead];
     __shared__ int n_heads;
     constexpr int TEAMS = kBlock / T;
-    constexpr int kAhead = 8;
     const int lane = threadIdx.x % T;
     const int tile0 = blockIdx.x * kItemTile;
     // 1) one THREAD per sorted occurrence: stage the tile's (item, source) pairs in LDS, find the heads of runs
@@ -348,8 +400,14 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
     for (int h = threadIdx.x / T; h < nh; h += TEAMS) {
         const int j0 = heads[h];
         const int r = item_tile[j0];
-        // runs longer than kHotRun are cut into pieces by the plan and summed by bprmf_item_hot_* (many workgroups)
-        if (skip_hot && tile0 + j0 + kHotRun < B2 && oc_item[tile0 + j0 + kHotRun] == r) continue;
+        // run length from the staged entries (entries past the batch are -1); runs longer than kHotRun are cut into pieces
+        // by the plan and summed by the piece workgroups + bprmf_item_hot_combine
+        int m = 2;
+        while (m <= kHotRun && item_tile[j0 + m] == r) ++m;
+        if (m > kHotRun) {
+            if (skip_hot) continue;
+            m = kHotRun;   // unreachable with a plan that lists its hot runs; never walk past the staged window
+        }
         {
             const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
             const int s0 = src_tile[j0], s1 = src_tile[j0 + 1];
@@ -364,25 +422,27 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                 g.v[k].z = fmaf(g1, z1.v[k].z, fmaf(g0, z0.v[k].z, 0.f));
                 g.v[k].w = fmaf(g1, z1.v[k].w, fmaf(g0, z0.v[k].w, 0.f));
             }
-            // third and later occurrences (rare): walk on, from LDS while inside the staged window
-            int j = j0 + 2;
-            for (;;) {
-                const int q = tile0 + j;
-                if (q >= B2) break;
-                const bool in_lds = j < kItemTile + kAhead;
-                const int it = in_lds ? item_tile[j] : oc_item[q];
-                if (it != r) break;
-                const int src = in_lds ? src_tile[j] : oc_src[q];
-                const Row<NV> z = load_row<T, NV, FULL>(Z, src >> 1, D, lane);
-                const float sgn = (src & 1) ? -1.0f : 1.0f;
+            // third and later occurrences: four stashed rows in flight at a time, added in sorted order
+            for (int j = 2; j < m; j += 4) {
+                int src[4];
+                Row<NV> z[4];
 #pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    g.v[k].x = fmaf(sgn, z.v[k].x, g.v[k].x);
-                    g.v[k].y = fmaf(sgn, z.v[k].y, g.v[k].y);
-                    g.v[k].z = fmaf(sgn, z.v[k].z, g.v[k].z);
-                    g.v[k].w = fmaf(sgn, z.v[k].w, g.v[k].w);
+                for (int f = 0; f < 4; ++f) src[f] = (j + f < m) ? src_tile[j0 + j + f] : -1;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    if (src[f] >= 0) z[f] = load_row<T, NV, FULL>(Z, src[f] >> 1, D, lane);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    if (src[f] < 0) continue;
+                    const float sgn = (src[f] & 1) ? -1.0f : 1.0f;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        g.v[k].x = fmaf(sgn, z[f].v[k].x, g.v[k].x);
+                        g.v[k].y = fmaf(sgn, z[f].v[k].y, g.v[k].y);
+                        g.v[k].z = fmaf(sgn, z[f].v[k].z, g.v[k].z);
+                        g.v[k].w = fmaf(sgn, z[f].v[k].w, g.v[k].w);
+                    }
                 }
-                ++j;
             }
             if (MODE == 0) {
                 Row<NV> w;
@@ -407,51 +467,6 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
             if (hot_loss != nullptr) s += (float)((double)(long long)hot_loss[0] / kHotLossScale);
             loss_out[0] = s / loss_denom;
         }
-    }
-}
-
-// ----------------------------------------------------------------------------------------------- hot rows
-// A piece = up to kHotPiece consecutive occurrences of ONE item row.  One workgroup per piece: team j sums occurrences
-// j, j+TEAMS, ... (next one prefetched), the TEAMS partial rows are added in team order through LDS.
-template <int T, int NV, bool FULL>
-__global__ __launch_bounds__(kBlock) void bprmf_item_hot_pieces(int D, const int *__restrict__ oc_src, const float *__restrict__ Z,
-                                                                 const int *__restrict__ piece_q, const int *__restrict__ piece_len,
-                                                                 float *__restrict__ hotP) {
-    extern __shared__ float rows[];  // [TEAMS][D]
-    constexpr int TEAMS = kBlock / T;
-    const int lane = threadIdx.x % T, team = threadIdx.x / T;
-    const int q0 = piece_q[blockIdx.x], len = piece_len[blockIdx.x];
-    Row<NV> g;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k = team;
-    int src = (k < len) ? oc_src[q0 + k] : 0;
-    Row<NV> z = (k < len) ? load_row<T, NV, FULL>(Z, src >> 1, D, lane) : g;
-    while (k < len) {
-        const int kn = k + TEAMS;
-        int src_n = 0;
-        Row<NV> zn = g;
-        if (kn < len) {
-            src_n = oc_src[q0 + kn];
-            zn = load_row<T, NV, FULL>(Z, src_n >> 1, D, lane);
-        }
-        const float sgn = (src & 1) ? -1.0f : 1.0f;
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            g.v[c].x = fmaf(sgn, z.v[c].x, g.v[c].x); g.v[c].y = fmaf(sgn, z.v[c].y, g.v[c].y);
-            g.v[c].z = fmaf(sgn, z.v[c].z, g.v[c].z); g.v[c].w = fmaf(sgn, z.v[c].w, g.v[c].w);
-        }
-        k = kn; src = src_n; z = zn;
-    }
-    store_row<T, NV, FULL>(rows, team, D, lane, g);
-    __syncthreads();
-    for (int c = threadIdx.x; c * 4 < D; c += kBlock) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = 0; j < TEAMS; ++j) {
-            const float4 v = reinterpret_cast<const float4 *>(rows + (int64_t)j * D)[c];
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
-        reinterpret_cast<float4 *>(hotP + (int64_t)blockIdx.x * D)[c] = a;
     }
 }
 
@@ -613,10 +628,13 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
         WR_LAUNCH_CHECK("bprmf_user_hot_*");
     }
     if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[1]), stream));
+    // hot pieces ride along as extra workgroups of the same launch (they only read the stash and write hotP)
+    const dim3 gridBP(gridB.x + (have_hot ? (unsigned)hot.item.n_pieces : 0u));
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
-    hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridB, block, 0, stream, I, D, oc_item, oc_src,        \
-                       (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)gridA.x, denom,         \
-                       loss_out, have_hot ? 1 : 0, have_hot_u ? w.hot_loss : nullptr)
+    hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridBP, block, have_hot ? lds_rows : 0, stream, I, D, \
+                       oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)gridA.x,  \
+                       denom, loss_out, have_hot ? 1 : 0, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,            \
+                       hot.item.piece_q, hot.item.piece_len, w.hotP)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
     WR_LAUNCH_CHECK("bprmf_item_phase");
@@ -624,8 +642,6 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
         const unsigned grun = (unsigned)n_blocks_for(hot.item.n_runs, D);
 #define WR_CALL_HOT(T_, NV_, FULL_)                                                                                      \
     do {                                                                                                                \
-        hipLaunchKernelGGL((bprmf_item_hot_pieces<T_, NV_, FULL_>), dim3((unsigned)hot.item.n_pieces), block, lds_rows,  \
-                           stream, D, oc_src, w.Z, hot.item.piece_q, hot.item.piece_len, w.hotP);                       \
         hipLaunchKernelGGL((bprmf_item_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, I, D, oc_item,  \
                            hot.item.run_q, hot.item.run_first, hot.item.run_np, hot.item.n_runs, w.hotP, lr, l2, gradI, \
                            stamp_i, step_id);                                                                           \
