@@ -36,11 +36,15 @@ def _worker(rank, world, port, payload, out_dir):
         nU, nI, D, B, lr, parts = payload["shape"]
         m = RotatingBprmf(nU, nI, D, torch.device("cpu"), parts=parts, local=OracleLocal())
         m.load_full(torch.from_numpy(payload["U"]), torch.from_numpy(payload["I"]))
-        losses = []
-        for r in range(world):
-            u, p, n, per_part = payload["strata"][rank][r]
-            assert m.held == (rank + r) % world
-            losses.append(m.run_subepoch(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n), per_part, B, lr))
+        T = torch.from_numpy
+        if payload["whole_epoch"]:                                  # all strata in one call: plans pipelined across rotations
+            losses = [m.run_strata([(T(u), T(p), T(n), pp) for (u, p, n, pp) in payload["strata"][rank]], B, lr)]
+        else:
+            losses = []
+            for r in range(world):
+                u, p, n, per_part = payload["strata"][rank][r]
+                assert m.held == (rank + r) % world
+                losses.append(m.run_subepoch(T(u), T(p), T(n), per_part, B, lr))
         assert m.held == rank                                       # a full epoch brings every block home
         gl = m.global_losses(torch.cat(losses))
         Uf, If = m.gather_full()
@@ -55,8 +59,8 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world,nI,parts", [(2, 61, 2), (3, 100, 2), (2, 40, 1), (3, 37, 3)])
-def test_rotating_epoch_equals_single_process(tmp_path, world, nI, parts):
+@pytest.mark.parametrize("world,nI,parts,whole", [(2, 61, 2, False), (3, 100, 2, True), (2, 40, 1, True), (3, 37, 3, False)])
+def test_rotating_epoch_equals_single_process(tmp_path, world, nI, parts, whole):
     from whisprrec_amd.sharded import n_local_rows
     rng = np.random.RandomState(world * 10 + parts)
     nU, D, B, lr = 53, 16, 32, 0.3
@@ -82,7 +86,7 @@ def test_rotating_epoch_equals_single_process(tmp_path, world, nI, parts):
             u, p, n = np.concatenate(us), np.concatenate(ps), np.concatenate(ns)
             strata[rank][r] = (u.astype(np.int64), p.astype(np.int64), n.astype(np.int64), steps_per_part)
             glob[r].append((u * world + rank, p * world + held, n * world + held))   # back to global ids
-    payload = dict(shape=(nU, nI, D, B, lr, parts), U=U, I=I, strata=strata)
+    payload = dict(shape=(nU, nI, D, B, lr, parts), U=U, I=I, strata=strata, whole_epoch=whole)
     mp.spawn(_worker, args=(world, _free_port(), payload, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     Uo, Io = U.copy(), I.copy()

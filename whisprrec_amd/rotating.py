@@ -142,27 +142,42 @@ class RotatingBprmf:
         the first steps_per_part[0] batches use items of part 0 only, the next steps_per_part[1] batches items of part 1, ...
         As soon as the steps of a part are enqueued the part is handed to the ring.  Every rank must pass the same
         steps_per_part.  Returns the per-step local losses (mean over ranks = loss of the global batch)."""
-        nb = int(sum(steps_per_part))
-        losses = torch.zeros(nb, dtype=torch.float32, device=self.device)
+        return self.run_strata([(u, p, n, steps_per_part)], batch, lr)
+
+    def run_strata(self, strata, batch, lr):
+        """Consecutive strata [(u, p, n, steps_per_part), ...] (see run_subepoch), one block rotation after each.  All
+        their batches go to the local runner as ONE list of segments, so its plan pipeline runs across the rotations: the
+        first plan of stratum r+1 is built while stratum r trains (a plan needs the indices only, not the block that is
+        still on its way).  With 8 GPUs a stratum is a few dozen steps: an exposed plan build per stratum would cost a
+        third of it."""
+        B = int(batch)
         # the global batch is the union of the G local batches: its mean loss has 1/(G*B) coefficients.  The local kernels
         # use 1/B, and the local batches touch disjoint rows, so dividing the learning rate by G gives the same update.
         lr = lr / self.world
-        B = int(batch)
-        segments, first = [], 0
-        per_part = [int(steps_per_part[k]) if k < len(steps_per_part) else 0 for k in range(self.parts)]
-        for k, st in enumerate(per_part):
-            lo, hi = self.part_range(self.held, k)
-            sl = slice(first * B, min(u.numel(), (first + st) * B))
-            segments.append((self.I[lo:hi], u[sl], p[sl] - lo, n[sl] - lo))
-            first += st
-        handle = self.local.plan(self.U, segments, B)
-        first = 0
-        for k, st in enumerate(per_part):
-            if st > 0:
-                self.local.run(handle, k, lr, losses[first:first + st])
+        bufs = (self.I, self.I_in)                      # stratum r trains on bufs[r % 2] (the rotation swaps them)
+        segments, counts, held = [], [], self.held
+        for r, (u, p, n, steps_per_part) in enumerate(strata):
+            per_part = [int(steps_per_part[k]) if k < len(steps_per_part) else 0 for k in range(self.parts)]
+            table = bufs[r % 2] if self.world > 1 else self.I
+            first = 0
+            for k, st in enumerate(per_part):
+                lo, hi = self.part_range(held, k)
+                sl = slice(first * B, min(u.numel(), (first + st) * B))
+                segments.append((table[lo:hi], u[sl], p[sl] - lo, n[sl] - lo))
                 first += st
-            self._send_part(k)
-        self._finish_rotation()
+            counts.append(per_part)
+            held = (held + 1) % self.world
+        losses = torch.zeros(sum(sum(c) for c in counts), dtype=torch.float32, device=self.device)
+        handle = self.local.plan(self.U, segments, B)
+        first, seg = 0, 0
+        for per_part in counts:
+            for k, st in enumerate(per_part):
+                if st > 0:
+                    self.local.run(handle, seg, lr, losses[first:first + st])
+                    first += st
+                seg += 1
+                self._send_part(k)
+            self._finish_rotation()
         return losses
 
     def global_losses(self, local_losses):
@@ -219,7 +234,7 @@ def bench_main(args, rank, world, local_rank):
         return sched, held
 
     def run_schedule(sched):
-        return torch.cat([model.run_subepoch(u, p, n, per_part, B, args.lr) for (u, p, n, per_part) in sched])
+        return model.run_strata(sched, B, args.lr)
 
     warm, held_after = make_schedule(W, model.held)
     timed, _ = make_schedule(K, held_after)
