@@ -191,17 +191,28 @@ __device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned nwg
 // ------------------------------------------------------------------------------------------------ optimizers
 // One element of torch.optim.Adam's single-tensor step (amsgrad off) — shared by the dense pass (wr_rows.hip) and the
 // lazy row replay (wr_lazy.hip), which must produce the same bits.  The two divisions and the square root of the
-// reference formula use the hardware v_rcp_f32 / v_sqrt_f32 (1 ulp) and a host-side 1/sqrt(bias_correction2): the lazy
-// replay is ALU-bound on exactly this function, and IEEE-rounded fdiv/fsqrt expansions cost 2.3x as many issue slots for
-// a difference far below the 1e-5 parity tolerance (the update term is off by <= 3 ulp, the weight by lr * that).
+// reference formula use the hardware v_rcp_f32 / v_sqrt_f32 (1 ulp) and a host-side 1/sqrt(bias_correction2), and the
+// multiply-adds are fused (as torch's own GPU kernels are free to): the lazy replay is ALU-bound on exactly this function,
+// and IEEE-rounded fdiv/fsqrt expansions cost 2.3x as many issue slots for a difference far below the 1e-5 parity
+// tolerance (the update term is off by <= 3 ulp, the weight by lr * that).
 template <bool L2 = true>
 __device__ __forceinline__ void adam_elem(float &w, float &m, float &v, float g, float l2, float b1, float b2, float eps,
                                           float step_size, float inv_bc2_sqrt) {
     if (L2 && l2 != 0.f) g = fmaf(l2, w, g);   // L2 = false: the caller knows l2 == 0
-    m = m + (1.0f - b1) * (g - m);         // exp_avg.lerp_(grad, 1-beta1)
-    v = b2 * v + (1.0f - b2) * g * g;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2_sqrt + eps;   // sqrt(v)/sqrt(bias_correction2) + eps
-    w = w - step_size * (m * __builtin_amdgcn_rcpf(denom));               // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m = fmaf(1.0f - b1, g - m, m);             // exp_avg.lerp_(grad, 1-beta1)
+    v = fmaf(b2, v, (1.0f - b2) * g * g);      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, eps);   // sqrt(v)/sqrt(bias_correction2) + eps
+    w = fmaf(-step_size, m * __builtin_amdgcn_rcpf(denom), w);                 // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+// The same element step with a zero gradient and l2 == 0 — what the lazy replay spends its time in: 5 VALU + sqrt + rcp.
+// Bit-identical to adam_elem<false>(.., g = 0, ..): g - m = -m exactly, fma(b2, v, +0) = b2 * v for v >= +0.
+__device__ __forceinline__ void adam_elem_zero_grad(float &w, float &m, float &v, float b1, float b2, float eps,
+                                                    float step_size, float inv_bc2_sqrt) {
+    m = fmaf(-(1.0f - b1), m, m);
+    v = b2 * v;
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, eps);
+    w = fmaf(-step_size, m * __builtin_amdgcn_rcpf(denom), w);
 }
 
 // Host side of the same step: step_size = lr/(1-beta1^t), 1/sqrt(1-beta2^t), in double as torch computes the bias

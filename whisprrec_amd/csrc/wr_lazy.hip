@@ -32,6 +32,10 @@ __device__ __forceinline__ void adam_rows(float *__restrict__ w, float *__restri
                                           const float *__restrict__ grad, const float *__restrict__ consts, float l2, float b1,
                                           float b2, float eps, int lane) {
     const float2 *__restrict__ c2 = reinterpret_cast<const float2 *>(consts);
+    auto replay = [&](float &ww, float &mm, float &vv, float2 k) {   // one gradient-free step
+        if (L2) adam_elem<true>(ww, mm, vv, 0.f, l2, b1, b2, eps, k.x, k.y);
+        else adam_elem_zero_grad(ww, mm, vv, b1, b2, eps, k.x, k.y);
+    };
     int64_t rows[R];
     int from[R];
 #pragma unroll
@@ -56,12 +60,10 @@ __device__ __forceinline__ void adam_rows(float *__restrict__ w, float *__restri
             int s = from[j] + 1;
             for (; s + 3 <= upto; s += 4) {   // four steps per trip: their (wave-uniform) constants are fetched together
                 const float2 k0 = c2[s], k1 = c2[s + 1], k2 = c2[s + 2], k3 = c2[s + 3];
-                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k0.x, k0.y);
-                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k1.x, k1.y);
-                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k2.x, k2.y);
-                adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, k3.x, k3.y);
+                replay(ww[j], mm[j], vv[j], k0); replay(ww[j], mm[j], vv[j], k1);
+                replay(ww[j], mm[j], vv[j], k2); replay(ww[j], mm[j], vv[j], k3);
             }
-            for (; s <= upto; ++s) adam_elem<L2>(ww[j], mm[j], vv[j], 0.f, l2, b1, b2, eps, c2[s].x, c2[s].y);
+            for (; s <= upto; ++s) replay(ww[j], mm[j], vv[j], c2[s]);
             if (grad != nullptr) adam_elem<L2>(ww[j], mm[j], vv[j], gg[j], l2, b1, b2, eps, c2[upto + 1].x, c2[upto + 1].y);
             const int64_t at = rows[j] * (int64_t)D + e;
             w[at] = ww[j]; m[at] = mm[j]; v[at] = vv[j];
