@@ -106,6 +106,9 @@ def bpr_fwd(user_tab, item_tab, u, p, n, scores=True, coef=False):
 
 
 # ----------------------------------------------------------------------------------------------- plan
+_FAST_BACKOFF = {}
+
+
 class BatchPlan:
     """Sorted batches for the fused step (see include/whisprrec_hip.h, "Batch plan").
 
@@ -142,6 +145,12 @@ class BatchPlan:
         self.hot = None
         self.builder = None
         args = (N, self.batch_size, self.n_users, self.n_items)
+        # "auto": ids skewed enough to overflow a bucket keep doing so chunk after chunk — after an overflow the next 32
+        # plans of the same shape go straight to the radix-sort builder instead of paying for a failed attempt each
+        backoff_key = (str(dev), self.batch_size, self.n_users, self.n_items)
+        if builder == "auto" and _FAST_BACKOFF.get(backoff_key, 0) > 0:
+            _FAST_BACKOFF[backoff_key] -= 1
+            builder = "generic"
         if builder in ("auto", "fast"):
             nbytes = abi.check_size(L.wr_bprmf_plan_fast_workspace_bytes(*args), "wr_bprmf_plan_fast_workspace_bytes")
             if nbytes > 0:
@@ -156,6 +165,7 @@ class BatchPlan:
                     raise abi.WhisprRecHipError("fast plan builder: bucket overflow (skewed ids)")
                 else:
                     self.flags.zero_()
+                    _FAST_BACKOFF[backoff_key] = 32
             elif builder == "fast":
                 raise abi.WhisprRecHipError("fast plan builder not applicable to this batch size")
         if self.builder is None:
