@@ -17,8 +17,8 @@ respect to the reference's sampling: the negative of a triplet is drawn from the
 1/G subset of the items, i % G) instead of from all items, and batches are drawn per stratum.
 
 Overlap.  Each block is split into ``parts`` contiguous row ranges; a stratum is trained part by part and a part is sent on
-a side stream as soon as its last step is enqueued, while the next part trains — with 2 parts the transfer of one half
-hides behind the compute of the other.
+a side stream as soon as its last step is enqueued, while the next part trains; an incoming part is waited for right before
+its first step of the next stratum.  With 2 parts every transfer (one half of a block) runs beside the compute of a half.
 """
 import math
 
@@ -49,7 +49,8 @@ class RotatingBprmf:
         self.I_in = torch.zeros(self.cap, self.D, device=device)           # landing buffer for the next block
         from .hip_ops import side_stream
         self.comm_stream = side_stream(device) if device.type == "cuda" else None
-        self._pending = []                                                  # (work handles, event) of parts in flight
+        self._incoming = {}      # part -> event: that part of the NEXT block has landed in I_in
+        self._ready = {}         # part -> event still to be waited for before the held block's part is touched
 
     # ------------------------------------------------------------------ layout helpers
     def block_rows(self, block):
@@ -120,21 +121,30 @@ class RotatingBprmf:
                     w.wait()                                              # comm stream waits for the transfer
                 ev = torch.cuda.Event()
                 ev.record(self.comm_stream)
-            self._pending.append(ev)
+            self._incoming[part] = ev
         else:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
     def _finish_rotation(self):
-        """all parts of the next block have landed: make it the held block"""
+        """every part of the held block has been handed on and every part of the next one is on its way: the landing buffer
+        becomes the held block.  Nothing is waited for here — a part is waited for right before it is first touched
+        (`_await_part`), so the transfer of a stratum's LAST part hides behind the next stratum's first part."""
         if self.world == 1:
             return
-        if self.comm_stream is not None:
-            for ev in self._pending:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-        self._pending = []
+        self._drain()                                   # parts of the outgoing block nobody waited for (no steps on them)
         self.I, self.I_in = self.I_in, self.I
         self.held = (self.held + 1) % self.world
+        self._ready, self._incoming = self._incoming, {}
+
+    def _await_part(self, part):
+        ev = self._ready.pop(part, None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def _drain(self):
+        for part in list(self._ready):
+            self._await_part(part)
 
     # ------------------------------------------------------------------ training
     def run_subepoch(self, u, p, n, steps_per_part, batch, lr):
@@ -173,11 +183,13 @@ class RotatingBprmf:
         for per_part in counts:
             for k, st in enumerate(per_part):
                 if st > 0:
+                    self._await_part(k)                 # the held block's part k has landed (it came in during the last stratum)
                     self.local.run(handle, seg, lr, losses[first:first + st])
                     first += st
                 seg += 1
                 self._send_part(k)
             self._finish_rotation()
+        self._drain()                                   # leave with the held block complete
         return losses
 
     def global_losses(self, local_losses):
