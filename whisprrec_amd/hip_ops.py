@@ -58,7 +58,9 @@ _WS = {}
 
 
 def workspace(device, tag):
-    key = (str(device), tag)
+    """scratch buffer per (device, tag, current stream): two streams never share scratch, whoever created them"""
+    sid = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    key = (str(device), tag, sid)
     if key not in _WS:
         _WS[key] = Workspace(device)
     return _WS[key]

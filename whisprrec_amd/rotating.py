@@ -29,6 +29,37 @@ import torch.distributed as dist
 from .sharded import n_local_rows
 
 
+class DistTransport:
+    """The collective side of the schedule over torch.distributed (backend nccl = RCCL on the GPUs, gloo in the CPU tests).
+    Kept behind this small interface so that tests can run several virtual ranks on ONE GPU (threads + in-process copies,
+    tests/test_hip_rotating_loopback.py) and exercise the stream / event ordering of the rotation for real."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def exchange(self, send_buf, dst, recv_buf, src):
+        """send_buf -> dst and recv_buf <- src (either may be None) as one grouped P2P batch; returns when the CURRENT
+        stream has the transfers ordered before whatever is enqueued next (no host wait on the GPU)"""
+        ops = []
+        if send_buf is not None:
+            ops.append(dist.P2POp(dist.isend, send_buf, dst, group=self.group))
+        if recv_buf is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_buf, src, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def all_gather(self, t):
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t.contiguous(), group=self.group)
+        return out
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
 def HipLocal(chunk=64):
     """local training of one stratum = the single-GPU pipelined run (hip_ops.PipelinedSgd)"""
     from . import hip_ops
@@ -36,9 +67,9 @@ def HipLocal(chunk=64):
 
 
 class RotatingBprmf:
-    def __init__(self, n_users, n_items, emb_size, device, parts=2, local=None, group=None):
-        self.group = group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+    def __init__(self, n_users, n_items, emb_size, device, parts=2, local=None, group=None, transport=None):
+        self.tx = transport if transport is not None else DistTransport(group)
+        self.rank, self.world = self.tx.rank, self.tx.world
         self.n_users, self.n_items, self.D = int(n_users), int(n_items), int(emb_size)
         self.device, self.parts = device, max(1, int(parts))
         self.local = local if local is not None else HipLocal()
@@ -79,14 +110,10 @@ class RotatingBprmf:
         capu = (self.n_users + G - 1) // G
         pu = torch.zeros(capu, D, device=self.device)
         pu[:self.U.shape[0]] = self.U
-        us = [torch.empty_like(pu) for _ in range(G)]
-        dist.all_gather(us, pu, group=self.group)
+        us = self.tx.all_gather(pu)
         U_full = torch.stack(us, dim=1).reshape(capu * G, D)[:self.n_users]
-        held = torch.tensor([self.held], device=self.device)
-        hs = [torch.empty_like(held) for _ in range(G)]
-        dist.all_gather(hs, held, group=self.group)
-        bs = [torch.empty_like(self.I) for _ in range(G)]
-        dist.all_gather(bs, self.I.contiguous(), group=self.group)
+        hs = self.tx.all_gather(torch.tensor([self.held], device=self.device))
+        bs = self.tx.all_gather(self.I)
         by_block = [None] * G
         for r in range(G):
             by_block[int(hs[r].item())] = bs[r]
@@ -103,28 +130,21 @@ class RotatingBprmf:
         nxt = (self.held + 1) % G
         lo2, hi2 = self.part_range(nxt, part)
         dst, src = (self.rank - 1) % G, (self.rank + 1) % G
-        send_buf, recv_buf = self.I[lo:hi], self.I_in[lo2:hi2]
-        ops = []
-        if hi > lo:
-            ops.append(dist.P2POp(dist.isend, send_buf, dst, group=self.group))
-        if hi2 > lo2:
-            ops.append(dist.P2POp(dist.irecv, recv_buf, src, group=self.group))
-        if not ops:
+        send_buf = self.I[lo:hi] if hi > lo else None
+        recv_buf = self.I_in[lo2:hi2] if hi2 > lo2 else None
+        if send_buf is None and recv_buf is None:
             return
         if self.comm_stream is not None:
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(self.device))          # the part's last step is enqueued
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(done)
-                works = dist.batch_isend_irecv(ops)
-                for w in works:
-                    w.wait()                                              # comm stream waits for the transfer
+                self.tx.exchange(send_buf, dst, recv_buf, src)            # comm stream ordered behind the transfer
                 ev = torch.cuda.Event()
                 ev.record(self.comm_stream)
             self._incoming[part] = ev
         else:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            self.tx.exchange(send_buf, dst, recv_buf, src)
 
     def _finish_rotation(self):
         """every part of the held block has been handed on and every part of the next one is on its way: the landing buffer
@@ -193,9 +213,7 @@ class RotatingBprmf:
         return losses
 
     def global_losses(self, local_losses):
-        out = local_losses.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
-        return out / self.world
+        return self.tx.all_reduce_sum(local_losses.clone()) / self.world
 
 
 def stratum_steps(n_interactions, world, batch):
