@@ -213,29 +213,40 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
     Row<NV> s;
 #pragma unroll
     for (int k = 0; k < NV; ++k) s.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t k = chunk_ptr[c];
+    // The chunk's column ids and values are fetched by the team's lanes in one go (2*T entries per trip, lane l takes
+    // entries l and l+T) and handed round with shuffles: one index round trip per 2*T non-zeros instead of one per four,
+    // and four row gathers in flight.  Accumulation order = CSR order, as in the sequential loop.
     const int64_t k1 = chunk_ptr[c + 1];
-    for (; k + 4 <= k1; k += 4) {
-        const float a0 = val[k], a1 = val[k + 1], a2 = val[k + 2], a3 = val[k + 3];
-        const Row<NV> x0 = load_row<T, NV, FULL>(X, col[k], D, lane);
-        const Row<NV> x1 = load_row<T, NV, FULL>(X, col[k + 1], D, lane);
-        const Row<NV> x2 = load_row<T, NV, FULL>(X, col[k + 2], D, lane);
-        const Row<NV> x3 = load_row<T, NV, FULL>(X, col[k + 3], D, lane);
+    for (int64_t base = chunk_ptr[c]; base < k1; base += 2 * T) {
+        const int cnt = (int)((k1 - base < 2 * T) ? (k1 - base) : 2 * T);
+        const int c_lo = (lane < cnt) ? col[base + lane] : 0, c_hi = (lane + T < cnt) ? col[base + T + lane] : 0;
+        const float a_lo = (lane < cnt) ? val[base + lane] : 0.f, a_hi = (lane + T < cnt) ? val[base + T + lane] : 0.f;
+        for (int j = 0; j < cnt; j += 4) {
+            int cj[4];
+            float aj[4];
+            Row<NV> x[4];
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {  // same order as the sequential loop: ((((s + a0 x0) + a1 x1) + a2 x2) + a3 x3)
-            s.v[q].x = fmaf(a3, x3.v[q].x, fmaf(a2, x2.v[q].x, fmaf(a1, x1.v[q].x, fmaf(a0, x0.v[q].x, s.v[q].x))));
-            s.v[q].y = fmaf(a3, x3.v[q].y, fmaf(a2, x2.v[q].y, fmaf(a1, x1.v[q].y, fmaf(a0, x0.v[q].y, s.v[q].y))));
-            s.v[q].z = fmaf(a3, x3.v[q].z, fmaf(a2, x2.v[q].z, fmaf(a1, x1.v[q].z, fmaf(a0, x0.v[q].z, s.v[q].z))));
-            s.v[q].w = fmaf(a3, x3.v[q].w, fmaf(a2, x2.v[q].w, fmaf(a1, x1.v[q].w, fmaf(a0, x0.v[q].w, s.v[q].w))));
-        }
-    }
-    for (; k < k1; ++k) {
-        const float a = val[k];
-        const Row<NV> x = load_row<T, NV, FULL>(X, col[k], D, lane);
+            for (int f = 0; f < 4; ++f) {   // entries past the chunk get value 0 and row 0: they add +0 in order
+                const int e = j + f;
+                const int src_lane = e < T ? e : e - T;
+                const int cl = __shfl(c_lo, src_lane, T), ch = __shfl(c_hi, src_lane, T);
+                const float al = __shfl(a_lo, src_lane, T), ah = __shfl(a_hi, src_lane, T);
+                cj[f] = e < T ? cl : ch;
+                aj[f] = e < cnt ? (e < T ? al : ah) : 0.f;
+                if (e >= cnt) cj[f] = -1;
+            }
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            s.v[q].x = fmaf(a, x.v[q].x, s.v[q].x); s.v[q].y = fmaf(a, x.v[q].y, s.v[q].y);
-            s.v[q].z = fmaf(a, x.v[q].z, s.v[q].z); s.v[q].w = fmaf(a, x.v[q].w, s.v[q].w);
+            for (int f = 0; f < 4; ++f)
+                if (cj[f] >= 0) x[f] = load_row<T, NV, FULL>(X, cj[f], D, lane);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (cj[f] < 0) continue;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    s.v[q].x = fmaf(aj[f], x[f].v[q].x, s.v[q].x); s.v[q].y = fmaf(aj[f], x[f].v[q].y, s.v[q].y);
+                    s.v[q].z = fmaf(aj[f], x[f].v[q].z, s.v[q].z); s.v[q].w = fmaf(aj[f], x[f].v[q].w, s.v[q].w);
+                }
+            }
         }
     }
     if (multi) {
@@ -265,11 +276,23 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, cons
     const bool head = (c == 0 || chunk_row[c - 1] != row) && (c + 1 < n_chunks && chunk_row[c + 1] == row);
     if (!head) return;
     Row<NV> s = load_row<T, NV, FULL>(partials, c, D, lane);
-    for (int j = c + 1; j < n_chunks && chunk_row[j] == row; ++j) {
-        const Row<NV> x = load_row<T, NV, FULL>(partials, j, D, lane);
+    // a hub row has hundreds of chunks: eight partial rows in flight per trip, added in chunk order
+    constexpr int kFly = 8;
+    for (int j = c + 1; j < n_chunks && chunk_row[j] == row; j += kFly) {
+        Row<NV> x[kFly];
+        bool ok[kFly];
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            s.v[q].x += x.v[q].x; s.v[q].y += x.v[q].y; s.v[q].z += x.v[q].z; s.v[q].w += x.v[q].w;
+        for (int f = 0; f < kFly; ++f) ok[f] = j + f < n_chunks && chunk_row[j + f] == row;
+#pragma unroll
+        for (int f = 0; f < kFly; ++f)
+            if (ok[f]) x[f] = load_row<T, NV, FULL>(partials, j + f, D, lane);
+#pragma unroll
+        for (int f = 0; f < kFly; ++f) {
+            if (!ok[f]) continue;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                s.v[q].x += x[f].v[q].x; s.v[q].y += x[f].v[q].y; s.v[q].z += x[f].v[q].z; s.v[q].w += x[f].v[q].w;
+            }
         }
     }
     store_row<T, NV, FULL>(Y, row, D, lane, s);
