@@ -432,37 +432,47 @@ class PipelinedSgd:
         self.plan_stream = None
 
     def plan(self, U, segments, batch):
-        """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order"""
+        """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order.
+        Only the last segment may end with a short batch."""
         if self.plan_stream is None:
             self.plan_stream = side_stream(U.device)
         B = int(batch)
-        todo = []                                                           # (segment, first batch, n batches) in run order
-        segs = []
+        segs, first = [], 0
         for k, (rows, u, p, n) in enumerate(segments):
             nb = (u.numel() + B - 1) // B
-            segs.append({"tabs": self.ops.BprmfTables(U, rows) if nb else None, "u": u, "p": p, "n": n, "nb": nb})
-            todo += [(k, f, min(self.chunk, nb - f)) for f in range(0, nb, self.chunk)]
-        h = {"segs": segs, "B": B, "todo": todo, "at": 0, "tag": 0, "next": None}
+            if u.numel() % B != 0 and any(s[1].numel() for s in segments[k + 1:]):
+                raise ValueError("only the last segment may end with a short batch")
+            segs.append({"tabs": self.ops.BprmfTables(U, rows) if nb else None, "nb": nb, "first": first})
+            first += nb
+        live = [s for s in segments if s[1].numel()]
+        if len(live) == 1:
+            u_all, p_all, n_all = live[0][1:]
+        else:   # one batch sequence across the segments: plan chunks are cut by size, not at segment ends (a plan holds
+            # indices only; with short segments — 8-GPU strata of a few steps — that is 5x fewer plans and host syncs)
+            u_all, p_all, n_all = (torch.cat([s[j] for s in live]) for j in (1, 2, 3))
+        n_items = max([s[0].shape[0] for s in live] or [1])
+        h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
+             "at": 0, "tag": 0, "next": None, "cur": None}
         self.plan_stream.wait_stream(torch.cuda.current_stream(U.device))   # the index tensors are ready
         self._prefetch(h)
         return h
 
     def _prefetch(self, h):
-        """enqueue the plan of the next chunk on the side stream"""
-        if h["at"] >= len(h["todo"]):
+        """enqueue the plan of the next chunk of batches on the side stream"""
+        if h["at"] >= h["nb"]:
             h["next"] = None
             return
-        k, first, c = h["todo"][h["at"]]
-        h["at"] += 1
-        sg, B = h["segs"][k], h["B"]
-        lo, hi = first * B, min(sg["u"].numel(), (first + c) * B)
+        first, B = h["at"], h["B"]
+        c = min(self.chunk, h["nb"] - first)
+        h["at"] += c
+        lo, hi = first * B, min(h["u"].numel(), (first + c) * B)
         with torch.cuda.stream(self.plan_stream):
-            plan = self.ops.BatchPlan(sg["u"][lo:hi], sg["p"][lo:hi], sg["n"][lo:hi], B, sg["tabs"].U.shape[0],
-                                      sg["tabs"].I.shape[0], validate=False, ws_tag="rot%d" % h["tag"])
+            plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
+                                      validate=False, ws_tag="rot%d" % h["tag"])
             ready = torch.cuda.Event()
             ready.record(self.plan_stream)
         h["tag"] ^= 1
-        h["next"] = (k, first, plan, ready)
+        h["next"] = (first, plan, ready)
 
     def run(self, handle, seg, lr, losses):
         """all steps of segment `seg` (segments must be run in order); losses: one slot per step"""
@@ -471,16 +481,23 @@ class PipelinedSgd:
         if sg["nb"] == 0:
             return
         main = torch.cuda.current_stream(sg["tabs"].U.device)
-        pos = 0
-        while pos < sg["nb"]:
-            k, first, plan, ready = h["next"]
-            assert k == seg and first == pos, "segments must be run in order"
-            main.wait_event(ready)
-            plan.validate()                                                 # flags came back with the hot-run counts: no sync
-            plan.record_stream(main)
-            sg["tabs"].run_sgd(plan, 0, plan.n_batches, lr, losses=losses[pos:pos + plan.n_batches])
-            pos += plan.n_batches
-            self._prefetch(h)                                               # steps are queued: build the next plan beside them
+        pos, end = sg["first"], sg["first"] + sg["nb"]
+        while pos < end:
+            cur = h["cur"]
+            if cur is None or pos >= cur[0] + cur[1].n_batches:
+                cur = h["next"]
+                assert cur is not None and cur[0] == pos, "segments must be run in order"
+                main.wait_event(cur[2])
+                cur[1].validate()                                           # flags came back with the hot-run counts: no sync
+                cur[1].record_stream(main)
+                h["cur"], h["next"] = cur, None
+            base, plan, _ = cur
+            c = min(end, base + plan.n_batches) - pos
+            off = pos - sg["first"]
+            sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[off:off + c])
+            pos += c
+            if h["next"] is None:
+                self._prefetch(h)                                           # steps are queued: build the next plan beside them
 
 
 class LazyOptimizerState:
