@@ -18,8 +18,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# dmabuf IPC only on this pool's hosts: RCCL / cross-process tensor sharing fails without it (set before HIP initialises)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
