@@ -459,3 +459,28 @@ def test_full_size_step_c2(ops, dev):
     tabs2 = ops.BprmfTables(Ud.clone(), Id.clone())
     tabs2.step_sgd(plan, 0, 0.05)
     assert torch.equal(tabs2.U, tabs.U) and torch.equal(tabs2.I, tabs.I)
+
+
+@pytest.mark.parametrize("hot", [False, True])
+def test_long_runs_with_and_without_hot_list(ops, dev, hot):
+    """rows with 33..2000 occurrences in one batch: with the plan's hot-run list (pieces + combine) and without it (a plan
+    built with hot=False, as LightGCN's backward does: the item phase must then walk the whole run itself)"""
+    rng = np.random.RandomState(77)
+    nU, nI, D, B = 500, 400, 64, 4096
+    U = (rng.standard_normal((nU, D)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) * 0.2).astype(np.float32)
+    u = rng.randint(0, nU, B); p = rng.randint(0, nI, B); n = rng.randint(0, nI, B)
+    p[:2000] = 7; n[2000:2040] = 9; p[2100:2133] = 11; u[:600] = 3          # runs of 2000+, 40+, 33+ and a hot user
+    tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+    plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, hot=hot)
+    assert (plan.hot is not None) == hot
+    loss = tabs.step_sgd(plan, 0, 0.2)
+    Uo, Io = U.copy(), I.copy()
+    lo = oracle.bprmf_step_sgd(Uo, Io, u, p, n, 0.2, 0.0)
+    assert abs(float(loss) - lo) / lo < TOL
+    assert rel_err(tabs.U.cpu().numpy(), Uo) < TOL and rel_err(tabs.I.cpu().numpy(), Io) < TOL
+    gU = torch.zeros(nU, D, device=dev); gI = torch.zeros(nI, D, device=dev)
+    tabs2 = ops.BprmfTables(T(U, dev), T(I, dev))
+    tabs2.grads(plan, 0, gU, gI)
+    rU, rI, _ = oracle.bpr_dense_grads(U, I, u, p, n)
+    assert rel_err(gU.cpu().numpy(), rU) < TOL and rel_err(gI.cpu().numpy(), rI) < TOL

@@ -351,7 +351,28 @@ __device__ __forceinline__ void item_hot_piece(int piece, int D, const int *__re
     }
 }
 
+// torch.optim.SGD on a finished item row (g' = g + l2 w ; w -= lr g'), or the gradient row itself for MODE != 0
 template <int T, int NV, bool FULL, int MODE>
+__device__ __forceinline__ void finish_item_row(float *__restrict__ I, float *__restrict__ gradI, int *__restrict__ stampI,
+                                                int step_id, int r, int D, int lane, float lr, float l2, const Row<NV> &ir,
+                                                const Row<NV> &g) {
+    if (MODE == 0) {
+        Row<NV> w;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            w.v[k].x = ir.v[k].x - lr * fmaf(l2, ir.v[k].x, g.v[k].x);
+            w.v[k].y = ir.v[k].y - lr * fmaf(l2, ir.v[k].y, g.v[k].y);
+            w.v[k].z = ir.v[k].z - lr * fmaf(l2, ir.v[k].z, g.v[k].z);
+            w.v[k].w = ir.v[k].w - lr * fmaf(l2, ir.v[k].w, g.v[k].w);
+        }
+        store_row<T, NV, FULL>(I, r, D, lane, w);
+    } else {
+        store_row<T, NV, FULL>(gradI, r, D, lane, g);
+    }
+    if (stampI != nullptr && lane == 0) stampI[r] = step_id;
+}
+
+template <int T, int NV, bool FULL, int MODE, bool PIECES>
 __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I, int D, const int *__restrict__ oc_item,
                                                             const int *__restrict__ oc_src, int B2,
                                                             const float *__restrict__ Z, float lr, float l2,
@@ -361,14 +382,18 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             const unsigned long long *__restrict__ hot_loss, int n_tiles,
                                                             const int *__restrict__ piece_q, const int *__restrict__ piece_len,
                                                             float *__restrict__ hotP) {
-    extern __shared__ float piece_rows[];   // [TEAMS][D], only when the launch carries hot pieces
-    if ((int)blockIdx.x >= n_tiles) {       // extra workgroups: one hot piece each (independent of the tiles' rows)
-        item_hot_piece<T, NV, FULL>((int)blockIdx.x - n_tiles, D, oc_src, Z, piece_q, piece_len, hotP, piece_rows);
-        return;
+    if constexpr (PIECES) {                 // this instantiation carries hot pieces as extra workgroups (one each; they are
+        extern __shared__ float piece_rows[];   // independent of the tiles' rows); the lean one keeps its 32 VGPRs
+        if ((int)blockIdx.x >= n_tiles) {
+            item_hot_piece<T, NV, FULL>((int)blockIdx.x - n_tiles, D, oc_src, Z, piece_q, piece_len, hotP, piece_rows);
+            return;
+        }
     }
     __shared__ float scratch[kBlock / 64];
     __shared__ int heads[kItemTile];
-    constexpr int kAhead = kHotRun + 1;       // a run that starts in the tile is in LDS up to the entry that proves it hot
+    // entries staged beyond the tile: with a hot-run list every run that starts in the tile is in LDS up to the entry that
+    // proves it hot; without one, eight (longer runs go on from the plan arrays)
+    constexpr int kAhead = PIECES ? kHotRun + 1 : 8;
     __shared__ int item_tile[kItemTile + kAhead];
     __shared__ int src_tile[kItemTile + kAhead];
     __shared__ int n_heads;
@@ -400,64 +425,82 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
     for (int h = threadIdx.x / T; h < nh; h += TEAMS) {
         const int j0 = heads[h];
         const int r = item_tile[j0];
-        // run length from the staged entries (entries past the batch are -1); runs longer than kHotRun are cut into pieces
-        // by the plan and summed by the piece workgroups + bprmf_item_hot_combine
-        int m = 2;
-        while (m <= kHotRun && item_tile[j0 + m] == r) ++m;
-        if (m > kHotRun) {
-            if (skip_hot) continue;
-            m = kHotRun;   // unreachable with a plan that lists its hot runs; never walk past the staged window
-        }
         {
             const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
             const int s0 = src_tile[j0], s1 = src_tile[j0 + 1];
             const Row<NV> z0 = load_row<T, NV, FULL>(Z, s0 >> 1, D, lane);
             const Row<NV> z1 = load_row<T, NV, FULL>(Z, s1 >> 1, D, lane);
-            Row<NV> g;
-            const float g0 = (s0 & 1) ? -1.0f : 1.0f, g1 = (s1 & 1) ? -1.0f : 1.0f;  // d/dI[p] = +cU, d/dI[n] = -cU
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                g.v[k].x = fmaf(g1, z1.v[k].x, fmaf(g0, z0.v[k].x, 0.f));
-                g.v[k].y = fmaf(g1, z1.v[k].y, fmaf(g0, z0.v[k].y, 0.f));
-                g.v[k].z = fmaf(g1, z1.v[k].z, fmaf(g0, z0.v[k].z, 0.f));
-                g.v[k].w = fmaf(g1, z1.v[k].w, fmaf(g0, z0.v[k].w, 0.f));
-            }
-            // third and later occurrences: four stashed rows in flight at a time, added in sorted order
-            for (int j = 2; j < m; j += 4) {
-                int src[4];
-                Row<NV> z[4];
-#pragma unroll
-                for (int f = 0; f < 4; ++f) src[f] = (j + f < m) ? src_tile[j0 + j + f] : -1;
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    if (src[f] >= 0) z[f] = load_row<T, NV, FULL>(Z, src[f] >> 1, D, lane);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    if (src[f] < 0) continue;
-                    const float sgn = (src[f] & 1) ? -1.0f : 1.0f;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        g.v[k].x = fmaf(sgn, z[f].v[k].x, g.v[k].x);
-                        g.v[k].y = fmaf(sgn, z[f].v[k].y, g.v[k].y);
-                        g.v[k].z = fmaf(sgn, z[f].v[k].z, g.v[k].z);
-                        g.v[k].w = fmaf(sgn, z[f].v[k].w, g.v[k].w);
-                    }
-                }
-            }
-            if (MODE == 0) {
-                Row<NV> w;
+            if constexpr (PIECES) {
+                // the plan lists this batch's hot runs (> kHotRun occurrences): they are skipped here, every other run is
+                // inside the staged window; the run length is read off LDS while the first loads fly
+                int m = 2;
+                while (m <= kHotRun && item_tile[j0 + m] == r) ++m;
+                if (m > kHotRun) continue;   // a hot run: its pieces and bprmf_item_hot_combine do the row
+                Row<NV> g;
+                const float g0 = (s0 & 1) ? -1.0f : 1.0f, g1 = (s1 & 1) ? -1.0f : 1.0f;  // d/dI[p] = +cU, d/dI[n] = -cU
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
-                    w.v[k].x = ir.v[k].x - lr * fmaf(l2, ir.v[k].x, g.v[k].x);
-                    w.v[k].y = ir.v[k].y - lr * fmaf(l2, ir.v[k].y, g.v[k].y);
-                    w.v[k].z = ir.v[k].z - lr * fmaf(l2, ir.v[k].z, g.v[k].z);
-                    w.v[k].w = ir.v[k].w - lr * fmaf(l2, ir.v[k].w, g.v[k].w);
+                    g.v[k].x = fmaf(g1, z1.v[k].x, fmaf(g0, z0.v[k].x, 0.f));
+                    g.v[k].y = fmaf(g1, z1.v[k].y, fmaf(g0, z0.v[k].y, 0.f));
+                    g.v[k].z = fmaf(g1, z1.v[k].z, fmaf(g0, z0.v[k].z, 0.f));
+                    g.v[k].w = fmaf(g1, z1.v[k].w, fmaf(g0, z0.v[k].w, 0.f));
                 }
-                store_row<T, NV, FULL>(I, r, D, lane, w);
+                // third and later occurrences: four stashed rows in flight at a time, added in sorted order
+                for (int j = 2; j < m; j += 4) {
+                    int src[4];
+                    Row<NV> z[4];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) src[f] = (j + f < m) ? src_tile[j0 + j + f] : -1;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        if (src[f] >= 0) z[f] = load_row<T, NV, FULL>(Z, src[f] >> 1, D, lane);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        if (src[f] < 0) continue;
+                        const float sgn = (src[f] & 1) ? -1.0f : 1.0f;
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) {
+                            g.v[k].x = fmaf(sgn, z[f].v[k].x, g.v[k].x);
+                            g.v[k].y = fmaf(sgn, z[f].v[k].y, g.v[k].y);
+                            g.v[k].z = fmaf(sgn, z[f].v[k].z, g.v[k].z);
+                            g.v[k].w = fmaf(sgn, z[f].v[k].w, g.v[k].w);
+                        }
+                    }
+                }
+                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g);
             } else {
-                store_row<T, NV, FULL>(gradI, r, D, lane, g);
+                // no hot-run list for this batch (none, or a plan built without one): walk the run to its end, whatever
+                // its length — from LDS inside the staged window, from the plan arrays beyond it
+                Row<NV> g;
+                const float g0 = (s0 & 1) ? -1.0f : 1.0f, g1 = (s1 & 1) ? -1.0f : 1.0f;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    g.v[k].x = fmaf(g1, z1.v[k].x, fmaf(g0, z0.v[k].x, 0.f));
+                    g.v[k].y = fmaf(g1, z1.v[k].y, fmaf(g0, z0.v[k].y, 0.f));
+                    g.v[k].z = fmaf(g1, z1.v[k].z, fmaf(g0, z0.v[k].z, 0.f));
+                    g.v[k].w = fmaf(g1, z1.v[k].w, fmaf(g0, z0.v[k].w, 0.f));
+                }
+                int j = j0 + 2;
+                for (;;) {
+                    const int q = tile0 + j;
+                    if (q >= B2) break;
+                    const bool in_lds = j < kItemTile + kAhead;
+                    const int it = in_lds ? item_tile[j] : oc_item[q];
+                    if (it != r) break;
+                    const int src = in_lds ? src_tile[j] : oc_src[q];
+                    const Row<NV> z = load_row<T, NV, FULL>(Z, src >> 1, D, lane);
+                    const float sgn = (src & 1) ? -1.0f : 1.0f;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        g.v[k].x = fmaf(sgn, z.v[k].x, g.v[k].x);
+                        g.v[k].y = fmaf(sgn, z.v[k].y, g.v[k].y);
+                        g.v[k].z = fmaf(sgn, z.v[k].z, g.v[k].z);
+                        g.v[k].w = fmaf(sgn, z.v[k].w, g.v[k].w);
+                    }
+                    ++j;
+                }
+                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g);
             }
-            if (stampI != nullptr && lane == 0) stampI[r] = step_id;
         }
     }
     if (blockIdx.x == 0 && loss_out != nullptr) {  // uniform per block: fold the user phase's partials
@@ -631,10 +674,18 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     // hot pieces ride along as extra workgroups of the same launch (they only read the stash and write hotP)
     const dim3 gridBP(gridB.x + (have_hot ? (unsigned)hot.item.n_pieces : 0u));
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
-    hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE>), gridBP, block, have_hot ? lds_rows : 0, stream, I, D, \
-                       oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials, (int)gridA.x,  \
-                       denom, loss_out, have_hot ? 1 : 0, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,            \
-                       hot.item.piece_q, hot.item.piece_len, w.hotP)
+    do {                                                                                                               \
+        if (have_hot)                                                                                                  \
+            hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE, true>), gridBP, block, lds_rows, stream, I, D,  \
+                               oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,        \
+                               (int)gridA.x, denom, loss_out, 1, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,      \
+                               hot.item.piece_q, hot.item.piece_len, w.hotP);                                          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE, false>), gridB, block, 0, stream, I, D,         \
+                               oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,        \
+                               (int)gridA.x, denom, loss_out, 0, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,      \
+                               nullptr, nullptr, nullptr);                                                             \
+    } while (0)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
     WR_LAUNCH_CHECK("bprmf_item_phase");
