@@ -17,6 +17,7 @@ Reference entry points exercised (paths relative to /root/reference):
   G4  src/models/general/LightGCN.py:54-175 (adjacency, forward, predict, grads)
   G5  src/models/sequential/SASRec.py:84,105-106 (item-embedding gather / scatter with padding_idx=0)
   G6  src/helpers/BaseRunner.py:50-92 (evaluate_method)
+  G8  src/helpers/BaseReader.py + src/utils/sample.py on data/ml-100k/ml-100k.inter: filtered ids, both split rules
   G7  src/models/general/SGL.py:67-79 + src/utils/augmentor.py:33-111 (graph views from Python's `random` stream),
       SGL.py:148-246 (three propagations, sum-BPR + EmbLoss + InfoNCE, grads), per view type ED / ND / RW
 """
@@ -440,9 +441,34 @@ def g7_sgl():
     save("g7_sgl", **out)
 
 
+def g8_reader():
+    """first 25,000 rows of ml-100k.inter (kept under the dataset name ml-100k so the rating rule applies) through
+    BaseReader under both --sample rules: the input columns and the three splits, in the reference's row order"""
+    src = os.path.join(REF, "data", "ml-100k", "ml-100k.inter")
+    with open(src) as f:
+        lines = f.readlines()[:25001]
+    raw = np.asarray([[int(float(x)) for x in ln.rstrip("\n").split("\t")] for ln in lines[1:]], dtype=np.int64)
+    out = {"in_user": raw[:, 0].astype(np.int32), "in_item": raw[:, 1].astype(np.int32), "in_rating": raw[:, 2].astype(np.int8),
+           "in_time": raw[:, 3]}
+    for rule in ("random", "loo"):
+        work = tempfile.mkdtemp(prefix="wr_golden_")
+        os.makedirs(os.path.join(work, "ml-100k"))
+        with open(os.path.join(work, "ml-100k", "ml-100k.inter"), "w") as f:
+            f.writelines(lines)
+        r = BaseReader(argparse.Namespace(sep="\t", path=work + "/", dataset="ml-100k", sample=rule))
+        out[rule + "_shape"] = np.asarray([r.n_users, r.n_items, len(r.all_df)], dtype=np.int64)
+        for ph in ("train", "dev", "test"):
+            df = r.data_df[ph]
+            out[f"{rule}_{ph}_user"] = df["user_id"].to_numpy().astype(np.int32)
+            out[f"{rule}_{ph}_item"] = df["item_id"].to_numpy().astype(np.int32)
+            out[f"{rule}_{ph}_time"] = df["timestamp"].to_numpy().astype(np.int64)
+        shutil.rmtree(work, ignore_errors=True)
+    save("g8_reader", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     torch.set_num_threads(4)
     for w in which:
         {"g1": g1_bprmf_step, "g2": g2_ml100k_curve, "g3": g3_sampler, "g4": g4_lightgcn,
-         "g5": g5_sasrec_emb, "g6": g6_eval, "g7": g7_sgl}[w]()
+         "g5": g5_sasrec_emb, "g6": g6_eval, "g7": g7_sgl, "g8": g8_reader}[w]()

@@ -5,6 +5,8 @@ Layout:
   abi.py       ctypes binding of the C-ABI (no CPU fallback: raises if the library is missing)
   hip_ops.py   tensor-level wrappers (PyTorch-ROCm owns memory and streams only)
   host.py      host-side mirror of the reference's BaseModel / GeneralModel / Dataset contract
+  reader.py    .inter reader with the reference's filters and split rules (reference src/helpers/BaseReader.py, utils/sample.py)
+  main.py      stand-alone launcher with the reference's command line (reference src/main.py)
   bprmf.py     BPRMF drop-in model (reference src/models/general/BPRMF.py)
   lightgcn.py  LightGCN drop-in model (reference src/models/general/LightGCN.py)
   sgl.py       SGL drop-in model: graph views on CSR + three propagations (reference src/models/general/SGL.py, utils/augmentor.py)
