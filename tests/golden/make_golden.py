@@ -462,6 +462,14 @@ def g8_reader():
             out[f"{rule}_{ph}_user"] = df["user_id"].to_numpy().astype(np.int32)
             out[f"{rule}_{ph}_item"] = df["item_id"].to_numpy().astype(np.int32)
             out[f"{rule}_{ph}_time"] = df["timestamp"].to_numpy().astype(np.int64)
+        if rule == "random":   # SeqReader on the same file: the position column of every split and two users' histories
+            from helpers.SeqReader import SeqReader
+            sr = SeqReader(argparse.Namespace(sep="\t", path=work + "/", dataset="ml-100k", sample=rule))
+            for ph in ("train", "dev", "test"):
+                out[f"seq_{ph}_position"] = sr.data_df[ph]["position"].to_numpy().astype(np.int32)
+                out[f"seq_{ph}_user"] = sr.data_df[ph]["user_id"].to_numpy().astype(np.int32)
+            for uid in (0, 5):
+                out[f"seq_his_{uid}"] = np.asarray(sr.user_his[uid], dtype=np.int64)
         shutil.rmtree(work, ignore_errors=True)
     save("g8_reader", **out)
 

@@ -69,7 +69,8 @@ def test_full_ml100k_matches_the_training_golden(tmp_path):
 @pytest.mark.parametrize("model,extra", [("BPRMF", ["--runner_name", "HipRunner", "--device_epoch_prep", "1", "--optimizer", "SGD", "--lr", "0.5"]),
                                          ("BPRMF", ["--lr", "1e-3", "--l2", "1e-6", "--lazy_optimizer", "1"]),
                                          ("LightGCN", ["--lr", "1e-3", "--gcn_layers", "2"]),
-                                         ("SGL", ["--lr", "1e-3", "--type", "ED"])])
+                                         ("SGL", ["--lr", "1e-3", "--type", "ED"]),
+                                         ("SASRec", ["--lr", "1e-3", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2"])])
 def test_standalone_launcher_trains_from_an_inter_file(g8, tmp_path, model, extra):
     """python -m whisprrec_amd.main: .inter file -> reader -> model -> runner.train (dev evaluation, best checkpoint) ->
     test metrics, with the reference's command line (src/main.py)"""
@@ -85,3 +86,15 @@ def test_standalone_launcher_trains_from_an_inter_file(g8, tmp_path, model, extr
     assert (tmp_path / "m.pt").exists()
     log = (tmp_path / "log.txt").read_text()
     assert "Best Iter(dev)" in log and "Epoch 3" in log
+
+
+def test_seq_reader_matches_reference(g8, tmp_path):
+    from whisprrec_amd.reader import SeqReader
+    path = _write_inter(g8, tmp_path)
+    r = SeqReader(argparse.Namespace(sep="\t", path=path, dataset="ml-100k", sample="random"))
+    for ph in ("train", "dev", "test"):
+        assert np.array_equal(r.data_df[ph]["position"], g8[f"seq_{ph}_position"]), ph
+        assert np.array_equal(r.data_df[ph]["user_id"], g8[f"seq_{ph}_user"]), ph
+    for uid in (0, 5):
+        assert np.array_equal(np.asarray(r.user_his[uid], dtype=np.int64), g8[f"seq_his_{uid}"])
+    assert r.corpus().user_his is r.user_his

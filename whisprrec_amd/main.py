@@ -16,10 +16,10 @@ import sys
 import numpy as np
 import torch
 
-from . import bprmf, lightgcn, reader, runner, sgl
+from . import bprmf, lightgcn, reader, runner, sasrec, sgl
 
-MODELS = {"BPRMF": bprmf.BPRMF, "LightGCN": lightgcn.LightGCN, "SGL": sgl.SGL}
-READERS = {"BaseReader": reader.BaseReader}
+MODELS = {"BPRMF": bprmf.BPRMF, "LightGCN": lightgcn.LightGCN, "SGL": sgl.SGL, "SASRec": sasrec.SASRec}
+READERS = {"BaseReader": reader.BaseReader, "SeqReader": reader.SeqReader}
 RUNNERS = {"BaseRunner": runner.BaseRunner, "HipRunner": runner.HipRunner}
 
 

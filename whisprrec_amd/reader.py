@@ -139,3 +139,38 @@ class BaseReader:
 
     def corpus(self):
         return Corpus(self.n_users, self.n_items, self.data_df, self.train_clicked_set, self.residual_clicked_set)
+
+
+class SeqReader(BaseReader):
+    """reference src/helpers/SeqReader.py: every interaction's position in its user's time-ordered history (stable sort by
+    user, then timestamp) and ``user_his`` = user -> [(item, time), ...]; the splits gain a ``position`` column.  The
+    reference attaches it with a left merge on (user, item, timestamp): a split row whose key occurs k times in the file
+    becomes k rows — reproduced."""
+
+    def __init__(self, args):
+        super().__init__(args)
+        users, items, times = self.all_df["user_id"], self.all_df["item_id"], self.all_df["timestamp"]
+        order = np.lexsort((np.arange(users.size), times, users))          # mergesort by (user_id, timestamp): stable
+        su, si, st = users[order], items[order], times[order]
+        starts = np.flatnonzero(np.r_[True, su[1:] != su[:-1]]) if su.size else np.zeros(0, np.int64)
+        pos = np.arange(su.size) - np.repeat(starts, np.diff(np.r_[starts, su.size]))
+        self.user_his = {}
+        for a, b, t in zip(su.tolist(), si.tolist(), st.tolist()):
+            self.user_his.setdefault(a, []).append((b, t))
+        by_key = {}
+        for a, b, t, q in zip(su.tolist(), si.tolist(), st.tolist(), pos.tolist()):
+            by_key.setdefault((a, b, t), []).append(q)
+        for key in ("train", "dev", "test"):
+            df = self.data_df[key]
+            rows, positions = [], []
+            for r, k in enumerate(zip(df["user_id"].tolist(), df["item_id"].tolist(), df["timestamp"].tolist())):
+                for q in by_key[k]:
+                    rows.append(r); positions.append(q)
+            rows = np.asarray(rows, np.int64)
+            self.data_df[key] = {c: v[rows] for c, v in df.items()}
+            self.data_df[key]["position"] = np.asarray(positions, np.int64)
+
+    def corpus(self):
+        c = super().corpus()
+        c.user_his = self.user_his
+        return c

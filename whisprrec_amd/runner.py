@@ -175,12 +175,22 @@ class BaseRunner(object):
         items = np.asarray(dataset.data["item_id"])
         scores, targets = [], []
         with torch.no_grad():
-            for lo in range(0, len(users), self.eval_batch_size):
-                ub = torch.from_numpy(users[lo:lo + self.eval_batch_size]).to(model.device)
-                pb = torch.from_numpy(items[lo:lo + self.eval_batch_size]).to(model.device)
-                s = model.full_predict({"user_id": ub, "pos_item": pb})
-                targets.append(s[torch.arange(len(pb), device=s.device), pb])
-                scores.append(s)
+            if "position" in dataset.data:   # sequential models: the batch needs the history fields the Dataset collates
+                dl = DataLoader(dataset, batch_size=self.eval_batch_size, shuffle=False, num_workers=0,
+                                collate_fn=dataset.collate_batch)
+                for batch in dl:
+                    batch = {k: (v.to(model.device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+                    s = model.full_predict(batch)
+                    pb = batch["pos_item"]
+                    targets.append(s[torch.arange(len(pb), device=s.device), pb])
+                    scores.append(s)
+            else:
+                for lo in range(0, len(users), self.eval_batch_size):
+                    ub = torch.from_numpy(users[lo:lo + self.eval_batch_size]).to(model.device)
+                    pb = torch.from_numpy(items[lo:lo + self.eval_batch_size]).to(model.device)
+                    s = model.full_predict({"user_id": ub, "pos_item": pb})
+                    targets.append(s[torch.arange(len(pb), device=s.device), pb])
+                    scores.append(s)
         target = torch.cat(targets).cpu().numpy()
         score = torch.cat(scores).cpu().numpy()
         if model.test_all:
