@@ -50,7 +50,7 @@ def bprmf_case(name, nU, nI, D, B, NB, opt="SGD", l2=0.0, zipf=0.0, lazy=False):
         st = hip_ops.LazyOptimizerState(tabs, opt, 1e-3 if opt == "Adam" else 0.05, l2)
         for k in range(NB):                                   # first pass: rows reach their steady-state replay lengths
             st.step(plan, k)
-        t = ev_time(lambda k: st.step(plan, k), NB)
+        t = ev_time(lambda k: st.run(plan, 0, NB), 1) / NB        # native multi-batch loop
         t_flush = ev_time(lambda k: st.flush(), 1)
         name += " [exact lazy rows; flush of all rows after %d steps: %.0f us]" % (2 * NB, t_flush * 1e6)
     elif opt == "SGD" and l2 == 0.0:

@@ -82,3 +82,32 @@ def test_lazy_adam_consts_table_grows():
         st.step(plan, k)
     st.flush()
     assert st.n_consts == 2 * n0 and torch.isfinite(U).all()
+
+
+@pytest.mark.parametrize("name,l2,zipf", [("Adam", 0.0, False), ("Adam", 1e-3, True), ("SGD", 1e-2, True)])
+def test_native_multi_batch_loop_equals_per_batch_calls(name, l2, zipf):
+    """wr_bprmf_run_adam_lazy / wr_bprmf_run_sgd_lazy: same bits as calling step() batch by batch (short last batch, hot rows)"""
+    nU, nI, D, B, steps, lr = 3000, 2500, 64, 256, 9, 1e-2
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    U = torch.randn(nU, D, generator=g, device=dev) * 0.1; I = torch.randn(nI, D, generator=g, device=dev) * 0.1
+    rng = np.random.RandomState(5)
+    N = steps * B - 100                                  # the last batch is short
+    u = rng.randint(0, nU, N)
+    p = np.minimum((rng.pareto(1.0, N) * 3).astype(np.int64), nI - 1) if zipf else rng.randint(0, nI, N)
+    n = rng.randint(1, nI, N)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    plan = hip_ops.BatchPlan(t(u), t(p), t(n), B, nU, nI)
+    outs = []
+    for native in (False, True):
+        Ua, Ia = U.clone(), I.clone()
+        st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ua, Ia), name, lr, l2)
+        if native:
+            l1 = st.run(plan, 0, 4); l2_ = st.run(plan, 4, steps - 4)
+            losses = torch.cat([l1, l2_])
+        else:
+            losses = torch.stack([st.step(plan, k).clone() for k in range(steps)])
+        st.flush()
+        outs.append((losses, Ua, Ia))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

@@ -86,6 +86,20 @@ class FusedOptimizer:
         return loss
 
     @torch.no_grad()
+    def run_batches(self, tabs, plan, first, count, losses):
+        """`count` consecutive step_batch calls; the lazy optimizers issue them from native code"""
+        if self._use_lazy(tabs, plan.batch_size):
+            if self.lazy_state is None:
+                self.lazy_state = hip_ops.LazyOptimizerState(tabs, self.name, self.lr, self.l2, self.betas, self.eps)
+            elif self.lazy_state.tabs.U.data_ptr() != tabs.U.data_ptr() or self.lazy_state.tabs.I.data_ptr() != tabs.I.data_ptr():
+                raise RuntimeError("the embedding tables were re-allocated after optimizer steps had been taken")
+            self.adam_step += count
+            return self.lazy_state.run(plan, first, count, losses)
+        for k in range(count):
+            self.step_batch(tabs, plan, first + k, loss_out=losses[k])
+        return losses
+
+    @torch.no_grad()
     def step(self):
         m = self.model
         if m._pending is None:
@@ -264,8 +278,7 @@ def make_bprmf(general_model_cls):
                         if opt is not None and opt.adam_step > 0 and opt.name == optimizer:
                             raise ValueError("lr / l2 changed after optimizer steps had been taken")
                         opt = self.optimizer = FusedOptimizer(self, optimizer, lr, l2, getattr(opt, "lazy", -1))
-                    for k in range(c):
-                        opt.step_batch(tabs, plan, k, loss_out=losses[done + k])
+                    opt.run_batches(tabs, plan, 0, c, losses[done:done + c])
                 else:
                     raise ValueError("train_epoch supports SGD and Adam; use BaseRunner.fit for %r" % optimizer)
                 done += c

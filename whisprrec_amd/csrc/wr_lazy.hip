@@ -269,4 +269,83 @@ int32_t wr_sgd_catchup_all(float *tab, int32_t *last_step, int64_t n_rows, int32
     return WR_OK;
 }
 
+static inline wr_hot_runs hot_at_batch(const wr_hot_runs *hot, int64_t b) {
+    wr_hot_runs h = *hot;
+    h.piece_q += b * hot->cap_pieces; h.piece_len += b * hot->cap_pieces;
+    h.run_q += b * hot->cap_runs; h.run_first += b * hot->cap_runs; h.run_np += b * hot->cap_runs;
+    h.u_piece_q += b * hot->cap_u_pieces; h.u_piece_len += b * hot->cap_u_pieces;
+    h.u_run_q += b * hot->cap_u_runs; h.u_run_first += b * hot->cap_u_runs; h.u_run_np += b * hot->cap_u_runs;
+    h.counts_host += 4 * b;
+    return h;
+}
+
+// The per-batch sequence  catch-up rows -> gradient kernels -> apply rows  for n_batches consecutive batches of a plan, issued
+// from native code: at the reference's default batch size (2,048) the GPU work of a step is ~47 us and a Python loop around
+// the five calls costs more than that.
+int32_t wr_bprmf_run_adam_lazy(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
+                               float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, float *grad_u,
+                               float *grad_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0, const int32_t *tu,
+                               const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
+                               int64_t n_triplets, int64_t batch_size, int64_t first_batch, int64_t n_batches,
+                               int64_t adam_step0, const float *consts, int64_t n_consts, float l2, float beta1, float beta2,
+                               float eps, float *loss_out, const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes,
+                               void *stream) {
+    WR_REQUIRE(n_triplets > 0 && batch_size > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(adam_step0 >= 1 && adam_step0 + n_batches <= n_consts, WR_E_RANGE,
+               "adam steps [%lld,%lld) outside the consts table (%lld entries)", (long long)adam_step0,
+               (long long)(adam_step0 + n_batches), (long long)n_consts);
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t b = first_batch + k, off = b * batch_size;
+        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
+        const int64_t t = adam_step0 + k;
+        int32_t rc;
+        wr_hot_runs hb;
+        if (hot != nullptr) hb = hot_at_batch(hot, b);
+        if ((rc = wr_adam_rows_lazy(user_tab, m_u, v_u, last_u, n_users, D, tu + off, Bk, nullptr, t, consts, n_consts, l2, beta1,
+                                    beta2, eps, stream)) != WR_OK) return rc;
+        if ((rc = wr_adam_rows_lazy(item_tab, m_i, v_i, last_i, n_items, D, oc_item + 2 * off, 2 * Bk, nullptr, t, consts,
+                                    n_consts, l2, beta1, beta2, eps, stream)) != WR_OK) return rc;
+        if ((rc = wr_bprmf_grads(user_tab, n_users, item_tab, n_items, D, tu + off, tp + off, tn + off, oc_item + 2 * off,
+                                 oc_src + 2 * off, Bk, grad_u, grad_i, stamp_u, stamp_i, step_id0 + (int32_t)k,
+                                 loss_out ? loss_out + k : nullptr, hot ? &hb : nullptr, workspace, workspace_bytes,
+                                 stream)) != WR_OK) return rc;
+        if ((rc = wr_adam_rows_lazy(user_tab, m_u, v_u, last_u, n_users, D, tu + off, Bk, grad_u, t, consts, n_consts, l2, beta1,
+                                    beta2, eps, stream)) != WR_OK) return rc;
+        if ((rc = wr_adam_rows_lazy(item_tab, m_i, v_i, last_i, n_items, D, oc_item + 2 * off, 2 * Bk, grad_i, t, consts,
+                                    n_consts, l2, beta1, beta2, eps, stream)) != WR_OK) return rc;
+    }
+    return WR_OK;
+}
+
+int32_t wr_bprmf_run_sgd_lazy(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, int32_t *last_u,
+                              int32_t *last_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0, const int32_t *tu,
+                              const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
+                              int64_t n_triplets, int64_t batch_size, int64_t first_batch, int64_t n_batches, int64_t step0,
+                              float lr, float l2, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                              int64_t workspace_bytes, void *stream) {
+    WR_REQUIRE(n_triplets > 0 && batch_size > 0 && first_batch >= 0 && n_batches >= 0 && step0 >= 1, WR_E_SHAPE,
+               "bad batch range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t b = first_batch + k, off = b * batch_size;
+        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
+        int32_t rc;
+        wr_hot_runs hb;
+        if (hot != nullptr) hb = hot_at_batch(hot, b);
+        if ((rc = wr_sgd_rows_lazy(user_tab, last_u, n_users, D, tu + off, Bk, step0 + k, lr, l2, stream)) != WR_OK) return rc;
+        if ((rc = wr_sgd_rows_lazy(item_tab, last_i, n_items, D, oc_item + 2 * off, 2 * Bk, step0 + k, lr, l2, stream)) != WR_OK)
+            return rc;
+        if ((rc = wr_bprmf_step_sgd(user_tab, n_users, item_tab, n_items, D, tu + off, tp + off, tn + off, oc_item + 2 * off,
+                                    oc_src + 2 * off, Bk, lr, l2, stamp_u, stamp_i, step_id0 + (int32_t)k,
+                                    loss_out ? loss_out + k : nullptr, hot ? &hb : nullptr, workspace, workspace_bytes,
+                                    stream)) != WR_OK) return rc;
+    }
+    return WR_OK;
+}
+
 }  // extern "C"

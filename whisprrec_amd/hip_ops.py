@@ -553,6 +553,36 @@ class LazyOptimizerState:
                                          _stream()), "wr_sgd_rows_lazy")
         return tabs.step_sgd(plan, k, self.lr, self.l2, loss_out=loss_out, decay_untouched=False)
 
+    def run(self, plan, first, count, losses=None):
+        """`count` consecutive optimizer steps on batches [first, first + count) of the plan, issued from native code
+        (wr_bprmf_run_adam_lazy / wr_bprmf_run_sgd_lazy); same result as `count` calls of step()"""
+        tabs, L = self.tabs, abi.lib()
+        if losses is None:
+            losses = torch.empty(count, dtype=torch.float32, device=tabs.dev)
+        ws = tabs._ws(plan.batch_size)
+        su, si = tabs._stamps()
+        hot = plan.hot_struct()
+        hp = ctypes.addressof(hot) if hot is not None else None
+        t0 = self.t + 1
+        if self.name == "Adam":
+            while self.t + count >= self.n_consts:
+                self._grow_consts(2 * self.n_consts)
+            abi.check(L.wr_bprmf_run_adam_lazy(
+                _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.m_u), _p(self.v_u), _p(self.m_i),
+                _p(self.v_i), _p(self.last_u), _p(self.last_i), _p(self.g_u), _p(self.g_i), _p(su), _p(si), tabs.step_id + 1,
+                _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets, plan.batch_size,
+                first, count, t0, _p(self.consts), self.n_consts, self.l2, self.betas[0], self.betas[1], self.eps,
+                _p(losses), hp, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_adam_lazy")
+        else:
+            abi.check(L.wr_bprmf_run_sgd_lazy(
+                _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.last_u), _p(self.last_i), _p(su),
+                _p(si), tabs.step_id + 1, _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src),
+                plan.n_triplets, plan.batch_size, first, count, t0, self.lr, self.l2, _p(losses), hp, _p(ws), ws.numel(),
+                _stream()), "wr_bprmf_run_sgd_lazy")
+        self.t += count
+        tabs.step_id += count
+        return losses
+
     def flush(self):
         """every row up to the current step: the tables are then what the dense optimizer would hold"""
         if self.flushed_at == self.t:
