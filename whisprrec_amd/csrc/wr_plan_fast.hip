@@ -45,8 +45,11 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
     L.nb = (n + B - 1) / B;
     L.user_bits = bits_for_rows(n_users);
     L.item_bits = bits_for_rows(n_items);
-    L.nbk = B > 131072 ? 1024 : 256;
-    const unsigned bbits = L.nbk == 1024 ? 10 : 8;
+#ifndef WR_PLAN_BBITS
+#define WR_PLAN_BBITS 8
+#endif
+    const unsigned bbits = B > 131072 ? 10 : WR_PLAN_BBITS;
+    L.nbk = 1 << bbits;
     L.shift_u = L.user_bits > bbits ? L.user_bits - bbits : 0;
     L.shift_i = L.item_bits > bbits ? L.item_bits - bbits : 0;
     const int64_t cu = 2 * ((B + L.nbk - 1) / L.nbk) + 64;
