@@ -278,7 +278,12 @@ def main():
                     "step_algorithmic_bytes": bytes_step, "step_achieved_GBs": bytes_step * K / dt / 1e9,
                     "step_frac": bytes_step * K / dt / 1e9 / HBM_PEAK_GBS,
                     "uniq_users_per_step": uniq_u, "uniq_items_per_step": uniq_i,
-                    "single_occurrence_items_per_step": single_i}
+                    "single_occurrence_items_per_step": single_i,
+                    # the read-only variant SURVEY 8d asks for beside the read+write figure: every unique row read once +
+                    # the indices, over the dominant kernel's time, against the same 8 TB/s
+                    "read_only_algorithmic_bytes_per_launch": row * (uniq_u + uniq_i) + 12 * B,
+                    "read_only_GBs": (row * (uniq_u + uniq_i) + 12 * B) / t_user / 1e9,
+                    "read_only_frac": (row * (uniq_u + uniq_i) + 12 * B) / t_user / 1e9 / HBM_PEAK_GBS}
 
     if roofline is not None:
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
