@@ -418,6 +418,21 @@ def adam_dense(tab, exp_avg, exp_avg_sq, grad, adam_step, lr, l2=0.0, beta1=0.9,
               "wr_adam_dense")
 
 
+def _join_views(ts):
+    """concatenation of 1-D tensors; free when they are adjacent views of the same storage"""
+    if len(ts) == 1:
+        return ts[0]
+    a = ts[0]
+    adjacent, end = a.is_contiguous(), a.storage_offset() + a.numel()
+    for b in ts[1:]:
+        adjacent = adjacent and b.is_contiguous() and b.dtype == a.dtype and \
+            b.untyped_storage().data_ptr() == a.untyped_storage().data_ptr() and b.storage_offset() == end
+        end += b.numel()
+    if adjacent:
+        return torch.as_strided(a, (end - a.storage_offset(),), (1,), a.storage_offset())
+    return torch.cat(ts)
+
+
 class PipelinedSgd:
     """Plain-SGD training over pre-ordered triplets with the plan build off the critical path.  The work is a list of
     segments (item table view + indices; one segment for a whole epoch on one GPU, one per part of the held block in the
@@ -445,11 +460,10 @@ class PipelinedSgd:
             segs.append({"tabs": self.ops.BprmfTables(U, rows) if nb else None, "nb": nb, "first": first})
             first += nb
         live = [s for s in segments if s[1].numel()]
-        if len(live) == 1:
-            u_all, p_all, n_all = live[0][1:]
-        else:   # one batch sequence across the segments: plan chunks are cut by size, not at segment ends (a plan holds
-            # indices only; with short segments — 8-GPU strata of a few steps — that is 5x fewer plans and host syncs)
-            u_all, p_all, n_all = (torch.cat([s[j] for s in live]) for j in (1, 2, 3))
+        # one batch sequence across the segments: plan chunks are cut by size, not at segment ends (a plan holds indices
+        # only; with short segments — 8-GPU strata of a few steps — that is 5x fewer plans and host syncs).  Segments that
+        # are consecutive views of one array (the usual case: slices of an epoch's arrays) are joined without a copy.
+        u_all, p_all, n_all = (_join_views([s[j] for s in live]) for j in (1, 2, 3))
         n_items = max([s[0].shape[0] for s in live] or [1])
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None}
@@ -485,6 +499,8 @@ class PipelinedSgd:
         while pos < end:
             cur = h["cur"]
             if cur is None or pos >= cur[0] + cur[1].n_batches:
+                if h["next"] is None:
+                    self._prefetch(h)
                 cur = h["next"]
                 assert cur is not None and cur[0] == pos, "segments must be run in order"
                 main.wait_event(cur[2])
@@ -496,8 +512,12 @@ class PipelinedSgd:
             off = pos - sg["first"]
             sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[off:off + c])
             pos += c
-            if h["next"] is None:
-                self._prefetch(h)                                           # steps are queued: build the next plan beside them
+            # Build the next plan beside the queued steps.  The build blocks the HOST for its duration (two small read-backs),
+            # so it is started only once enough steps of the current plan are queued to keep the GPU busy meanwhile — with
+            # short segments (a dozen steps) right after a plan change the queue would otherwise run dry.
+            queued = pos - base
+            if h["next"] is None and (queued >= min(32, (plan.n_batches + 1) // 2) or queued >= plan.n_batches):
+                self._prefetch(h)
 
 
 class LazyOptimizerState:

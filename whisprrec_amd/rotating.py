@@ -174,12 +174,12 @@ class RotatingBprmf:
         steps_per_part.  Returns the per-step local losses (mean over ranks = loss of the global batch)."""
         return self.run_strata([(u, p, n, steps_per_part)], batch, lr)
 
-    def run_strata(self, strata, batch, lr):
+    def run_strata(self, strata, batch, lr, part_relative=False):
         """Consecutive strata [(u, p, n, steps_per_part), ...] (see run_subepoch), one block rotation after each.  All
         their batches go to the local runner as ONE list of segments, so its plan pipeline runs across the rotations: the
         first plan of stratum r+1 is built while stratum r trains (a plan needs the indices only, not the block that is
         still on its way).  With 8 GPUs a stratum is a few dozen steps: an exposed plan build per stratum would cost a
-        third of it."""
+        third of it.  part_relative=True: p and n already count rows from the start of their part (no offset pass)."""
         B = int(batch)
         # the global batch is the union of the G local batches: its mean loss has 1/(G*B) coefficients.  The local kernels
         # use 1/B, and the local batches touch disjoint rows, so dividing the learning rate by G gives the same update.
@@ -193,7 +193,8 @@ class RotatingBprmf:
             for k, st in enumerate(per_part):
                 lo, hi = self.part_range(held, k)
                 sl = slice(first * B, min(u.numel(), (first + st) * B))
-                segments.append((table[lo:hi], u[sl], p[sl] - lo, n[sl] - lo))
+                segments.append((table[lo:hi], u[sl], p[sl] if part_relative else p[sl] - lo,
+                                 n[sl] if part_relative else n[sl] - lo))
                 first += st
             counts.append(per_part)
             held = (held + 1) % self.world
@@ -239,32 +240,39 @@ def bench_main(args, rank, world, local_rank):
     g = torch.Generator(device=dev)
     g.manual_seed(3407 * 7919 + rank)
 
-    def synth_subepoch(held, steps):
-        """uniform users of this rank, positives and negatives uniform inside each part of block `held` (item 0, which the
-        reference never draws as a negative, is local row 0 of block 0); batches of part 0 first, then part 1, ..."""
-        per_part = [steps // model.parts + (1 if k < steps % model.parts else 0) for k in range(model.parts)]
-        us, ps, ns = [], [], []
-        for k, st in enumerate(per_part):
-            lo, hi = model.part_range(held, k)
-            cnt = st * B
-            us.append(torch.randint(0, model.U.shape[0], (cnt,), generator=g, device=dev, dtype=torch.int32))
-            ps.append(torch.randint(lo, max(hi, lo + 1), (cnt,), generator=g, device=dev, dtype=torch.int32))
-            first = lo + 1 if (held == 0 and lo == 0) else lo
-            ns.append(torch.randint(first, max(hi, first + 1), (cnt,), generator=g, device=dev, dtype=torch.int32))
-        return torch.cat(us), torch.cat(ps), torch.cat(ns), per_part
-
     def make_schedule(count, held0):
-        """(held block, data) for every stratum of `count` steps — generated BEFORE the timed region, like the N=1 bench"""
-        sched, done, held = [], 0, held0
+        """strata of `count` steps in all, generated BEFORE the timed region like the N=1 bench: uniform users of this rank,
+        positives and negatives uniform inside each part of the held block (item 0, which the reference never draws as a
+        negative, is local row 0 of block 0), batches of part 0 first, then part 1, ...; indices count rows from the start
+        of their part.  One flat array per column for the whole schedule: the strata and parts are views of it."""
+        layout, done, held = [], 0, held0
         while done < count:
             st = min(S, count - done)
-            sched.append(synth_subepoch(held, st))
+            per_part = [st // model.parts + (1 if k < st % model.parts else 0) for k in range(model.parts)]
+            layout.append((held, per_part))
             held = (held + 1) % world
             done += st
+        total = count * B
+        u_all = torch.randint(0, model.U.shape[0], (total,), generator=g, device=dev, dtype=torch.int32)
+        p_all = torch.empty(total, dtype=torch.int32, device=dev)
+        n_all = torch.empty(total, dtype=torch.int32, device=dev)
+        sched, at = [], 0
+        for blk, per_part in layout:
+            first = at
+            for k, stp in enumerate(per_part):
+                lo, hi = model.part_range(blk, k)
+                cnt = stp * B
+                if cnt:
+                    width = max(hi - lo, 1)
+                    p_all[at:at + cnt] = torch.randint(0, width, (cnt,), generator=g, device=dev, dtype=torch.int32)
+                    n0 = 1 if (blk == 0 and lo == 0 and width > 1) else 0
+                    n_all[at:at + cnt] = torch.randint(n0, width, (cnt,), generator=g, device=dev, dtype=torch.int32)
+                at += cnt
+            sched.append((u_all[first:at], p_all[first:at], n_all[first:at], per_part))
         return sched, held
 
     def run_schedule(sched):
-        return model.run_strata(sched, B, args.lr)
+        return model.run_strata(sched, B, args.lr, part_relative=True)
 
     warm, held_after = make_schedule(W, model.held)
     timed, _ = make_schedule(K, held_after)
