@@ -219,20 +219,28 @@ int32_t wr_sgd_rows_lazy(float *tab, int32_t *last_step, int64_t n_rows, int32_t
 int32_t wr_sgd_catchup_all(float *tab, int32_t *last_step, int64_t n_rows, int32_t D, int64_t step, float lr, float l2,
                            void *stream);
 
+/* One Adam step on one batch with the update fused into the step kernels (the fused SGD step's two kernels with Adam where
+ * they apply SGD): the team that finishes a row reads its two moment rows, takes torch.optim.Adam's step (adam_elem, the
+ * arithmetic of wr_adam_dense) and writes weights and moments back; no gradient table.  Every row of the batch must be up to
+ * date through adam_step - 1 (wr_adam_rows_lazy with grad = NULL first); last_* [n_rows] become adam_step for those rows. */
+int32_t wr_bprmf_step_adam(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
+                           float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
+                           const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src, int64_t B,
+                           int64_t adam_step, float lr, float l2, float beta1, float beta2, float eps, float *loss_out,
+                           const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes, void *stream);
 /* n_batches consecutive optimizer steps over batches [first_batch, first_batch + n_batches) of a plan, issued from native
  * code (the inner loop of BaseRunner.fit, BaseRunner.py:196-199, with the lazy optimizers): per batch
- *   Adam:  wr_adam_rows_lazy(NULL) on U and I rows -> wr_bprmf_grads -> wr_adam_rows_lazy(grad) on U and I rows;
+ *   Adam:  wr_adam_rows_lazy(NULL) on U and I rows -> wr_bprmf_step_adam (gradients + Adam on the rows it finishes);
  *   SGD + weight decay:  wr_sgd_rows_lazy on U and I rows -> wr_bprmf_step_sgd.
  * adam_step0 / step0 = optimizer step number of the first batch (1-based); step_id0 = stamp id of the first batch;
- * loss_out[k] receives batch k's loss (may be NULL); grad_u / grad_i [n_rows, D] scratch (only the batch's rows are used). */
+ * loss_out[k] receives batch k's loss (may be NULL). */
 int32_t wr_bprmf_run_adam_lazy(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
-                               float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, float *grad_u,
-                               float *grad_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0, const int32_t *tu,
+                               float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
                                const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
                                int64_t n_triplets, int64_t batch_size, int64_t first_batch, int64_t n_batches,
-                               int64_t adam_step0, const float *consts, int64_t n_consts, float l2, float beta1, float beta2,
-                               float eps, float *loss_out, const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes,
-                               void *stream);
+                               int64_t adam_step0, float lr, const float *consts, int64_t n_consts, float l2, float beta1,
+                               float beta2, float eps, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                               int64_t workspace_bytes, void *stream);
 int32_t wr_bprmf_run_sgd_lazy(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, int32_t *last_u,
                               int32_t *last_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0, const int32_t *tu,
                               const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,

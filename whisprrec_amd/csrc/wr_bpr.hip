@@ -69,8 +69,38 @@ __global__ __launch_bounds__(kBlock) void finish_loss_kernel(const float *__rest
     if (threadIdx.x == 0) out[0] = s / denom;
 }
 
+// ----------------------------------------------------------------------------------------------- MODE 3: Adam in place
+// torch.optim.Adam applied where MODE 0 applies SGD: the team that finishes a row holds its weights and its complete
+// gradient in registers, so it reads the row's two moments, takes the step (adam_elem: the dense kernel's arithmetic) and
+// writes weights and moments back — no gradient table, no second pass over the rows.  The rows must be up to date through
+// step t-1 (wr_adam_rows_lazy with grad = NULL before this launch); last[row] becomes t.
+struct AdamArgs {
+    float *mU, *vU, *mI, *vI;
+    int *lastU, *lastI;
+    float step_size, inv_bc2_sqrt, b1, b2, eps, l2;
+    int t;
+};
+
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ void adam_finish_row(float *__restrict__ W, float *__restrict__ M, float *__restrict__ V,
+                                                int *__restrict__ last, int row, int D, int lane, const Row<NV> &w0,
+                                                const Row<NV> &g, const AdamArgs &a) {
+    Row<NV> m = load_row<T, NV, FULL>(M, row, D, lane), v = load_row<T, NV, FULL>(V, row, D, lane), w = w0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        adam_elem(w.v[k].x, m.v[k].x, v.v[k].x, g.v[k].x, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+        adam_elem(w.v[k].y, m.v[k].y, v.v[k].y, g.v[k].y, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+        adam_elem(w.v[k].z, m.v[k].z, v.v[k].z, g.v[k].z, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+        adam_elem(w.v[k].w, m.v[k].w, v.v[k].w, g.v[k].w, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+    }
+    store_row<T, NV, FULL>(W, row, D, lane, w);
+    store_row<T, NV, FULL>(M, row, D, lane, m);
+    store_row<T, NV, FULL>(V, row, D, lane, v);
+    if (lane == 0) last[row] = a.t;
+}
+
 // ----------------------------------------------------------------------------------------------- user phase
-// MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.
+// MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.  MODE 3: Adam apply in place.
 // MODE 2 (row-sharded step): user rows applied in place, item gradients emitted (the item "table" is the buffer of
 // rows received from their owners and gradI the buffer of gradient rows sent back).
 // Everything one triplet contributes, given the three rows in registers: loss term, coefficient, user-row gradient,
@@ -79,7 +109,7 @@ template <int T, int NV, bool FULL, int MODE>
 __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &pr, const Row<NV> &nr, int praw, int nraw, int t,
                                              float *I, float *__restrict__ gradI, float *__restrict__ Z,
                                              int *__restrict__ stampI, int step_id, int D, int lane, float lr, float l2,
-                                             float denom, Row<NV> &g, float &terms) {
+                                             float denom, Row<NV> &g, float &terms, const AdamArgs &ad) {
     const int p = praw & 0x7fffffff, n = nraw & 0x7fffffff;
     const bool p_shared = praw < 0, n_shared = nraw < 0;   // bit 31: the item row has other occurrences in this batch
     const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
@@ -98,6 +128,17 @@ __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &p
     }
     // An item row that occurs once in the batch is read by this team only: finish it here
     // (gradient = +z for the positive, -z for the negative), no stash, no item-phase work.
+    if (MODE == 3) {
+        if (!p_shared) adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, p, D, lane, pr, z, ad);
+        if (!n_shared) {
+            Row<NV> zn;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) zn.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
+            adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, n, D, lane, nr, zn, ad);
+        }
+        if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
+        return;
+    }
     if (!p_shared) {
         Row<NV> w;
 #pragma unroll
@@ -137,7 +178,11 @@ __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &p
 template <int T, int NV, bool FULL, int MODE>
 __device__ __forceinline__ void finish_user_row(float *__restrict__ U, float *__restrict__ gradU, int *__restrict__ stampU,
                                                 int step_id, int u, int D, int lane, float lr, float l2, const Row<NV> &ur,
-                                                const Row<NV> &g) {
+                                                const Row<NV> &g, const AdamArgs &ad) {
+    if (MODE == 3) {
+        adam_finish_row<T, NV, FULL>(U, ad.mU, ad.vU, ad.lastU, u, D, lane, ur, g, ad);
+        return;
+    }
     if (MODE != 1) {
         Row<NV> w;
 #pragma unroll
@@ -163,7 +208,7 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
                                                             float *__restrict__ Z, float *__restrict__ partials,
                                                             float *__restrict__ gradU, int *__restrict__ stampU,
                                                             float *__restrict__ gradI, int *__restrict__ stampI,
-                                                            int step_id, float denom) {
+                                                            int step_id, float denom, AdamArgs ad) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
@@ -209,7 +254,7 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
         bool more;
         do {
             triplet_body<T, NV, FULL, MODE>(ur[s], pr, nr, praw, nraw, t, I, gradI, Z, stampI, step_id, D, lane, lr, l2, denom, g,
-                                            term_acc);
+                                            term_acc, ad);
             ++t;
             more = (t < B) && (tu[t] == u);
             if (more) {  // next triplet of this user (nothing is kept live across the body: 8 waves per SIMD, no spill)
@@ -219,7 +264,7 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
                 nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
             }
         } while (more);
-        finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur[s], g);
+        finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur[s], g, ad);
     }
     if (lane != 0) term_acc = 0.f;  // every lane of a team holds the same terms: count them once
     const float sum = block_sum(term_acc, scratch);
@@ -237,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_hot_pieces(const float *__r
                                                                  float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
                                                                  float denom, const int *__restrict__ piece_q,
                                                                  const int *__restrict__ piece_len, float *__restrict__ hotPU,
-                                                                 unsigned long long *__restrict__ hot_loss) {
+                                                                 unsigned long long *__restrict__ hot_loss, AdamArgs ad) {
     extern __shared__ float rows[];  // [TEAMS][D]
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
@@ -254,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_hot_pieces(const float *__r
         const int praw = tp[t], nraw = tn[t];
         const Row<NV> pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
         const Row<NV> nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
-        triplet_body<T, NV, FULL, MODE>(ur, pr, nr, praw, nraw, t, I, gradI, Z, stampI, step_id, D, lane, lr, l2, denom, g, terms);
+        triplet_body<T, NV, FULL, MODE>(ur, pr, nr, praw, nraw, t, I, gradI, Z, stampI, step_id, D, lane, lr, l2, denom, g, terms, ad);
     }
     store_row<T, NV, FULL>(rows, team, D, lane, g);
     __syncthreads();
@@ -277,7 +322,8 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_hot_combine(float *__restri
                                                                   const int *__restrict__ run_q, const int *__restrict__ run_first,
                                                                   const int *__restrict__ run_np, int n_runs,
                                                                   const float *__restrict__ hotPU, float lr, float l2,
-                                                                  float *__restrict__ gradU, int *__restrict__ stampU, int step_id) {
+                                                                  float *__restrict__ gradU, int *__restrict__ stampU, int step_id,
+                                                                  AdamArgs ad) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int h = blockIdx.x * TEAMS + threadIdx.x / T;
@@ -293,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_user_hot_combine(float *__restri
         }
     }
     const Row<NV> ur = load_row<T, NV, FULL>(U, u, D, lane);
-    finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur, g);
+    finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur, g, ad);
 }
 
 // ----------------------------------------------------------------------------------------------- item phase
@@ -355,7 +401,11 @@ __device__ __forceinline__ void item_hot_piece(int piece, int D, const int *__re
 template <int T, int NV, bool FULL, int MODE>
 __device__ __forceinline__ void finish_item_row(float *__restrict__ I, float *__restrict__ gradI, int *__restrict__ stampI,
                                                 int step_id, int r, int D, int lane, float lr, float l2, const Row<NV> &ir,
-                                                const Row<NV> &g) {
+                                                const Row<NV> &g, const AdamArgs &ad) {
+    if (MODE == 3) {
+        adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
+        return;
+    }
     if (MODE == 0) {
         Row<NV> w;
 #pragma unroll
@@ -381,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                                                             float loss_denom, float *__restrict__ loss_out, int skip_hot,
                                                             const unsigned long long *__restrict__ hot_loss, int n_tiles,
                                                             const int *__restrict__ piece_q, const int *__restrict__ piece_len,
-                                                            float *__restrict__ hotP) {
+                                                            float *__restrict__ hotP, AdamArgs ad) {
     if constexpr (PIECES) {                 // this instantiation carries hot pieces as extra workgroups (one each; they are
         extern __shared__ float piece_rows[];   // independent of the tiles' rows); the lean one keeps its 32 VGPRs
         if ((int)blockIdx.x >= n_tiles) {
@@ -467,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                         }
                     }
                 }
-                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g);
+                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             } else {
                 // no hot-run list for this batch (none, or a plan built without one): walk the run to its end, whatever
                 // its length — from LDS inside the staged window, from the plan arrays beyond it.  One stashed row at a
@@ -501,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                     }
                     ++j;
                 }
-                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g);
+                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             }
         }
     }
@@ -521,7 +571,8 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_hot_combine(float *__restri
                                                                   const int *__restrict__ run_q, const int *__restrict__ run_first,
                                                                   const int *__restrict__ run_np, int n_runs,
                                                                   const float *__restrict__ hotP, float lr, float l2,
-                                                                  float *__restrict__ gradI, int *__restrict__ stampI, int step_id) {
+                                                                  float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
+                                                                  AdamArgs ad) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int h = blockIdx.x * TEAMS + threadIdx.x / T;
@@ -535,6 +586,11 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_hot_combine(float *__restri
         for (int c = 0; c < NV; ++c) {
             g.v[c].x += x.v[c].x; g.v[c].y += x.v[c].y; g.v[c].z += x.v[c].z; g.v[c].w += x.v[c].w;
         }
+    }
+    if (MODE == 3) {
+        const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
+        adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
+        return;
     }
     if (MODE == 0) {
         const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
@@ -627,7 +683,7 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
                            void *workspace, hipStream_t stream, void *const *events = nullptr, float denom = 0.f,
                            HotBatch hot = HotBatch{{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
                                                    {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}},
-                           int64_t ws_batch = 0) {
+                           int64_t ws_batch = 0, AdamArgs ad = AdamArgs{}) {
     if (denom <= 0.f) denom = (float)B;  // single-device step: mean over this batch
     if (ws_batch <= 0) ws_batch = B;     // the workspace was sized for the plan's batch size (>= this batch)
     const StepWs w = carve_step_ws(workspace, ws_batch, D);
@@ -648,10 +704,10 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     do {                                                                                                                  \
         if (have_hot_u)                                                                                                   \
             hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, true>), gridA, block, 0, stream, U, I, D, tu, tp, \
-                               tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom);       \
+                               tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad);   \
         else                                                                                                              \
             hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, false>), gridA, block, 0, stream, U, I, D, tu,    \
-                               tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom);   \
+                               tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad); \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
@@ -663,10 +719,10 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     do {                                                                                                                 \
         hipLaunchKernelGGL((bprmf_user_hot_pieces<T_, NV_, FULL_, MODE>), dim3((unsigned)hot.user.n_pieces), block,        \
                            lds_rows, stream, U, I, D, tu, tp, tn, lr, l2, w.Z, w.partials, gradI, stamp_i, step_id, denom,  \
-                           hot.user.piece_q, hot.user.piece_len, w.hotPU, w.hot_loss);                                    \
+                           hot.user.piece_q, hot.user.piece_len, w.hotPU, w.hot_loss, ad);                                \
         hipLaunchKernelGGL((bprmf_user_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, U, D, tu,         \
                            hot.user.run_q, hot.user.run_first, hot.user.run_np, hot.user.n_runs, w.hotPU, lr, l2, gradU,   \
-                           stamp_u, step_id);                                                                            \
+                           stamp_u, step_id, ad);                                                                        \
     } while (0)
         WR_DISPATCH_D(D, WR_CALL_HOTU);
 #undef WR_CALL_HOTU
@@ -681,12 +737,12 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
             hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE, true>), gridBP, block, lds_rows, stream, I, D,  \
                                oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,        \
                                (int)gridA.x, denom, loss_out, 1, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,      \
-                               hot.item.piece_q, hot.item.piece_len, w.hotP);                                          \
+                               hot.item.piece_q, hot.item.piece_len, w.hotP, ad);                                      \
         else                                                                                                           \
             hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE, false>), gridB, block, 0, stream, I, D,         \
                                oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,        \
                                (int)gridA.x, denom, loss_out, 0, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,      \
-                               nullptr, nullptr, nullptr);                                                             \
+                               nullptr, nullptr, nullptr, ad);                                                         \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
@@ -697,7 +753,7 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     do {                                                                                                                \
         hipLaunchKernelGGL((bprmf_item_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, I, D, oc_item,  \
                            hot.item.run_q, hot.item.run_first, hot.item.run_np, hot.item.n_runs, w.hotP, lr, l2, gradI, \
-                           stamp_i, step_id);                                                                           \
+                           stamp_i, step_id, ad);                                                                       \
     } while (0)
         WR_DISPATCH_D(D, WR_CALL_HOT);
 #undef WR_CALL_HOT
@@ -820,6 +876,29 @@ int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item
     return launch_step<1>(const_cast<float *>(user_tab), const_cast<float *>(item_tab), D, tu, tp, tn, oc_item, oc_src, B,
                           0.f, 0.f, grad_u, grad_i, stamp_u, stamp_i, step_id, loss_out, workspace,
                           reinterpret_cast<hipStream_t>(stream_), nullptr, 0.f, hot_of(hot, 0));
+}
+
+int32_t wr_bprmf_step_adam(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
+                           float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
+                           const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src, int64_t B,
+                           int64_t adam_step, float lr, float l2, float beta1, float beta2, float eps, float *loss_out,
+                           const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_table(m_u, n_users, D, "m_u")) != WR_OK) return rc;
+    if ((rc = check_table(v_u, n_users, D, "v_u")) != WR_OK) return rc;
+    if ((rc = check_table(m_i, n_items, D, "m_i")) != WR_OK) return rc;
+    if ((rc = check_table(v_i, n_items, D, "v_i")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, B)) != WR_OK) return rc;
+    WR_REQUIRE(last_u != nullptr && last_i != nullptr, WR_E_NULL, "last_u / last_i is NULL");
+    WR_REQUIRE(adam_step >= 1 && adam_step < INT32_MAX, WR_E_RANGE, "adam_step must be >= 1");
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
+               "wr_bprmf_step_adam: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
+    AdamArgs ad{m_u, v_u, m_i, v_i, last_u, last_i, 0.f, 0.f, beta1, beta2, eps, l2, (int)adam_step};
+    adam_step_consts(adam_step, lr, beta1, beta2, &ad.step_size, &ad.inv_bc2_sqrt);
+    return launch_step<3>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, B, lr, l2, nullptr, nullptr, nullptr, nullptr, 0,
+                          loss_out, workspace, reinterpret_cast<hipStream_t>(stream_), nullptr, 0.f, hot_of(hot, 0), 0, ad);
 }
 
 int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,

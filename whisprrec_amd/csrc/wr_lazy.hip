@@ -279,17 +279,16 @@ static inline wr_hot_runs hot_at_batch(const wr_hot_runs *hot, int64_t b) {
     return h;
 }
 
-// The per-batch sequence  catch-up rows -> gradient kernels -> apply rows  for n_batches consecutive batches of a plan, issued
-// from native code: at the reference's default batch size (2,048) the GPU work of a step is ~47 us and a Python loop around
-// the five calls costs more than that.
+// The per-batch sequence  catch-up rows -> fused step (gradients + Adam on the finished rows)  for n_batches consecutive
+// batches of a plan, issued from native code: at the reference's default batch size (2,048) a Python loop around the calls
+// costs about as much as the GPU work of a step.
 int32_t wr_bprmf_run_adam_lazy(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
-                               float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, float *grad_u,
-                               float *grad_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0, const int32_t *tu,
+                               float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
                                const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
                                int64_t n_triplets, int64_t batch_size, int64_t first_batch, int64_t n_batches,
-                               int64_t adam_step0, const float *consts, int64_t n_consts, float l2, float beta1, float beta2,
-                               float eps, float *loss_out, const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes,
-                               void *stream) {
+                               int64_t adam_step0, float lr, const float *consts, int64_t n_consts, float l2, float beta1,
+                               float beta2, float eps, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                               int64_t workspace_bytes, void *stream) {
     WR_REQUIRE(n_triplets > 0 && batch_size > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
     const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
     WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
@@ -308,14 +307,10 @@ int32_t wr_bprmf_run_adam_lazy(float *user_tab, int64_t n_users, float *item_tab
                                     beta2, eps, stream)) != WR_OK) return rc;
         if ((rc = wr_adam_rows_lazy(item_tab, m_i, v_i, last_i, n_items, D, oc_item + 2 * off, 2 * Bk, nullptr, t, consts,
                                     n_consts, l2, beta1, beta2, eps, stream)) != WR_OK) return rc;
-        if ((rc = wr_bprmf_grads(user_tab, n_users, item_tab, n_items, D, tu + off, tp + off, tn + off, oc_item + 2 * off,
-                                 oc_src + 2 * off, Bk, grad_u, grad_i, stamp_u, stamp_i, step_id0 + (int32_t)k,
-                                 loss_out ? loss_out + k : nullptr, hot ? &hb : nullptr, workspace, workspace_bytes,
-                                 stream)) != WR_OK) return rc;
-        if ((rc = wr_adam_rows_lazy(user_tab, m_u, v_u, last_u, n_users, D, tu + off, Bk, grad_u, t, consts, n_consts, l2, beta1,
-                                    beta2, eps, stream)) != WR_OK) return rc;
-        if ((rc = wr_adam_rows_lazy(item_tab, m_i, v_i, last_i, n_items, D, oc_item + 2 * off, 2 * Bk, grad_i, t, consts,
-                                    n_consts, l2, beta1, beta2, eps, stream)) != WR_OK) return rc;
+        if ((rc = wr_bprmf_step_adam(user_tab, n_users, item_tab, n_items, D, m_u, v_u, m_i, v_i, last_u, last_i, tu + off,
+                                     tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk, t, lr, l2, beta1, beta2, eps,
+                                     loss_out ? loss_out + k : nullptr, hot ? &hb : nullptr, workspace, workspace_bytes,
+                                     stream)) != WR_OK) return rc;
     }
     return WR_OK;
 }

@@ -538,7 +538,6 @@ class LazyOptimizerState:
         if name == "Adam":
             z = torch.zeros_like
             self.m_u, self.v_u, self.m_i, self.v_i = z(tabs.U), z(tabs.U), z(tabs.I), z(tabs.I)
-            self.g_u, self.g_i = torch.empty_like(tabs.U), torch.empty_like(tabs.I)   # only the batch's rows are ever read
             self.consts = None
             self._grow_consts(4096)
 
@@ -563,10 +562,19 @@ class LazyOptimizerState:
                 self._grow_consts(2 * self.n_consts)
             self._adam_rows(tabs.U, self.m_u, self.v_u, self.last_u, tu, B, None)       # the batch's rows up to t-1
             self._adam_rows(tabs.I, self.m_i, self.v_i, self.last_i, oi, 2 * B, None)
-            loss, _ = tabs.grads(plan, k, self.g_u, self.g_i, loss_out=loss_out)
-            self._adam_rows(tabs.U, self.m_u, self.v_u, self.last_u, tu, B, self.g_u)   # step t on those rows
-            self._adam_rows(tabs.I, self.m_i, self.v_i, self.last_i, oi, 2 * B, self.g_i)
-            return loss
+            # gradients + Adam on the rows the step kernels finish (no gradient table)
+            if loss_out is None:
+                loss_out = torch.empty((), dtype=torch.float32, device=tabs.dev)
+            _, tp, tn, _, os_, _ = tabs._plan_ptrs(plan, k)
+            ws = tabs._ws(plan.batch_size)
+            hot = plan.hot_struct(k)
+            abi.check(abi.lib().wr_bprmf_step_adam(
+                _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.m_u), _p(self.v_u), _p(self.m_i),
+                _p(self.v_i), _p(self.last_u), _p(self.last_i), tu, tp, tn, oi, os_, B, self.t, self.lr, self.l2,
+                self.betas[0], self.betas[1], self.eps, _p(loss_out), ctypes.addressof(hot) if hot is not None else None,
+                _p(ws), ws.numel(), _stream()), "wr_bprmf_step_adam")
+            tabs.step_id += 1
+            return loss_out
         L = abi.lib()
         for tab, last, keys, n in ((tabs.U, self.last_u, tu, B), (tabs.I, self.last_i, oi, 2 * B)):
             abi.check(L.wr_sgd_rows_lazy(_p(tab), _p(last), tab.shape[0], tab.shape[1], keys, n, self.t, self.lr, self.l2,
@@ -589,9 +597,9 @@ class LazyOptimizerState:
                 self._grow_consts(2 * self.n_consts)
             abi.check(L.wr_bprmf_run_adam_lazy(
                 _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.m_u), _p(self.v_u), _p(self.m_i),
-                _p(self.v_i), _p(self.last_u), _p(self.last_i), _p(self.g_u), _p(self.g_i), _p(su), _p(si), tabs.step_id + 1,
+                _p(self.v_i), _p(self.last_u), _p(self.last_i),
                 _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets, plan.batch_size,
-                first, count, t0, _p(self.consts), self.n_consts, self.l2, self.betas[0], self.betas[1], self.eps,
+                first, count, t0, self.lr, _p(self.consts), self.n_consts, self.l2, self.betas[0], self.betas[1], self.eps,
                 _p(losses), hp, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_adam_lazy")
         else:
             abi.check(L.wr_bprmf_run_sgd_lazy(
