@@ -125,11 +125,32 @@ class BaseModel(nn.Module):
             return out
 
 
-def sample_negatives(user_ids, n_items, clicked_sets, num_neg=1, rng=np.random):
+def clicked_keys(clicked_sets, n_items):
+    """sorted int64 keys user * n_items + item of every (user, train item) pair: one vectorised membership test instead of a
+    Python ``in`` per row"""
+    parts = [np.fromiter(items, dtype=np.int64, count=len(items)) + int(uu) * int(n_items)
+             for uu, items in clicked_sets.items() if len(items)]
+    return np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.int64)
+
+
+def sample_negatives(user_ids, n_items, clicked_sets, num_neg=1, rng=np.random, keys=None):
     """One negative per training row, NumPy legacy global stream, bit-identical to the reference
     (src/models/BaseModel.py:167-177): a single vectorised randint(1, n_items) draw, then row by row scalar redraws
-    while the candidate is in the user's train set.  Item 0 is never drawn."""
+    while the candidate is in the user's train set.  Item 0 is never drawn.
+
+    With ``keys`` (clicked_keys) and one negative per row, the rows whose first draw is rejected are found in one vectorised
+    pass and only those are visited — in ascending order, with the same redraw loop, so the stream is consumed exactly as
+    the row-by-row loop consumes it."""
     neg = rng.randint(1, n_items, size=(len(user_ids), num_neg))
+    if keys is not None and num_neg == 1:
+        cand = np.asarray(user_ids, dtype=np.int64) * int(n_items) + neg[:, 0]
+        pos = np.searchsorted(keys, cand)
+        hit = (pos < keys.size) & (keys[np.minimum(pos, max(keys.size - 1, 0))] == cand) if keys.size else np.zeros(len(cand), bool)
+        for i in np.flatnonzero(hit).tolist():
+            clicked = clicked_sets[user_ids[i]]
+            while neg[i][0] in clicked:
+                neg[i][0] = rng.randint(1, n_items)
+        return neg.reshape(-1)
     for i, uu in enumerate(user_ids):
         clicked = clicked_sets[uu]
         for j in range(num_neg):
@@ -163,8 +184,11 @@ class GeneralModel(BaseModel):
             return {"user_id": self.data["user_id"][index], "pos_item": self.data["item_id"][index], "neg_items": neg}
 
         def actions_before_epoch(self):
+            if getattr(self, "_clicked_keys", None) is None:
+                self._clicked_keys = clicked_keys(self.corpus.train_clicked_set, self.corpus.n_items)
             self.data["neg_items"] = sample_negatives(self.data["user_id"], self.corpus.n_items,
-                                                      self.corpus.train_clicked_set, self.model.num_neg)
+                                                      self.corpus.train_clicked_set, self.model.num_neg,
+                                                      keys=self._clicked_keys)
 
 
 class SequentialModel(GeneralModel):
