@@ -235,6 +235,8 @@ if __name__ == "__main__":
     if "lazy" in which:
         bprmf_case("C2 SGD l2=1e-6", 1_000_000, 1_000_000, 64, 65536, 64, l2=1e-6, lazy=True)
         bprmf_case("C2 Adam", 1_000_000, 1_000_000, 64, 65536, 64, opt="Adam", lazy=True)
+        bprmf_case("C2 Adam l2=1e-6 (the reference README's command line)", 1_000_000, 1_000_000, 64, 65536, 64, opt="Adam", l2=1e-6, lazy=True)
+        bprmf_case("C2 Adam l2=1e-6 B=2048 (README command line, default batch)", 1_000_000, 1_000_000, 64, 2048, 256, opt="Adam", l2=1e-6, lazy=True)
         bprmf_case("C2 Adam Zipf(1.0) items", 1_000_000, 1_000_000, 64, 65536, 64, opt="Adam", zipf=1.0, lazy=True)
         bprmf_case("C2 Adam B=2048", 1_000_000, 1_000_000, 64, 2048, 256, opt="Adam", lazy=True)
     if "c4" in which:
