@@ -147,3 +147,33 @@ def test_chunked_spmm_matches_oracle_on_power_law_graph(D, L):
     assert not Y[5].any()
     Y3 = hip_ops.spmm_csr(t(rp), t(col), t(val), t(X))
     assert rel_err(Y3.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.gpu
+def test_hip_runner_batches_equal_reference_loop(g4):
+    """HipRunner.fit drives LightGCN with batches sliced from the epoch's device columns; with the reference streams
+    (--device_epoch_prep 0) they are the batches BaseRunner.fit's DataLoader collates sample by sample: same losses"""
+    import random
+    from whisprrec_amd import runner
+    from whisprrec_amd.lightgcn import LightGCN
+    dev = torch.device("cuda:0")
+    corpus = _corpus(g4)
+    rng = np.random.RandomState(0)
+    tu, ti = [], []
+    for uu, items in corpus.train_clicked_set.items():
+        if len(items) > 40:
+            continue                      # user 0 clicked every item: the reference's rejection sampler would never return
+        for it in items:
+            tu.append(uu); ti.append(it)
+    corpus.data_df["train"] = {"user_id": np.asarray(tu), "item_id": np.asarray(ti)}
+    out = []
+    for cls in (runner.BaseRunner, runner.HipRunner):
+        random.seed(1); np.random.seed(1); torch.manual_seed(1)
+        args = _args(dev, optimizer="Adam", lr=2e-3, l2=0.0, epoch=1, check_epoch=1, test_epoch=-1, early_stop=10, batch_size=64,
+                     eval_batch_size=256, num_workers=0, pin_memory=0, topk="10", metric="NDCG", device_epoch_prep=0)
+        m = LightGCN(args, corpus).to(dev)
+        ds = LightGCN.Dataset(m, corpus, "train")
+        r = cls(args)
+        out.append((r.fit(ds, epoch=1), r.fit(ds, epoch=2), m.user_embedding.weight.detach().clone()))
+    assert abs(out[0][0] - out[1][0]) < 1e-6 and abs(out[0][1] - out[1][1]) < 1e-6
+    assert torch.allclose(out[0][2], out[1][2], rtol=0, atol=1e-7)

@@ -269,22 +269,45 @@ def make_hip_runner(base_runner_cls):
             rank, _ = hip_ops.rank_eval(user_mat.contiguous(), item_mat.contiguous(), eu, et, cache[2], cache[3])
             return self.metrics_from_ranks(rank.cpu().numpy().astype(np.int64), topks, metrics)
 
+        def _epoch_columns(self, dataset, dev, epoch):
+            """the epoch's (user, positive, negative) columns in batch order on the device"""
+            if self.device_epoch_prep:
+                if hasattr(dataset.model, "graph_construction"):
+                    dataset.model.graph_construction()  # SGL draws its views in actions_before_epoch (SGL.py:258-262)
+                return self._device_epoch(dataset, dev, epoch)
+            dataset.actions_before_epoch()              # must happen before the shuffle draws, as in the reference
+            order = epoch_order(len(dataset), self.batch_size)
+            return [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64).reshape(len(dataset), -1)[:, 0][order]
+                    .to(dev) for k in ("user_id", "item_id", "neg_items")]
+
         def fit(self, dataset, epoch=-1):
             model = dataset.model
-            if not hasattr(model, "train_epoch") or self.optimizer_name not in ("SGD", "Adam"):
+            sequential = "position" in dataset.data     # history fields come from the Dataset's per-sample collate
+            if sequential or not hasattr(model, "user_num"):
                 return base_runner_cls.fit(self, dataset, epoch)
-            dev = model.user_embeddings.weight.device
+            dev = next(model.parameters()).device
             model.train()
-            if self.device_epoch_prep:
-                cols = self._device_epoch(dataset, dev, epoch)
-            else:
-                dataset.actions_before_epoch()          # must happen before the shuffle draws, as in the reference
-                order = epoch_order(len(dataset), self.batch_size)
-                cols = [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64)[order].to(dev)
-                        for k in ("user_id", "item_id", "neg_items")]
-            losses = model.train_epoch(cols[0], cols[1], cols[2], self.batch_size, self.learning_rate, float(self.l2),
-                                       self.optimizer_name)
-            return float(np.mean(losses.cpu().numpy()))  # one sync per epoch instead of one per batch (:200)
+            if hasattr(model, "train_epoch") and self.optimizer_name in ("SGD", "Adam"):
+                cols = self._epoch_columns(dataset, dev, epoch)
+                losses = model.train_epoch(cols[0], cols[1], cols[2], self.batch_size, self.learning_rate, float(self.l2),
+                                           self.optimizer_name)
+                return float(np.mean(losses.cpu().numpy()))  # one sync per epoch instead of one per batch (:200)
+            # any other triplet model (LightGCN, SGL, ...): the reference loop (BaseRunner.py:196-200) over batches that are
+            # slices of the epoch's device columns — the same batches the DataLoader would collate sample by sample in Python
+            if model.optimizer is None:
+                model.optimizer = self._build_optimizer(model)
+            cols = self._epoch_columns(dataset, dev, epoch)
+            n, B = cols[0].numel(), self.batch_size
+            losses = []
+            for lo in range(0, n, B):
+                batch = {"user_id": cols[0][lo:lo + B], "pos_item": cols[1][lo:lo + B], "neg_items": cols[2][lo:lo + B].unsqueeze(1),
+                         "batch_size": min(B, n - lo), "phase": "train"}
+                model.optimizer.zero_grad()
+                loss = model.predict(batch)
+                loss.backward()
+                model.optimizer.step()
+                losses.append(loss.detach().reshape(-1)[0])
+            return float(torch.stack(losses).mean().cpu())
 
     HipRunner.__qualname__ = "HipRunner"
     return HipRunner
