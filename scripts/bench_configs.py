@@ -161,6 +161,39 @@ def lightgcn_case():
          spmm_GBs=(nnz * 8 + 2 * (nU + nI) * 64 * 4) / t_spmm / 1e9, spmm_GFLOPs=2 * nnz * 64 / t_spmm / 1e9)
 
 
+def lightgcn_epoch_case():
+    """C3 end to end: one fit() epoch of LightGCN on the ml-1m-shaped synthetic graph (sampler + batching + steps) through the
+    reference loop (per-sample DataLoader collation) and through HipRunner (batches sliced from device columns)"""
+    import random
+    from whisprrec_amd import runner
+    from whisprrec_amd.lightgcn import LightGCN
+    rng = np.random.RandomState(0)
+    nU, nI, B = 6040, 3706, 2048
+    sets, tu, ti = {}, [], []
+    for uu in range(nU):
+        k = int(min(nI - 1, max(16, rng.pareto(1.2) * 40)))
+        items = np.unique(np.minimum((rng.pareto(0.8, k) * 30).astype(np.int64), nI - 1))
+        items = items[items < nI - 64]                       # leave every user some items to draw negatives from
+        sets[uu] = set(items.tolist()); tu += [uu] * len(items); ti += items.tolist()
+    frames = {"train": {"user_id": np.asarray(tu), "item_id": np.asarray(ti)}, "dev": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)},
+              "test": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)}}
+    corpus = host.Corpus(nU, nI, frames, sets, {u: set() for u in sets})
+    for name, cls, prep in (("BaseRunner (reference loop)", runner.BaseRunner, 0), ("HipRunner", runner.HipRunner, 0),
+                            ("HipRunner --device_epoch_prep 1", runner.HipRunner, 1)):
+        random.seed(1); np.random.seed(1); torch.manual_seed(1)
+        args = argparse.Namespace(device=dev, model_path="/tmp/x.pt", buffer=1, num_neg=1, test_all=1, embedding_size=64, gcn_layers=2,
+                                  reg_weight=1e-5, optimizer="Adam", lr=2e-3, l2=0.0, epoch=1, check_epoch=1, test_epoch=-1,
+                                  early_stop=10, batch_size=B, eval_batch_size=B, num_workers=0, pin_memory=0, topk="10",
+                                  metric="NDCG", device_epoch_prep=prep, random_seed=1)
+        m = LightGCN(args, corpus).to(dev)
+        ds = LightGCN.Dataset(m, corpus, "train")
+        r = cls(args)
+        r.fit(ds, epoch=1); torch.cuda.synchronize()
+        t0 = time.perf_counter(); loss = r.fit(ds, epoch=2); torch.cuda.synchronize(); t = time.perf_counter() - t0
+        emit(case="C3 LightGCN L=2 D=64 ml-1m-shaped, whole fit() epoch (%d train rows, B=2048, Adam)" % len(tu), runner=name,
+             epoch_s=t, triplets_per_s=len(tu) / t, loss=loss)
+
+
 def sasrec_embedding_case():
     nI, D, B, T = 3706, 64, 2048, 20
     g = torch.Generator(device=dev); g.manual_seed(1)
@@ -219,7 +252,7 @@ def eval_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c2big", "lazy", "c2epoch", "c2pcie", "c4", "c3", "c5", "c1", "eval"]
+    which = sys.argv[1:] or ["c2", "c2big", "lazy", "c2epoch", "c2pcie", "c4", "c3", "c3epoch", "c5", "c1", "eval"]
     if "c2" in which:
         for B, NB in ((2048, 256), (16384, 128), (65536, 64), (262144, 16)):
             bprmf_case("C2 BPRMF 1Mx1M D=64 SGD l2=0", 1_000_000, 1_000_000, 64, B, NB)
@@ -243,6 +276,8 @@ if __name__ == "__main__":
         bprmf_case("C4 shapes on ONE GPU: 10Mx10M D=128 SGD l2=0", 10_000_000, 10_000_000, 128, 65536, 32)
     if "c3" in which:
         lightgcn_case()
+    if "c3epoch" in which:
+        lightgcn_epoch_case()
     if "c5" in which:
         sasrec_embedding_case()
     if "c1" in which:

@@ -31,11 +31,52 @@ def format_metric(result_dict):
     return ",".join(parts)
 
 
+def _epoch_order_via_loader(n, batch_size):
+    dl = DataLoader(_Rows(n), batch_size=batch_size, shuffle=True, num_workers=0)
+    it = iter(dl)
+    sampler_iter = getattr(it, "_sampler_iter", None)
+    if sampler_iter is None:                                   # unknown DataLoader internals: fetch through the loader
+        return torch.cat([b for b in it])
+    return torch.tensor([i for batch in sampler_iter for i in batch], dtype=torch.int64)
+
+
+def _epoch_order_direct(n, batch_size):
+    """what the loader machinery does to the global torch RNG, without its per-index Python loops: the iterator draws a base
+    seed, RandomSampler draws its own seed and permutes with a private generator (torch/utils/data/{dataloader,sampler}.py)"""
+    torch.empty((), dtype=torch.int64).random_()               # _BaseDataLoaderIter: base seed
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g)
+
+
+_DIRECT_OK = None
+
+
 def epoch_order(n, batch_size, num_workers=0):
-    """The row order DataLoader(dataset, batch_size, shuffle=True) visits (reference BaseRunner.py:188-193), obtained
-    from the very same sampler machinery so that the global torch RNG is consumed identically."""
-    dl = DataLoader(torch.arange(n), batch_size=batch_size, shuffle=True, num_workers=0)
-    return torch.cat([b for b in dl])
+    """The row order DataLoader(dataset, batch_size, shuffle=True) visits (reference BaseRunner.py:188-193), with the
+    global torch RNG consumed identically.  The direct restatement is checked once per process against the loader
+    machinery itself (order AND resulting RNG state); if this torch version behaves differently the machinery is used."""
+    global _DIRECT_OK
+    if _DIRECT_OK is None:
+        state = torch.get_rng_state()
+        a = _epoch_order_via_loader(257, 32); sa = torch.get_rng_state()
+        torch.set_rng_state(state)
+        b = _epoch_order_direct(257, 32); sb = torch.get_rng_state()
+        torch.set_rng_state(state)
+        _DIRECT_OK = bool(torch.equal(a, b) and torch.equal(sa, sb))
+    return _epoch_order_direct(n, batch_size) if _DIRECT_OK else _epoch_order_via_loader(n, batch_size)
+
+
+class _Rows:
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return i
 
 
 class BaseRunner(object):
