@@ -18,8 +18,12 @@ def _setup(nU, nI, D, B, steps, seed, zipf=False):
     u = rng.randint(0, nU, steps * B)
     p = np.minimum((rng.pareto(1.0, steps * B) * 3).astype(np.int64), nI - 1) if zipf else rng.randint(0, nI, steps * B)
     n = rng.randint(1, nI, steps * B)
+    if zipf:
+        u[::5] = 7                        # a hot USER too (every batch: > 32 triplets of user 7): pieces + combine on that side
     t = lambda a: torch.from_numpy(a).to(dev)
     plan = hip_ops.BatchPlan(t(u), t(p), t(n), B, nU, nI)
+    if zipf:
+        assert plan.hot is not None and int(plan.hot["counts_host"].view(-1, 4)[:, 3].min()) >= 1
     return hip_ops, U, I, plan
 
 
