@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Bounded randomized parity sweep on the GPU (not part of the test suite): random table sizes, embedding sizes, batch
+sizes and id distributions; fused SGD step vs the oracle, lazy Adam vs the dense kernels (bitwise), two runs bitwise equal."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle
+from whisprrec_amd import hip_ops
+
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+t_end = time.time() + budget
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+n_cases = worst = 0
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+while time.time() < t_end:
+    D = int(rng.choice([4, 8, 16, 20, 32, 64, 64, 64, 96, 128, 256]))
+    nU, nI = int(rng.randint(3, 5000)), int(rng.randint(3, 5000))
+    B = int(rng.choice([1, 7, 64, 257, 1024, 2048, 5000]))
+    nb = int(rng.randint(1, 4))
+    N = nb * B - int(rng.randint(0, B))          # short last batch
+    N = max(N, 1)
+    kind = rng.randint(0, 4)
+    u = rng.randint(0, nU, N); p = rng.randint(0, nI, N); n = rng.randint(0, nI, N)
+    if kind == 1:
+        p = np.minimum((rng.pareto(1.0, N) * 2).astype(np.int64), nI - 1)
+    elif kind == 2:
+        u = np.minimum((rng.pareto(0.8, N) * 2).astype(np.int64), nU - 1); n[::3] = p[::3]
+    elif kind == 3:
+        u[: N // 2] = 0; p[: N // 3] = 1; n[N // 3: N // 2] = 1
+    U = (rng.standard_normal((nU, D)) * 0.3).astype(np.float32); I = (rng.standard_normal((nI, D)) * 0.3).astype(np.float32)
+    hot = bool(rng.randint(0, 2))
+    plan = hip_ops.BatchPlan(T(u), T(p), T(n), B, nU, nI, hot=hot)
+    nbat = plan.n_batches
+    # fused SGD vs oracle, and run-to-run bitwise
+    res = []
+    for rep in range(2):
+        tabs = hip_ops.BprmfTables(T(U), T(I))
+        losses = tabs.run_sgd(plan, 0, nbat, 0.1)
+        res.append((tabs.U.clone(), tabs.I.clone(), losses.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]), "not reproducible"
+    Uo, Io = U.copy(), I.copy()
+    for k in range(nbat):
+        sl = slice(k * B, min(N, (k + 1) * B))
+        lo = oracle.bprmf_step_sgd(Uo, Io, u[sl], p[sl], n[sl], 0.1, 0.0)
+        assert abs(float(res[0][2][k]) - lo) <= 2e-5 * max(abs(lo), 1e-3), ("loss", D, nU, nI, B, kind, k, float(res[0][2][k]), lo)
+    e = max(np.abs(res[0][0].cpu().numpy() - Uo).max() / max(np.abs(Uo).max(), 1e-30), np.abs(res[0][1].cpu().numpy() - Io).max() / max(np.abs(Io).max(), 1e-30))
+    assert e < 2e-5, ("tables", D, nU, nI, B, kind, e)
+    worst = max(worst, e)
+    # lazy Adam (fused step) vs dense Adam, bitwise
+    l2 = float(rng.choice([0.0, 1e-3]))
+    Ud, Id = T(U), T(I); td = hip_ops.BprmfTables(Ud, Id); z = torch.zeros_like
+    gU, gI, mU, vU, mI, vI = z(Ud), z(Id), z(Ud), z(Ud), z(Id), z(Id)
+    for k in range(nbat):
+        _, sid = td.grads(plan, k, gU, gI)
+        hip_ops.adam_dense(Ud, mU, vU, gU, k + 1, 1e-2, l2, stamp=td.stamp_u, step_id=sid)
+        hip_ops.adam_dense(Id, mI, vI, gI, k + 1, 1e-2, l2, stamp=td.stamp_i, step_id=sid)
+    Ul, Il = T(U), T(I); st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ul, Il), "Adam", 1e-2, l2)
+    st.run(plan, 0, nbat); st.flush()
+    assert torch.equal(Ul, Ud) and torch.equal(Il, Id) and torch.equal(st.m_u, mU) and torch.equal(st.v_i, vI), ("lazy adam", D, nU, nI, B, kind, l2, hot)
+    n_cases += 1
+print("stress_parity: %d random cases ok, worst table rel err %.2e" % (n_cases, worst))
