@@ -18,6 +18,8 @@ Reference entry points exercised (paths relative to /root/reference):
   G5  src/models/sequential/SASRec.py:84,105-106 (item-embedding gather / scatter with padding_idx=0)
   G6  src/helpers/BaseRunner.py:50-92 (evaluate_method)
   G8  src/helpers/BaseReader.py + src/utils/sample.py on data/ml-100k/ml-100k.inter: filtered ids, both split rules
+  G9  the whole src/main.py flow for BPRMF on the G8 subset: reader -> model -> BaseRunner.train (fit + evaluate every epoch)
+      -> test metrics, with the README's optimizer settings (Adam, --lr 1e-3 --l2 1e-6) and with SGD
   G7  src/models/general/SGL.py:67-79 + src/utils/augmentor.py:33-111 (graph views from Python's `random` stream),
       SGL.py:148-246 (three propagations, sum-BPR + EmbLoss + InfoNCE, grads), per view type ED / ND / RW
 """
@@ -474,9 +476,46 @@ def g8_reader():
     save("g8_reader", **out)
 
 
+def g9_end_to_end():
+    """per-epoch training loss, dev metrics and the final test metrics of the reference's own train loop (seed 3407)"""
+    src = os.path.join(REF, "data", "ml-100k", "ml-100k.inter")
+    with open(src) as f:
+        lines = f.readlines()[:25001]
+    out = {}
+    for tag, opt, lr, l2 in (("adam", "Adam", 1e-2, 1e-6), ("sgd", "SGD", 8.0, 0.0)):
+        work = tempfile.mkdtemp(prefix="wr_golden_")
+        os.makedirs(os.path.join(work, "ml-100k"))
+        with open(os.path.join(work, "ml-100k", "ml-100k.inter"), "w") as f:
+            f.writelines(lines)
+        ref_utils.init_seed(3407)
+        rargs = argparse.Namespace(sep="\t", path=work + "/", dataset="ml-100k", sample="random")
+        corpus = BaseReader(rargs)
+        args = _args(embedding_size=64, model_path=os.path.join(work, "m.pt"), epoch=6, check_epoch=1, test_epoch=-1, early_stop=10,
+                     lr=lr, l2=l2, batch_size=1024, eval_batch_size=2048, optimizer=opt, num_workers=0, pin_memory=0, topk="10,20",
+                     metric="NDCG, HR")
+        model = BPRMF(args, corpus).to(args.device)
+        data = {ph: BPRMF.Dataset(model, corpus, ph) for ph in ("train", "dev", "test")}
+        runner = BaseRunner(args)
+        losses, devs = [], []
+        for epoch in range(args.epoch):           # BaseRunner.train's loop body (BaseRunner.py:131-146), results captured
+            losses.append(runner.fit(data["train"], epoch=epoch + 1))
+            devs.append(runner.evaluate(data["dev"], runner.topk[:1], runner.metrics))
+        test = runner.evaluate(data["test"], runner.topk, runner.metrics)
+        out[tag + "_hp"] = np.asarray([lr, l2], dtype=np.float64)
+        out[tag + "_loss"] = np.asarray(losses, dtype=np.float64)
+        keys = sorted(devs[0])
+        out[tag + "_dev_keys"] = np.asarray(keys)
+        out[tag + "_dev"] = np.asarray([[d[k] for k in keys] for d in devs], dtype=np.float64)
+        tkeys = sorted(test)
+        out[tag + "_test_keys"] = np.asarray(tkeys)
+        out[tag + "_test"] = np.asarray([test[k] for k in tkeys], dtype=np.float64)
+        shutil.rmtree(work, ignore_errors=True)
+    save("g9_end_to_end", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     torch.set_num_threads(4)
     for w in which:
         {"g1": g1_bprmf_step, "g2": g2_ml100k_curve, "g3": g3_sampler, "g4": g4_lightgcn,
-         "g5": g5_sasrec_emb, "g6": g6_eval, "g7": g7_sgl, "g8": g8_reader}[w]()
+         "g5": g5_sasrec_emb, "g6": g6_eval, "g7": g7_sgl, "g8": g8_reader, "g9": g9_end_to_end}[w]()

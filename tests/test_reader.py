@@ -98,3 +98,39 @@ def test_seq_reader_matches_reference(g8, tmp_path):
     for uid in (0, 5):
         assert np.array_equal(np.asarray(r.user_his[uid], dtype=np.int64), g8[f"seq_his_{uid}"])
     assert r.corpus().user_his is r.user_his
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,runner_name", [("adam", "BaseRunner"), ("adam", "HipRunner"), ("sgd", "HipRunner")])
+def test_end_to_end_run_matches_the_reference_train_loop(g8, tmp_path, tag, runner_name):
+    """the same command line, the same seed, the same data file: per-epoch training loss, dev metrics after every epoch and
+    the final test metrics of the reference's BaseRunner.train on CPU (tests/golden/g9_end_to_end.npz) — reader, sampler and
+    shuffle streams, initial tables, six epochs of training (README optimizer settings for 'adam') and full-ranking evaluation."""
+    from whisprrec_amd import main as launcher
+    g9 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_end_to_end.npz"))
+    path = _write_inter(g8, tmp_path)
+    lr, l2 = g9[tag + "_hp"]
+    argv = ["--model_name", "BPRMF", "--runner_name", runner_name, "--dataset", "ml-100k", "--path", path, "--epoch", "6",
+            "--batch_size", "1024", "--eval_batch_size", "2048", "--optimizer", "Adam" if tag == "adam" else "SGD", "--lr", repr(float(lr)),
+            "--l2", repr(float(l2)), "--log_file", str(tmp_path / "log.txt"), "--model_path", str(tmp_path / "m.pt"),
+            "--num_workers", "0", "--topk", "10,20", "--metric", "NDCG, HR", "--random_seed", "3407"]
+    args, model_class, reader_class, runner_class = launcher.build_args(argv)
+    launcher.init_seed(args.random_seed)
+    import torch
+    args.device = torch.device("cuda")
+    corpus = reader_class(args).corpus()
+    model = model_class(args, corpus).to(args.device)
+    data = {ph: model_class.Dataset(model, corpus, ph) for ph in ("train", "dev", "test")}
+    run = runner_class(args)
+    losses, devs = [], []
+    for epoch in range(args.epoch):
+        losses.append(run.fit(data["train"], epoch=epoch + 1))
+        devs.append(run.evaluate(data["dev"], run.topk[:1], run.metrics))
+    test = run.evaluate(data["test"], run.topk, run.metrics)
+    assert np.allclose(losses, g9[tag + "_loss"], rtol=2e-5, atol=0)
+    n_eval = len(data["dev"])
+    flips = 6.0 / n_eval                              # a handful of near-tied ranks may fall on the other side of the cut
+    dev = np.asarray([[d[k] for k in g9[tag + "_dev_keys"]] for d in devs])
+    assert np.abs(dev - g9[tag + "_dev"]).max() <= flips, np.abs(dev - g9[tag + "_dev"]).max()
+    tst = np.asarray([test[k] for k in g9[tag + "_test_keys"]])
+    assert np.abs(tst - g9[tag + "_test"]).max() <= flips

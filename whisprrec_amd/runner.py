@@ -68,6 +68,13 @@ def epoch_order(n, batch_size, num_workers=0):
     return _epoch_order_direct(n, batch_size) if _DIRECT_OK else _epoch_order_via_loader(n, batch_size)
 
 
+def consume_loader_seed():
+    """Every DataLoader iterator draws a base seed from the global torch RNG when it is created — the reference's evaluation
+    loop too (BaseRunner.py:229-235), between two training epochs.  Code that replaces such a loop by array work draws the
+    same number, so the next epoch's shuffle sees the stream where the reference's would."""
+    torch.empty((), dtype=torch.int64).random_()
+
+
 class _Rows:
     def __init__(self, n):
         self.n = n
@@ -226,6 +233,7 @@ class BaseRunner(object):
                     targets.append(s[torch.arange(len(pb), device=s.device), pb])
                     scores.append(s)
             else:
+                consume_loader_seed()
                 for lo in range(0, len(users), self.eval_batch_size):
                     ub = torch.from_numpy(users[lo:lo + self.eval_batch_size]).to(model.device)
                     pb = torch.from_numpy(items[lo:lo + self.eval_batch_size]).to(model.device)
@@ -292,6 +300,7 @@ def make_hip_runner(base_runner_cls):
             if not hasattr(model, "eval_factors") or model.eval_factors()[0].shape[1] > 256:
                 return base_runner_cls.evaluate(self, dataset, topks, metrics)
             from . import hip_ops
+            consume_loader_seed()                       # the evaluation DataLoader this replaces would draw its base seed
             model.eval()
             user_mat, item_mat = model.eval_factors()
             dev = user_mat.device
