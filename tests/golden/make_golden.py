@@ -482,7 +482,12 @@ def g9_end_to_end():
     with open(src) as f:
         lines = f.readlines()[:25001]
     out = {}
-    for tag, opt, lr, l2 in (("adam", "Adam", 1e-2, 1e-6), ("sgd", "SGD", 8.0, 0.0)):
+    from models.general.SGL import SGL
+    cases = (("adam", BPRMF, "Adam", 1e-2, 1e-6, 6, {}), ("sgd", BPRMF, "SGD", 8.0, 0.0, 6, {}),
+             ("lightgcn", LightGCN, "Adam", 5e-3, 0.0, 3, dict(gcn_layers=2, reg_weight=1e-5)),
+             ("sgl", SGL, "Adam", 5e-3, 0.0, 3, dict(gcn_layers=2, reg_weight=1e-4, type="ED", ssl_tau=0.2, ssl_weight=0.05,
+                                                  drop_ratio=0.1)))
+    for tag, cls, opt, lr, l2, epochs, extra in cases:
         work = tempfile.mkdtemp(prefix="wr_golden_")
         os.makedirs(os.path.join(work, "ml-100k"))
         with open(os.path.join(work, "ml-100k", "ml-100k.inter"), "w") as f:
@@ -490,18 +495,18 @@ def g9_end_to_end():
         ref_utils.init_seed(3407)
         rargs = argparse.Namespace(sep="\t", path=work + "/", dataset="ml-100k", sample="random")
         corpus = BaseReader(rargs)
-        args = _args(embedding_size=64, model_path=os.path.join(work, "m.pt"), epoch=6, check_epoch=1, test_epoch=-1, early_stop=10,
-                     lr=lr, l2=l2, batch_size=1024, eval_batch_size=2048, optimizer=opt, num_workers=0, pin_memory=0, topk="10,20",
-                     metric="NDCG, HR")
-        model = BPRMF(args, corpus).to(args.device)
-        data = {ph: BPRMF.Dataset(model, corpus, ph) for ph in ("train", "dev", "test")}
+        args = _args(embedding_size=64, model_path=os.path.join(work, "m.pt"), epoch=epochs, check_epoch=1, test_epoch=-1,
+                     early_stop=10, lr=lr, l2=l2, batch_size=1024, eval_batch_size=2048, optimizer=opt, num_workers=0,
+                     pin_memory=0, topk="10,20", metric="NDCG, HR", **extra)
+        model = cls(args, corpus).to(args.device)
+        data = {ph: cls.Dataset(model, corpus, ph) for ph in ("train", "dev", "test")}
         runner = BaseRunner(args)
         losses, devs = [], []
         for epoch in range(args.epoch):           # BaseRunner.train's loop body (BaseRunner.py:131-146), results captured
             losses.append(runner.fit(data["train"], epoch=epoch + 1))
             devs.append(runner.evaluate(data["dev"], runner.topk[:1], runner.metrics))
         test = runner.evaluate(data["test"], runner.topk, runner.metrics)
-        out[tag + "_hp"] = np.asarray([lr, l2], dtype=np.float64)
+        out[tag + "_hp"] = np.asarray([lr, l2, epochs], dtype=np.float64)
         out[tag + "_loss"] = np.asarray(losses, dtype=np.float64)
         keys = sorted(devs[0])
         out[tag + "_dev_keys"] = np.asarray(keys)
