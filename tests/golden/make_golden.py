@@ -486,7 +486,8 @@ def g9_end_to_end():
     cases = (("adam", BPRMF, "Adam", 1e-2, 1e-6, 6, {}), ("sgd", BPRMF, "SGD", 8.0, 0.0, 6, {}),
              ("lightgcn", LightGCN, "Adam", 5e-3, 0.0, 3, dict(gcn_layers=2, reg_weight=1e-5)),
              ("sgl", SGL, "Adam", 5e-3, 0.0, 3, dict(gcn_layers=2, reg_weight=1e-4, type="ED", ssl_tau=0.2, ssl_weight=0.05,
-                                                  drop_ratio=0.1)))
+                                                  drop_ratio=0.1)),
+             ("sasrec", SASRec, "Adam", 2e-3, 0.0, 2, dict(emb_size=32, num_layers=1, num_heads=2, dropout=0.0, history_max=20)))
     for tag, cls, opt, lr, l2, epochs, extra in cases:
         work = tempfile.mkdtemp(prefix="wr_golden_")
         os.makedirs(os.path.join(work, "ml-100k"))
@@ -494,7 +495,11 @@ def g9_end_to_end():
             f.writelines(lines)
         ref_utils.init_seed(3407)
         rargs = argparse.Namespace(sep="\t", path=work + "/", dataset="ml-100k", sample="random")
-        corpus = BaseReader(rargs)
+        if cls is SASRec:
+            from helpers.SeqReader import SeqReader
+            corpus = SeqReader(rargs)
+        else:
+            corpus = BaseReader(rargs)
         args = _args(embedding_size=64, model_path=os.path.join(work, "m.pt"), epoch=epochs, check_epoch=1, test_epoch=-1,
                      early_stop=10, lr=lr, l2=l2, batch_size=1024, eval_batch_size=2048, optimizer=opt, num_workers=0,
                      pin_memory=0, topk="10,20", metric="NDCG, HR", **extra)

@@ -102,7 +102,8 @@ def test_seq_reader_matches_reference(g8, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,runner_name", [("adam", "BaseRunner"), ("adam", "HipRunner"), ("sgd", "HipRunner"),
-                                             ("lightgcn", "BaseRunner"), ("lightgcn", "HipRunner"), ("sgl", "HipRunner")])
+                                             ("lightgcn", "BaseRunner"), ("lightgcn", "HipRunner"), ("sgl", "HipRunner"),
+                                             ("sasrec", "BaseRunner")])
 def test_end_to_end_run_matches_the_reference_train_loop(g8, tmp_path, tag, runner_name):
     """the same command line, the same seed, the same data file: per-epoch training loss, dev metrics after every epoch and
     the final test metrics of the reference's BaseRunner.train on CPU (tests/golden/g9_end_to_end.npz) — reader, sampler and
@@ -113,7 +114,8 @@ def test_end_to_end_run_matches_the_reference_train_loop(g8, tmp_path, tag, runn
     lr, l2, epochs = g9[tag + "_hp"]
     name, extra = {"adam": ("BPRMF", []), "sgd": ("BPRMF", []), "lightgcn": ("LightGCN", ["--gcn_layers", "2", "--reg_weight", "1e-5"]),
                    "sgl": ("SGL", ["--gcn_layers", "2", "--reg_weight", "1e-4", "--type", "ED", "--ssl_tau", "0.2", "--ssl_weight", "0.05",
-                                   "--drop_ratio", "0.1"])}[tag]
+                                   "--drop_ratio", "0.1"]),
+                   "sasrec": ("SASRec", ["--emb_size", "32", "--num_layers", "1", "--num_heads", "2", "--dropout", "0.0", "--history_max", "20"])}[tag]
     argv = extra + ["--model_name", name, "--runner_name", runner_name, "--dataset", "ml-100k", "--path", path, "--epoch", str(int(epochs)),
             "--batch_size", "1024", "--eval_batch_size", "2048", "--optimizer", "SGD" if tag == "sgd" else "Adam", "--lr", repr(float(lr)),
             "--l2", repr(float(l2)), "--log_file", str(tmp_path / "log.txt"), "--model_path", str(tmp_path / "m.pt"),
@@ -131,7 +133,7 @@ def test_end_to_end_run_matches_the_reference_train_loop(g8, tmp_path, tag, runn
         losses.append(run.fit(data["train"], epoch=epoch + 1))
         devs.append(run.evaluate(data["dev"], run.topk[:1], run.metrics))
     test = run.evaluate(data["test"], run.topk, run.metrics)
-    assert np.allclose(losses, g9[tag + "_loss"], rtol=5e-5 if tag in ("lightgcn", "sgl") else 2e-5, atol=0)
+    assert np.allclose(losses, g9[tag + "_loss"], rtol=5e-5 if tag in ("lightgcn", "sgl", "sasrec") else 2e-5, atol=0)
     n_eval = len(data["dev"])
     flips = 6.0 / n_eval                              # a handful of near-tied ranks may fall on the other side of the cut
     dev = np.asarray([[d[k] for k in g9[tag + "_dev_keys"]] for d in devs])
