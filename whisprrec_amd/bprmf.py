@@ -16,7 +16,6 @@ Two ways to drive it:
 Other ``--optimizer`` names (Adagrad, Adadelta, ...) work through ``torch.optim`` on the dense gradients the backward
 kernels emit.
 """
-import numpy as np
 import torch
 import torch.nn as nn
 

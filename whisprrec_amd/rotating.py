@@ -228,7 +228,6 @@ def bench_main(args, rank, world, local_rank):
     often as a full epoch of args.interactions interactions would require (every stratum_steps steps), inside the timed
     region."""
     import json
-    import os
     import time
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -23,7 +23,6 @@ Per step (hot path)
 Link budget per rank and step: 2 * D*4 * (unique remote items) bytes each way — see DESIGN.md §6.
 """
 import math
-import os
 import time
 
 import numpy as np
