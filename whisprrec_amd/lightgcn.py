@@ -179,7 +179,9 @@ def make_lightgcn(general_model_cls):
             # gradient w.r.t. the propagated tables: BPRMF gradient kernels on (Ua, Ia).  One small batch: the radix-sort
             # builder and the sequential run path need no host round trip besides the index check.
             tabs = hip_ops.BprmfTables(Ua, Ia)
-            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="generic", hot=False)
+            # indices already range-checked for the whole epoch (HipRunner): no per-batch read-back, the step never waits on the host
+            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="generic", hot=False,
+                                     validate=not getattr(self, "_trusted_indices", False))
             gOut = torch.zeros(nU + self.n_items, D, device=allE.device)
             tabs.grads(plan, 0, gOut[:nU], gOut[nU:])
             # back through the propagation: A is symmetric, d(mean_l A^l E0) = mean_l A^l gOut

@@ -348,6 +348,12 @@ def make_hip_runner(base_runner_cls):
                 model.optimizer = self._build_optimizer(model)
             cols = self._epoch_columns(dataset, dev, epoch)
             n, B = cols[0].numel(), self.batch_size
+            # one range check for the whole epoch (nn.Embedding would raise IndexError batch by batch); the models then skip
+            # their per-batch check and its device-to-host read-back
+            lo_ok = min(int(c.min()) for c in cols) >= 0
+            if not lo_ok or int(cols[0].max()) >= model.user_num or max(int(cols[1].max()), int(cols[2].max())) >= model.item_num:
+                raise IndexError("index out of range in the training frame")
+            model._trusted_indices = True
             losses = []
             for lo in range(0, n, B):
                 batch = {"user_id": cols[0][lo:lo + B], "pos_item": cols[1][lo:lo + B], "neg_items": cols[2][lo:lo + B].unsqueeze(1),
@@ -357,6 +363,7 @@ def make_hip_runner(base_runner_cls):
                 loss.backward()
                 model.optimizer.step()
                 losses.append(loss.detach().reshape(-1)[0])
+            model._trusted_indices = False
             return float(torch.stack(losses).mean().cpu())
 
     HipRunner.__qualname__ = "HipRunner"
