@@ -189,6 +189,15 @@ int32_t wr_adam_dense(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_r
                       const int32_t *stamp, int32_t step_id, int64_t adam_step, float lr, float l2, float beta1,
                       float beta2, float eps, void *stream);
 
+/* wr_adam_dense with the step number in device memory (consts as for wr_adam_rows_lazy: consts[2t] = lr/(1-beta1^t),
+ * consts[2t+1] = 1/sqrt(1-beta2^t); t = step_dev[0], 1-based, must be < n_consts): the launch has no step-dependent
+ * argument, so a hipGraph that captured a whole training step can be replayed; wr_counter_add advances the counter inside the
+ * same graph.  All rows take the gradient (no stamps). */
+int32_t wr_adam_dense_dev(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_rows, int32_t D, const float *grad,
+                          const float *consts, int64_t n_consts, const int32_t *step_dev, float l2, float beta1, float beta2,
+                          float eps, void *stream);
+int32_t wr_counter_add(int32_t *counter, int32_t delta, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K5 (lazy, exact)  The same optimizers without the table passes.  torch.optim.Adam / SGD(weight_decay) move every
  * row at every step (BaseRunner.py:120-124,199); between two batches that contain it a row's trajectory depends on

@@ -177,3 +177,37 @@ def test_hip_runner_batches_equal_reference_loop(g4):
         out.append((r.fit(ds, epoch=1), r.fit(ds, epoch=2), m.user_embedding.weight.detach().clone()))
     assert abs(out[0][0] - out[1][0]) < 1e-6 and abs(out[0][1] - out[1][1]) < 1e-6
     assert torch.allclose(out[0][2], out[1][2], rtol=0, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_captured_step_graph_equals_eager_loop():
+    """HipRunner replays a hipGraph of the whole LightGCN training step; losses and tables must equal the eager loop's bits"""
+    import random
+    from whisprrec_amd import runner
+    from whisprrec_amd.lightgcn import LightGCN
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(3)
+    nU, nI, B = 500, 300, 256
+    sets, tu, ti = {}, [], []
+    for uu in range(nU):
+        items = np.unique(rng.randint(0, nI - 40, rng.randint(4, 30)))
+        sets[uu] = set(items.tolist()); tu += [uu] * len(items); ti += items.tolist()
+    frames = {"train": {"user_id": np.asarray(tu), "item_id": np.asarray(ti)},
+              "dev": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)},
+              "test": {"user_id": np.zeros(0, np.int64), "item_id": np.zeros(0, np.int64)}}
+    corpus = host.Corpus(nU, nI, frames, sets, {u: set() for u in sets})
+    assert len(tu) >= 10 * B
+    out = []
+    for graphs in (0, 1):
+        random.seed(1); np.random.seed(1); torch.manual_seed(1)
+        args = _args(dev, optimizer="Adam", lr=2e-3, l2=0.0, epoch=1, check_epoch=1, test_epoch=-1, early_stop=10, batch_size=B,
+                     eval_batch_size=256, num_workers=0, pin_memory=0, topk="10", metric="NDCG", device_epoch_prep=0, hip_graphs=graphs)
+        m = LightGCN(args, corpus).to(dev)
+        ds = LightGCN.Dataset(m, corpus, "train")
+        r = runner.HipRunner(args)
+        l1, l2 = r.fit(ds, epoch=1), r.fit(ds, epoch=2)
+        assert (getattr(r, "_graph_cache", None) is not None) == bool(graphs)
+        out.append((l1, l2, m.user_embedding.weight.detach().clone(), m.item_embedding.weight.detach().clone(), m.optimizer.t))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
+    assert out[0][4] == out[1][4]

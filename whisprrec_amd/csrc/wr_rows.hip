@@ -138,6 +138,31 @@ __global__ __launch_bounds__(kBlock) void adam_dense_kernel(float4 *__restrict__
     }
 }
 
+// The same pass with the step number in DEVICE memory: consts[2t], consts[2t+1] = step_size, 1/sqrt(bias_correction2) of step
+// t = *step_dev.  Nothing in the launch depends on the step, so a captured hipGraph of a training step can be replayed.
+__global__ __launch_bounds__(kBlock) void adam_dense_dev_kernel(float4 *__restrict__ w, float4 *__restrict__ m,
+                                                                 float4 *__restrict__ v, const float4 *__restrict__ g,
+                                                                 int64_t n4, int D4, const int *__restrict__ stamp,
+                                                                 const int *__restrict__ step_id_dev, float l2, float b1,
+                                                                 float b2, float eps, const float *__restrict__ consts,
+                                                                 const int *__restrict__ step_dev) {
+    const int t = step_dev[0];
+    const float step_size = consts[2 * t], inv_bc2 = consts[2 * t + 1];
+    const int step_id = step_id_dev != nullptr ? step_id_dev[0] : 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const bool live = (stamp == nullptr) || (stamp[i / D4] == step_id);
+        float4 ww = w[i], mm = m[i], vv = v[i];
+        const float4 gg = live ? g[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        adam_elem(ww.x, mm.x, vv.x, gg.x, l2, b1, b2, eps, step_size, inv_bc2);
+        adam_elem(ww.y, mm.y, vv.y, gg.y, l2, b1, b2, eps, step_size, inv_bc2);
+        adam_elem(ww.z, mm.z, vv.z, gg.z, l2, b1, b2, eps, step_size, inv_bc2);
+        adam_elem(ww.w, mm.w, vv.w, gg.w, l2, b1, b2, eps, step_size, inv_bc2);
+        w[i] = ww; m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ void counter_add_kernel(int *__restrict__ c, int delta) { c[0] += delta; }
+
 __global__ __launch_bounds__(kBlock) void axpy_kernel(float4 *__restrict__ y, const float4 *__restrict__ x, int64_t n4,
                                                        float alpha, int overwrite, float *__restrict__ ytail,
                                                        const float *__restrict__ xtail, int tail) {
@@ -518,6 +543,31 @@ int32_t wr_adam_dense(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_r
                        reinterpret_cast<float4 *>(exp_avg_sq), reinterpret_cast<const float4 *>(grad), n4, D / 4, stamp,
                        step_id, l2, beta1, beta2, eps, step_size, bc2_sqrt);
     WR_LAUNCH_CHECK("adam_dense_kernel");
+    return WR_OK;
+}
+
+int32_t wr_adam_dense_dev(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_rows, int32_t D, const float *grad,
+                          const float *consts, int64_t n_consts, const int32_t *step_dev, float l2, float beta1, float beta2,
+                          float eps, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg, n_rows, D, "exp_avg")) != WR_OK) return rc;
+    if ((rc = check_table(exp_avg_sq, n_rows, D, "exp_avg_sq")) != WR_OK) return rc;
+    if ((rc = check_table(grad, n_rows, D, "grad")) != WR_OK) return rc;
+    WR_REQUIRE(consts != nullptr && step_dev != nullptr && n_consts >= 2, WR_E_NULL, "consts / step_dev is NULL");
+    const int64_t n4 = n_rows * (D / 4);
+    hipLaunchKernelGGL(adam_dense_dev_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream_),
+                       reinterpret_cast<float4 *>(tab), reinterpret_cast<float4 *>(exp_avg),
+                       reinterpret_cast<float4 *>(exp_avg_sq), reinterpret_cast<const float4 *>(grad), n4, D / 4, nullptr,
+                       nullptr, l2, beta1, beta2, eps, consts, step_dev);
+    WR_LAUNCH_CHECK("adam_dense_dev_kernel");
+    return WR_OK;
+}
+
+int32_t wr_counter_add(int32_t *counter, int32_t delta, void *stream_) {
+    WR_REQUIRE(counter != nullptr, WR_E_NULL, "counter is NULL");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream_), counter, delta);
+    WR_LAUNCH_CHECK("counter_add_kernel");
     return WR_OK;
 }
 

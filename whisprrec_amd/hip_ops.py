@@ -628,6 +628,26 @@ class LazyOptimizerState:
         self.flushed_at = self.t
 
 
+def adam_consts(n, lr, beta1=0.9, beta2=0.999, device=None):
+    """device table of the per-step Adam constants for steps 0..n-1 (wr_adam_consts: the host expressions of wr_adam_dense)"""
+    host = torch.empty(2 * n, dtype=torch.float32)
+    abi.check(abi.lib().wr_adam_consts(0, n, lr, beta1, beta2, host.data_ptr()), "wr_adam_consts")
+    return host.to(device) if device is not None else host
+
+
+def adam_dense_dev(tab, exp_avg, exp_avg_sq, grad, consts, step_dev, l2=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """wr_adam_dense with the step number read from device memory (graph-replayable)"""
+    for t, nm in ((tab, "tab"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (grad, "grad")):
+        _req(t, torch.float32, nm, 2)
+    abi.check(abi.lib().wr_adam_dense_dev(_p(tab), _p(exp_avg), _p(exp_avg_sq), tab.shape[0], tab.shape[1], _p(grad),
+                                          _p(consts), consts.numel() // 2, _p(step_dev), l2, beta1, beta2, eps, _stream()),
+              "wr_adam_dense_dev")
+
+
+def counter_add(counter, delta=1):
+    abi.check(abi.lib().wr_counter_add(_p(_req(counter, torch.int32, "counter", 1)), int(delta), _stream()), "wr_counter_add")
+
+
 # ----------------------------------------------------------------------------------------------- rows
 def gather_rows(tab, idx):
     """nn.Embedding forward: out[..., :] = tab[idx[...], :]."""

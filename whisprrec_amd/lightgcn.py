@@ -53,7 +53,11 @@ def build_norm_adj_csr(n_users, n_items, train_clicked_set):
 
 class DenseHipOptimizer:
     """zero_grad/step over dense ``.grad`` tensors with the HIP dense optimizers (torch.optim.SGD / Adam semantics,
-    reference BaseRunner.py:120-124)."""
+    reference BaseRunner.py:120-124).  Adam keeps its step number on the DEVICE (a counter bumped by a one-thread kernel,
+    bias-correction constants in a table): no launch argument changes from step to step, so a hipGraph that captured a
+    whole training step (HipRunner) replays correctly."""
+
+    MAX_STEPS = 1 << 20
 
     def __init__(self, params, name, lr, l2):
         if name not in ("SGD", "Adam"):
@@ -61,14 +65,37 @@ class DenseHipOptimizer:
         self.params, self.name, self.lr, self.l2 = list(params), name, float(lr), float(l2)
         self.t = 0
         self.state = {}
+        self.step_dev = self.consts = None
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             p.grad = None
 
+    def prepare(self):
+        """allocate everything step() needs (moments, step counter, constants): nothing is allocated inside a graph capture"""
+        if self.name == "Adam":
+            dev = self.params[0].device
+            if self.step_dev is None or self.step_dev.device != dev:
+                self.step_dev = torch.full((1,), self.t, dtype=torch.int32, device=dev)
+                self.consts = hip_ops.adam_consts(self.MAX_STEPS, self.lr, device=dev)
+            for p in self.params:
+                if p not in self.state:
+                    self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+
+    def sync_step_count(self):
+        """after graph replays (which bump the device counter only) bring the host mirror up to date"""
+        if self.step_dev is not None:
+            self.t = int(self.step_dev.item())
+
     @torch.no_grad()
     def step(self):
+        if self.name == "Adam":
+            self.prepare()                     # the device counter starts at the number of steps taken so far
         self.t += 1
+        if self.name == "Adam":
+            if self.t >= self.MAX_STEPS:
+                raise RuntimeError("more than %d Adam steps" % self.MAX_STEPS)
+            hip_ops.counter_add(self.step_dev, 1)
         for p in self.params:
             if p.grad is None:
                 continue
@@ -76,10 +103,8 @@ class DenseHipOptimizer:
             if self.name == "SGD":
                 hip_ops.sgd_dense(p.data, g, self.lr, self.l2)
             else:
-                if p not in self.state:
-                    self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
                 m, v = self.state[p]
-                hip_ops.adam_dense(p.data, m, v, g, self.t, self.lr, self.l2)
+                hip_ops.adam_dense_dev(p.data, m, v, g, self.consts, self.step_dev, self.l2)
 
 
 class _LightGcnLoss(torch.autograd.Function):
@@ -102,6 +127,7 @@ def make_lightgcn(general_model_cls):
         reader = "BaseReader"
         runner = "BaseRunner"
         extra_log_args = ["embedding_size", "gcn_layers", "reg_weight"]
+        graph_capturable = True     # with range-checked indices the step never touches the host: HipRunner may capture it
 
         @staticmethod
         def parse_model_args(parser):

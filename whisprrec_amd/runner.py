@@ -266,11 +266,14 @@ def make_hip_runner(base_runner_cls):
             parser.add_argument("--device_epoch_prep", type=int, default=0,
                                 help="1: sample negatives and shuffle on the device (counter-based generator; same rule "
                                      "as the reference sampler but not its NumPy stream). 0: reference streams, bit-exact.")
+            parser.add_argument("--hip_graphs", type=int, default=1,
+                                help="1: capture the training step of graph-capturable models (LightGCN) in a hipGraph.")
             return base_runner_cls.parse_runner_args(parser)
 
         def __init__(self, args):
             super().__init__(args)
             self.device_epoch_prep = int(getattr(args, "device_epoch_prep", 0))
+            self.hip_graphs = int(getattr(args, "hip_graphs", 1))
             self.seed = int(getattr(args, "random_seed", 3407))
             self._epoch_cache = None
 
@@ -319,6 +322,47 @@ def make_hip_runner(base_runner_cls):
             rank, _ = hip_ops.rank_eval(user_mat.contiguous(), item_mat.contiguous(), eu, et, cache[2], cache[3])
             return self.metrics_from_ranks(rank.cpu().numpy().astype(np.int64), topks, metrics)
 
+        def _step_graph(self, model, cols, B, n, eager_step):
+            """hipGraph of one whole training step (zero_grad / predict / backward / optimizer.step) of a model that declares
+            itself ``graph_capturable`` — its step is ~60 small launches and host-bound, nothing in it depends on the host
+            from step to step (indices arrive in static buffers, Adam's step number lives on the device).  The first three
+            batches run eagerly on a side stream (they are ordinary training steps and size every scratch buffer), then the
+            step is captured once per (model, batch size, graph view) and replayed.  -> (graph, static index tensors, static
+            loss, first row not yet trained) or None."""
+            if not getattr(model, "graph_capturable", False) or n < 8 * B or not hasattr(model.optimizer, "prepare"):
+                return None
+            key = (id(model), B, getattr(model, "graph_key", lambda: 0)())
+            cached = getattr(self, "_graph_cache", None)
+            if cached is not None and cached[0] == key:
+                return cached[1], cached[2], cached[3], 0
+            try:
+                dev = cols[0].device
+                model.optimizer.prepare()
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for i in range(3):
+                        eager_step(i * B)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                static = [torch.empty(B, dtype=c.dtype, device=dev) for c in cols]
+                batch = {"user_id": static[0], "pos_item": static[1], "neg_items": static[2].unsqueeze(1), "batch_size": B,
+                         "phase": "train"}
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    model.optimizer.zero_grad()
+                    static_loss = model.predict(batch)
+                    static_loss.backward()
+                    model.optimizer.step()
+                if hasattr(model.optimizer, "sync_step_count"):
+                    model.optimizer.t -= 1               # the captured step() call itself trained nothing
+                self._graph_cache = (key, g, static, static_loss)
+                return g, static, static_loss, 3 * B
+            except Exception as e:  # noqa: BLE001 - capture is an optimisation: fall back to the eager loop
+                logging.warning("hipGraph capture of the training step failed (%r); continuing without graphs", e)
+                self.hip_graphs = 0
+                torch.cuda.synchronize()
+                return None
+
         def _epoch_columns(self, dataset, dev, epoch):
             """the epoch's (user, positive, negative) columns in batch order on the device"""
             if self.device_epoch_prep:
@@ -355,7 +399,8 @@ def make_hip_runner(base_runner_cls):
                 raise IndexError("index out of range in the training frame")
             model._trusted_indices = True
             losses = []
-            for lo in range(0, n, B):
+
+            def eager_step(lo):
                 batch = {"user_id": cols[0][lo:lo + B], "pos_item": cols[1][lo:lo + B], "neg_items": cols[2][lo:lo + B].unsqueeze(1),
                          "batch_size": min(B, n - lo), "phase": "train"}
                 model.optimizer.zero_grad()
@@ -363,6 +408,22 @@ def make_hip_runner(base_runner_cls):
                 loss.backward()
                 model.optimizer.step()
                 losses.append(loss.detach().reshape(-1)[0])
+
+            lo = 0
+            graph = self._step_graph(model, cols, B, n, eager_step) if self.hip_graphs else None
+            if graph is not None:
+                g, static, static_loss, lo = graph
+                while lo + B <= n:                          # full batches: copy the indices in, replay the captured step
+                    for dst, src in zip(static, cols):
+                        dst.copy_(src[lo:lo + B])
+                    g.replay()
+                    losses.append(static_loss.detach().reshape(-1)[0].clone())
+                    lo += B
+                if hasattr(model.optimizer, "sync_step_count"):
+                    model.optimizer.sync_step_count()
+            while lo < n:                                   # no graph, or the short last batch
+                eager_step(lo)
+                lo += B
             model._trusted_indices = False
             return float(torch.stack(losses).mean().cpu())
 

@@ -145,6 +145,7 @@ def make_sgl(general_model_cls):
         reader = "BaseReader"
         runner = "BaseRunner"
         extra_log_args = ["embedding_size", "gcn_layers", "reg_weight", "type", "ssl_tau", "ssl_weight", "drop_ratio"]
+        graph_capturable = True     # HipRunner may capture the step in a hipGraph; re-captured when the views change (graph_key)
 
         @staticmethod
         def parse_model_args(parser):
@@ -182,8 +183,12 @@ def make_sgl(general_model_cls):
                                                    getattr(args, "l2", 0.0))
 
         # ------------------------------------------------------------------ views
+        def graph_key(self):
+            return getattr(self, "_views_version", 0)
+
         def graph_construction(self):
             """two views per epoch from Python's ``random`` stream, in the reference's order (SGL.py:67-79)"""
+            self._views_version = getattr(self, "_views_version", 0) + 1
             N = self.n_users + self.n_items
             rows, cols = self._edges
             for name in ("sub1", "sub2"):
