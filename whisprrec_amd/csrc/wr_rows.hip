@@ -289,6 +289,53 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
     }
 }
 
+// Rows cut into several chunks are put together in two levels, so that a hub row with hundreds of chunks is not one team's
+// chain of hundreds of dependent adds.  Level 1: inside every aligned group of kGroup chunk slots, the first chunk of a row
+// adds that row's other chunks of the group into its own partial (in place; the groups' segments are disjoint).  Level 2: the
+// row's head adds the group leaders (its own partial, then the ones at the following group boundaries) and writes the row.
+// Fixed order, no atomics.
+constexpr int kGroup = 16;
+
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ Row<NV> sum_partials(const float *__restrict__ partials, const int *__restrict__ chunk_row, int row,
+                                                int first, int next, int step, int end, int D, int lane) {
+    Row<NV> s = load_row<T, NV, FULL>(partials, first, D, lane);
+    constexpr int kFly = 8;   // partial rows in flight per trip, added in order
+    for (int j = next; j < end && chunk_row[j] == row; j += kFly * step) {
+        Row<NV> x[kFly];
+        bool ok[kFly];
+#pragma unroll
+        for (int f = 0; f < kFly; ++f) ok[f] = j + f * step < end && chunk_row[j + f * step] == row;
+#pragma unroll
+        for (int f = 0; f < kFly; ++f)
+            if (ok[f]) x[f] = load_row<T, NV, FULL>(partials, j + f * step, D, lane);
+#pragma unroll
+        for (int f = 0; f < kFly; ++f) {
+            if (!ok[f]) continue;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                s.v[q].x += x[f].v[q].x; s.v[q].y += x[f].v[q].y; s.v[q].z += x[f].v[q].z; s.v[q].w += x[f].v[q].w;
+            }
+        }
+    }
+    return s;
+}
+
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void spmm_combine_groups_kernel(int n_chunks, const int *__restrict__ chunk_row,
+                                                                      float *__restrict__ partials, int D) {
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int c = blockIdx.x * TEAMS + threadIdx.x / T;
+    if (c >= n_chunks) return;
+    const int row = chunk_row[c];
+    const bool leader = (c % kGroup == 0) || chunk_row[c - 1] != row;
+    const int end = (c / kGroup + 1) * kGroup < n_chunks ? (c / kGroup + 1) * kGroup : n_chunks;
+    if (!leader || c + 1 >= end || chunk_row[c + 1] != row) return;   // nothing of this row follows inside the group
+    const Row<NV> s = sum_partials<T, NV, FULL>(partials, chunk_row, row, c, c + 1, 1, end, D, lane);
+    store_row<T, NV, FULL>(partials, c, D, lane, s);
+}
+
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, const int *__restrict__ chunk_row,
                                                                const float *__restrict__ partials, int D, float *__restrict__ Y,
@@ -300,26 +347,8 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, cons
     const int row = chunk_row[c];
     const bool head = (c == 0 || chunk_row[c - 1] != row) && (c + 1 < n_chunks && chunk_row[c + 1] == row);
     if (!head) return;
-    Row<NV> s = load_row<T, NV, FULL>(partials, c, D, lane);
-    // a hub row has hundreds of chunks: eight partial rows in flight per trip, added in chunk order
-    constexpr int kFly = 8;
-    for (int j = c + 1; j < n_chunks && chunk_row[j] == row; j += kFly) {
-        Row<NV> x[kFly];
-        bool ok[kFly];
-#pragma unroll
-        for (int f = 0; f < kFly; ++f) ok[f] = j + f < n_chunks && chunk_row[j + f] == row;
-#pragma unroll
-        for (int f = 0; f < kFly; ++f)
-            if (ok[f]) x[f] = load_row<T, NV, FULL>(partials, j + f, D, lane);
-#pragma unroll
-        for (int f = 0; f < kFly; ++f) {
-            if (!ok[f]) continue;
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                s.v[q].x += x[f].v[q].x; s.v[q].y += x[f].v[q].y; s.v[q].z += x[f].v[q].z; s.v[q].w += x[f].v[q].w;
-            }
-        }
-    }
+    // the head's own partial holds its group's sum; the row's other group leaders sit at the following group boundaries
+    const Row<NV> s = sum_partials<T, NV, FULL>(partials, chunk_row, row, c, (c / kGroup + 1) * kGroup, kGroup, n_chunks, D, lane);
     store_row<T, NV, FULL>(Y, row, D, lane, s);
     if (acc != nullptr) {
         Row<NV> a = load_row<T, NV, FULL>(acc, row, D, lane);
@@ -608,6 +637,8 @@ int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chu
     do {                                                                                                                \
         hipLaunchKernelGGL((spmm_chunk_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,      \
                            chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials);                                     \
+        hipLaunchKernelGGL((spmm_combine_groups_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream,            \
+                           (int)n_chunks, chunk_row, partials, D);                                                      \
         hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,    \
                            chunk_row, partials, D, Y, acc);                                                             \
     } while (0)
