@@ -103,7 +103,7 @@ def test_seq_reader_matches_reference(g8, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,runner_name", [("adam", "BaseRunner"), ("adam", "HipRunner"), ("sgd", "HipRunner"),
                                              ("lightgcn", "BaseRunner"), ("lightgcn", "HipRunner"), ("sgl", "HipRunner"),
-                                             ("sasrec", "BaseRunner")])
+                                             ("sasrec", "BaseRunner"), ("sasrec", "HipRunner")])
 def test_end_to_end_run_matches_the_reference_train_loop(g8, tmp_path, tag, runner_name):
     """the same command line, the same seed, the same data file: per-epoch training loss, dev metrics after every epoch and
     the final test metrics of the reference's BaseRunner.train on CPU (tests/golden/g9_end_to_end.npz) — reader, sampler and

@@ -291,6 +291,7 @@ def make_hip_runner(base_runner_cls):
             g = torch.Generator(device=dev)
             g.manual_seed(self.seed * 1000003 + max(epoch, 0))
             order = torch.randperm(users.numel(), device=dev, generator=g)
+            self._last_order = order
             if int(err.item()) == 1:
                 raise IndexError("user id out of range in the training frame")
             return users[order], items[order], neg[order]
@@ -371,13 +372,40 @@ def make_hip_runner(base_runner_cls):
                 return self._device_epoch(dataset, dev, epoch)
             dataset.actions_before_epoch()              # must happen before the shuffle draws, as in the reference
             order = epoch_order(len(dataset), self.batch_size)
+            self._last_order = order
             return [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64).reshape(len(dataset), -1)[:, 0][order]
                     .to(dev) for k in ("user_id", "item_id", "neg_items")]
 
+        def _history_columns(self, dataset, dev):
+            """[n, history_max] item histories (left-aligned, zero-padded like collate_batch's pad_sequence) and their lengths
+            for every training row of a sequential dataset, built once with array operations: row i takes the last
+            history_max entries of its user's history before position[i] (SequentialModel.Dataset._get_feed_dict)."""
+            cached = getattr(self, "_hist_cache", None)
+            if cached is not None and cached[0] is dataset:
+                return cached[1], cached[2]
+            T = int(dataset.model.history_max)
+            users = np.asarray(dataset.data["user_id"]).astype(np.int64)
+            pos = np.asarray(dataset.data["position"]).astype(np.int64)
+            his = dataset.corpus.user_his
+            uniq = np.unique(users)
+            counts = np.asarray([len(his[int(uu)]) for uu in uniq], dtype=np.int64)
+            start_of = np.zeros(int(uniq.max()) + 2, np.int64)
+            start_of[uniq] = np.concatenate([[0], np.cumsum(counts)[:-1]])
+            flat = np.concatenate([np.fromiter((x[0] for x in his[int(uu)]), dtype=np.int64, count=len(his[int(uu)])) for uu in uniq])
+            length = np.minimum(pos, T) if T > 0 else pos
+            width = int(length.max()) if length.size else 1
+            first = start_of[users] + pos - length
+            idx = first[:, None] + np.arange(width)[None, :]
+            valid = np.arange(width)[None, :] < length[:, None]
+            hist = np.where(valid, flat[np.minimum(idx, flat.size - 1)], 0)
+            out = (torch.from_numpy(hist).to(dev), torch.from_numpy(length).to(dev))
+            self._hist_cache = (dataset, out[0], out[1])
+            return out
+
         def fit(self, dataset, epoch=-1):
             model = dataset.model
-            sequential = "position" in dataset.data     # history fields come from the Dataset's per-sample collate
-            if sequential or not hasattr(model, "user_num"):
+            sequential = "position" in dataset.data
+            if not hasattr(model, "user_num") or (sequential and not hasattr(model, "history_max")):
                 return base_runner_cls.fit(self, dataset, epoch)
             dev = next(model.parameters()).device
             model.train()
@@ -399,10 +427,17 @@ def make_hip_runner(base_runner_cls):
                 raise IndexError("index out of range in the training frame")
             model._trusted_indices = True
             losses = []
+            hist = None
+            if sequential:   # the per-row histories travel with the shuffle: same batches as the per-sample collate builds
+                hist_all, len_all = self._history_columns(dataset, dev)
+                order = self._last_order.to(dev)
+                hist, hlen = hist_all[order], len_all[order]
 
             def eager_step(lo):
                 batch = {"user_id": cols[0][lo:lo + B], "pos_item": cols[1][lo:lo + B], "neg_items": cols[2][lo:lo + B].unsqueeze(1),
                          "batch_size": min(B, n - lo), "phase": "train"}
+                if hist is not None:
+                    batch["history_items"], batch["lengths"] = hist[lo:lo + B], hlen[lo:lo + B]
                 model.optimizer.zero_grad()
                 loss = model.predict(batch)
                 loss.backward()
