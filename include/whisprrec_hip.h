@@ -155,8 +155,10 @@ int32_t wr_bprmf_step_sgd(float *user_tab, int64_t n_users, float *item_tab, int
 /* Runs consecutive steps over batches [first_batch, first_batch + n_batches) of a plan built with
  * `batch_size` over `n_triplets` triplets (the native inner loop of BaseRunner.fit, BaseRunner.py:194-200).
  * loss_out[k] receives the loss of batch first_batch + k (may be NULL).  l2 must be 0 here.
- * phase_events (may be NULL): 3*n_batches hipEvent_t handles; for step k, events 3k / 3k+1 / 3k+2 are recorded
- * on `stream` before the user phase, between the two kernels and after the item phase (per-kernel timing). */
+ * phase_events (may be NULL): 4*n_batches hipEvent_t handles, any of them NULL (per-kernel timing).  For step k, events
+ * 4k / 4k+1 are attached to the first / last kernel of the user phase as that dispatch's start / stop event, 4k+2 / 4k+3
+ * likewise for the item phase: they carry the kernels' own timestamps (what rocprofv3 --kernel-trace reports) and no
+ * marker packet is queued.  elapsed(4k, 4k+1) is the user phase of step k, elapsed(4k+1, 4k+3) launch to launch. */
 int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
                          const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                          const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,

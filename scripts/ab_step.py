@@ -25,10 +25,10 @@ for rep in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); tabs.run_sgd(plan, 0, NB, 0.05); e1.record(); torch.cuda.synchronize()
     out.append(e0.elapsed_time(e1) / NB * 1e3)
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * NB)]
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * NB)]
 tabs.run_sgd(plan, 0, NB, 0.05, phase_events=ev); torch.cuda.synchronize()
-ua = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(NB)) / NB * 1e3
-ia = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(NB)) / NB * 1e3
+ua = sum(ev[4 * k].elapsed_time(ev[4 * k + 1]) for k in range(NB)) / NB * 1e3
+ia = sum(ev[4 * k + 2].elapsed_time(ev[4 * k + 3]) for k in range(NB)) / NB * 1e3
 import time
 pt = []
 for rep in range(5):

@@ -17,9 +17,9 @@ for name, u in (("users with replacement", u_rep), ("users distinct inside a bat
     tabs = hip_ops.BprmfTables(U, I)
     plan = hip_ops.BatchPlan(u, p, n, B, nU, nI)
     tabs.run_sgd(plan, 0, NB, 0.05); torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * NB)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * NB)]
     tabs.run_sgd(plan, 0, NB, 0.05, phase_events=ev); torch.cuda.synchronize()
-    ua = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(NB)) / NB * 1e3
+    ua = sum(ev[4 * k].elapsed_time(ev[4 * k + 1]) for k in range(NB)) / NB * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); tabs.run_sgd(plan, 0, NB, 0.05); e1.record(); torch.cuda.synchronize()
     print("%-32s step %.2f us, user phase (events) %.2f us" % (name, e0.elapsed_time(e1) / NB * 1e3, ua))

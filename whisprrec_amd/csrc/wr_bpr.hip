@@ -22,6 +22,7 @@
 //     are complete at the kernel boundary).  Block 0 also folds the user phase's per-block loss partials into the loss.
 // No float atomics anywhere: each row has one writer and a fixed summation order.
 #include "wr_common.h"
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: stop events attached to a dispatch (timing hooks of launch_step)
 
 namespace wr {
 
@@ -216,20 +217,27 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
     const int seg = (B + SLOTS - 1) / SLOTS;
     float term_acc = 0.f;
 
-    int t0[SLOTS], uu[SLOTS], praw0[SLOTS], nraw0[SLOTS];
+    // All six index loads of a position go out together, on clamped addresses and without a branch between them: the
+    // obvious short-circuit tests (t == 0 || tu[t-1] != u, head && tu[t+kHotRun] == u, ...) compile to four memory round
+    // trips in a row before the first row load is issued, and a workgroup's lifetime is what bounds the bytes in flight.
+    int t0[SLOTS], uu[SLOTS], unext[SLOTS], praw0[SLOTS], nraw0[SLOTS];
     bool head[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         t0[s] = team + s * seg;
         head[s] = false;
-        uu[s] = praw0[s] = nraw0[s] = 0;
+        uu[s] = unext[s] = praw0[s] = nraw0[s] = 0;
         if (team < seg && t0[s] < B) {
-            uu[s] = tu[t0[s]];
-            head[s] = (t0[s] == 0) || (tu[t0[s] - 1] != uu[s]);   // first position of a run of equal users
+            const int t = t0[s];
+            const int u = tu[t], uprev = tu[max(t - 1, 0)], un = tu[min(t + 1, B - 1)];
+            const int uhot = SKIP_HOT ? tu[min(t + kHotRun, B - 1)] : 0;
+            praw0[s] = tp[t];
+            nraw0[s] = tn[t];
+            uu[s] = u;
+            unext[s] = (t + 1 < B) ? un : ~u;
+            head[s] = (t == 0) || (uprev != u);   // first position of a run of equal users
             // users with more than kHotRun triplets in the batch are cut into pieces by the plan (bprmf_user_hot_*)
-            if (SKIP_HOT && head[s] && t0[s] + kHotRun < B && tu[t0[s] + kHotRun] == uu[s]) head[s] = false;
-            praw0[s] = tp[t0[s]];
-            nraw0[s] = tn[t0[s]];
+            if (SKIP_HOT && t + kHotRun < B && uhot == u) head[s] = false;
         }
     }
     Row<NV> ur[SLOTS], pr0[SLOTS], nr0[SLOTS];
@@ -251,19 +259,18 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
         int t = t0[s];
         int praw = praw0[s], nraw = nraw0[s];
         Row<NV> pr = pr0[s], nr = nr0[s];
-        bool more;
-        do {
+        bool more = unext[s] == u;   // known before the first body: the single-triplet user's row store waits on nothing
+        for (;;) {
             triplet_body<T, NV, FULL, MODE>(ur[s], pr, nr, praw, nraw, t, I, gradI, Z, stampI, step_id, D, lane, lr, l2, denom, g,
                                             term_acc, ad);
-            ++t;
-            more = (t < B) && (tu[t] == u);
-            if (more) {  // next triplet of this user (nothing is kept live across the body: 8 waves per SIMD, no spill)
-                praw = tp[t];
-                nraw = tn[t];
-                pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
-                nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
-            }
-        } while (more);
+            if (!more) break;
+            ++t;   // next triplet of this user (nothing is kept live across the body: 8 waves per SIMD, no spill)
+            praw = tp[t];
+            nraw = tn[t];
+            more = (t + 1 < B) && (tu[t + 1] == u);
+            pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
+            nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
+        }
         finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur[s], g, ad);
     }
     if (lane != 0) term_acc = 0.f;  // every lane of a team holds the same terms: count them once
@@ -699,15 +706,26 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     // bytes in flight.
     const dim3 gridA((unsigned)n_blocks_for(B, D));
     const dim3 gridB((unsigned)((2 * B + kItemTile - 1) / kItemTile));  // item phase: one thread per occurrence
-    if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[0]), stream));
+    // Timing hooks, four events per step, any of them NULL: [0] / [1] start of the first and stop of the last kernel of the
+    // user phase, [2] / [3] the same for the item phase.  They are attached to the dispatches (hipExtLaunchKernelGGL: the
+    // events carry the kernel's own start / end timestamps, the ones rocprofv3 reports); no marker packet is queued.
+    auto ev = [&](int j) { return events ? reinterpret_cast<hipEvent_t>(events[j]) : (hipEvent_t) nullptr; };
+    const hipEvent_t none = nullptr;
+#define WR_LAUNCH(kernel_, grid_, lds_, start_, stop_, ...)                                                               \
+    do {                                                                                                                  \
+        if ((start_) != nullptr || (stop_) != nullptr)                                                                    \
+            hipExtLaunchKernelGGL(kernel_, grid_, block, lds_, stream, (start_), (stop_), 0, __VA_ARGS__);                 \
+        else                                                                                                              \
+            hipLaunchKernelGGL(kernel_, grid_, block, lds_, stream, __VA_ARGS__);                                          \
+    } while (0)
 #define WR_CALL_USER(T_, NV_, FULL_)                                                                                      \
     do {                                                                                                                  \
         if (have_hot_u)                                                                                                   \
-            hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, true>), gridA, block, 0, stream, U, I, D, tu, tp, \
-                               tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad);   \
+            WR_LAUNCH((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, true>), gridA, 0, ev(0), none, U, I, D, tu, tp,         \
+                      tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad);            \
         else                                                                                                              \
-            hipLaunchKernelGGL((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, false>), gridA, block, 0, stream, U, I, D, tu,    \
-                               tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad); \
+            WR_LAUNCH((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, false>), gridA, 0, ev(0), ev(1), U, I, D, tu,             \
+                      tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad);        \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
@@ -720,29 +738,28 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
         hipLaunchKernelGGL((bprmf_user_hot_pieces<T_, NV_, FULL_, MODE>), dim3((unsigned)hot.user.n_pieces), block,        \
                            lds_rows, stream, U, I, D, tu, tp, tn, lr, l2, w.Z, w.partials, gradI, stamp_i, step_id, denom,  \
                            hot.user.piece_q, hot.user.piece_len, w.hotPU, w.hot_loss, ad);                                \
-        hipLaunchKernelGGL((bprmf_user_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, U, D, tu,         \
-                           hot.user.run_q, hot.user.run_first, hot.user.run_np, hot.user.n_runs, w.hotPU, lr, l2, gradU,   \
-                           stamp_u, step_id, ad);                                                                        \
+        WR_LAUNCH((bprmf_user_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), 0, none, ev(1), U, D, tu,                    \
+                  hot.user.run_q, hot.user.run_first, hot.user.run_np, hot.user.n_runs, w.hotPU, lr, l2, gradU,            \
+                  stamp_u, step_id, ad);                                                                                 \
     } while (0)
         WR_DISPATCH_D(D, WR_CALL_HOTU);
 #undef WR_CALL_HOTU
         WR_LAUNCH_CHECK("bprmf_user_hot_*");
     }
-    if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[1]), stream));
     // hot pieces ride along as extra workgroups of the same launch (they only read the stash and write hotP)
     const dim3 gridBP(gridB.x + (have_hot ? (unsigned)hot.item.n_pieces : 0u));
 #define WR_CALL_ITEM(T_, NV_, FULL_)                                                                                   \
     do {                                                                                                               \
         if (have_hot)                                                                                                  \
-            hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE, true>), gridBP, block, lds_rows, stream, I, D,  \
-                               oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,        \
-                               (int)gridA.x, denom, loss_out, 1, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,      \
-                               hot.item.piece_q, hot.item.piece_len, w.hotP, ad);                                      \
+            WR_LAUNCH((bprmf_item_phase<T_, NV_, FULL_, MODE, true>), gridBP, lds_rows, ev(2), none, I, D,         \
+                      oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,                 \
+                      (int)gridA.x, denom, loss_out, 1, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,               \
+                      hot.item.piece_q, hot.item.piece_len, w.hotP, ad);                                               \
         else                                                                                                           \
-            hipLaunchKernelGGL((bprmf_item_phase<T_, NV_, FULL_, MODE, false>), gridB, block, 0, stream, I, D,         \
-                               oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,        \
-                               (int)gridA.x, denom, loss_out, 0, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,      \
-                               nullptr, nullptr, nullptr, ad);                                                         \
+            WR_LAUNCH((bprmf_item_phase<T_, NV_, FULL_, MODE, false>), gridB, 0, ev(2), ev(3), I, D,                  \
+                      oc_item, oc_src, (int)(2 * B), w.Z, lr, l2, gradI, stamp_i, step_id, w.partials,                 \
+                      (int)gridA.x, denom, loss_out, 0, have_hot_u ? w.hot_loss : nullptr, (int)gridB.x,               \
+                      (const int *)nullptr, (const int *)nullptr, (float *)nullptr, ad);                               \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_ITEM);
 #undef WR_CALL_ITEM
@@ -751,15 +768,15 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
         const unsigned grun = (unsigned)n_blocks_for(hot.item.n_runs, D);
 #define WR_CALL_HOT(T_, NV_, FULL_)                                                                                      \
     do {                                                                                                                \
-        hipLaunchKernelGGL((bprmf_item_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), block, 0, stream, I, D, oc_item,  \
-                           hot.item.run_q, hot.item.run_first, hot.item.run_np, hot.item.n_runs, w.hotP, lr, l2, gradI, \
-                           stamp_i, step_id, ad);                                                                       \
+        WR_LAUNCH((bprmf_item_hot_combine<T_, NV_, FULL_, MODE>), dim3(grun), 0, none, ev(3), I, D, oc_item,             \
+                  hot.item.run_q, hot.item.run_first, hot.item.run_np, hot.item.n_runs, w.hotP, lr, l2, gradI,          \
+                  stamp_i, step_id, ad);                                                                                \
     } while (0)
         WR_DISPATCH_D(D, WR_CALL_HOT);
 #undef WR_CALL_HOT
         WR_LAUNCH_CHECK("bprmf_item_hot_*");
     }
-    if (events) WR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(events[2]), stream));
+#undef WR_LAUNCH
     return WR_OK;
 }
 
@@ -852,7 +869,7 @@ int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int6
         const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
         rc = launch_step<0>(user_tab, item_tab, D, tu + off, tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk,
                             lr, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, loss_out ? loss_out + k : nullptr,
-                            workspace, stream, phase_events ? phase_events + 3 * k : nullptr, 0.f, hot_of(hot, b),
+                            workspace, stream, phase_events ? phase_events + 4 * k : nullptr, 0.f, hot_of(hot, b),
                             batch_size);
         if (rc != WR_OK) return rc;
     }

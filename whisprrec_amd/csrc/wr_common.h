@@ -147,10 +147,14 @@ __device__ __forceinline__ float dot_partial(const Row<NV> &a, const Row<NV> &b)
 // BPR per-triplet loss term and coefficient from the two scores (reference src/utils/loss.py:38 and its
 // autograd): term = -log(gamma + s), coef = -(s(1-s)/(gamma+s)) / B, s = sigmoid(pos-neg).
 __device__ __forceinline__ void bpr_terms(float pos, float neg, float batch_f, float &term, float &coef) {
+    // sigmoid, log and the two quotients on the hardware transcendental unit (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp):
+    // every lane of a team evaluates this for its triplet, and the libm expf / logf + three IEEE divisions cost ~10x the
+    // issue slots for a difference of 1e-7 relative (the parity bar is 1e-5).  exp overflow -> s = 0 -> coef = 0, as before.
     const float x = pos - neg;
-    const float s = 1.0f / (1.0f + expf(-x));
-    term = -logf(kGamma + s);
-    coef = -(s * (1.0f - s) / (kGamma + s)) / batch_f;
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.44269504088896341f));
+    const float gs = kGamma + s;
+    term = -0.693147180559945309f * __builtin_amdgcn_logf(gs);        // v_log_f32 is log2
+    coef = -(s * (1.0f - s) * __builtin_amdgcn_rcpf(gs)) * __builtin_amdgcn_rcpf(batch_f);
 }
 
 // Shape dispatch: picks <T, NV, FULL> for an embedding size D (multiple of 4, <= 1024).

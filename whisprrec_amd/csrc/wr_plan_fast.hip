@@ -65,6 +65,7 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
 }
 
 constexpr int kTile = 4096;       // elements of one batch handled by one scatter workgroup
+constexpr unsigned kBinShift = 2;   // counting-sort bins per bucket = capacity >> kBinShift
 constexpr int kMaxGroup = 32;     // longest run of equal rows a single thread orders by insertion (else: overflow)
 
 // Reserve bucket slots for a tile: ranks inside the tile come from LDS atomics, one global atomic per non-empty
@@ -165,32 +166,38 @@ __device__ __forceinline__ int pow2_ceil(int x) {
 #endif
 constexpr int kSortBlock = WR_SORT_BLOCK;   // threads of a bucket-sort workgroup (one bucket each)
 
-// exclusive prefix of this bucket's count inside its batch (sum of the counts of the buckets before it)
-__device__ __forceinline__ int bucket_prefix(const int *__restrict__ cnt_batch, int bucket, int cap, int *scratch) {
-    int a = 0;
-    for (int j = threadIdx.x; j < bucket; j += kSortBlock) a += min(cnt_batch[j], cap);
-    __syncthreads();
-    if (threadIdx.x == 0) scratch[0] = 0;
-    __syncthreads();
-    if (a) atomicAdd(&scratch[0], a);  // integer sum: order irrelevant
-    __syncthreads();
-    return scratch[0];
-}
-
-// Sorts the `count` composites of one bucket ascending, in LDS, into `out`:
-//   counting sort on the top `bin_bits` of the `low_bits` row bits that vary inside a bucket (about one composite per
-//   bin), then every bin's run is ordered on the full composite by one thread (insertion sort; runs are short in any
-//   non-degenerate batch).  `cnt` has 1 << bin_bits ints.  Runs longer than kMaxGroup raise the overflow flag.
-__device__ __forceinline__ void bucket_sort_lds(const unsigned long long *__restrict__ kin, unsigned long long *__restrict__ out,
-                                                int *__restrict__ cnt, int *__restrict__ wave_tot, int count, unsigned low_bits,
-                                                unsigned bin_bits, int *__restrict__ flags) {
+// Sorts the composites of one bucket (global `src`, `count` of them) ascending into the LDS array `out` and returns the
+// exclusive prefix of this bucket's count inside its batch (sum of the capped counts of the buckets before it):
+//   counting sort on the top `bin_bits` of the `low_bits` row bits that vary inside a bucket (about two composites per
+//   bin: fewer counters to clear, scan and walk than elements), then every bin's run is ordered on the full composite by
+//   one thread (insertion sort; runs are short in any non-degenerate batch).  `cnt` has 1 << bin_bits ints.  Runs longer
+//   than kMaxGroup raise the overflow flag.  A workgroup's lifetime is a chain of barriers and memory round trips, and
+//   16 K workgroups per plan chunk wait on it: the prefix's loads travel with the composites' and its partial sums share
+//   the barriers the sort needs anyway.
+__device__ __forceinline__ int bucket_sort_lds(const unsigned long long *__restrict__ src, const int *__restrict__ cnt_batch,
+                                               int bucket, int cap, unsigned long long *__restrict__ kin,
+                                               unsigned long long *__restrict__ out, int *__restrict__ cnt,
+                                               int *__restrict__ wave_tot, int *__restrict__ wave_pre, int count,
+                                               unsigned low_bits, unsigned bin_bits, int *__restrict__ flags) {
     const int nbin = 1 << bin_bits;
     const unsigned down = low_bits - bin_bits;
     const unsigned mask = (unsigned)nbin - 1u;
+    int a = 0;
+    for (int j = threadIdx.x; j < bucket; j += kSortBlock) a += min(cnt_batch[j], cap);
     for (int j = threadIdx.x; j < nbin; j += kSortBlock) cnt[j] = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);   // integer sum: order irrelevant
+    if ((threadIdx.x & 63) == 0) wave_pre[threadIdx.x >> 6] = a;
     __syncthreads();
-    for (int j = threadIdx.x; j < count; j += kSortBlock) atomicAdd(&cnt[((unsigned)(kin[j] >> 32) >> down) & mask], 1);
+    for (int j = threadIdx.x; j < count; j += kSortBlock) {
+        const unsigned long long kv = src[j];
+        kin[j] = kv;
+        atomicAdd(&cnt[((unsigned)(kv >> 32) >> down) & mask], 1);
+    }
     __syncthreads();
+    int prefix = 0;
+#pragma unroll
+    for (int w = 0; w < kSortBlock / 64; ++w) prefix += wave_pre[w];
     // exclusive scan of cnt[0..nbin): thread t owns counters [t*per, (t+1)*per)
     const int per = (nbin + kSortBlock - 1) / kSortBlock;
     const int c0 = threadIdx.x * per;
@@ -239,6 +246,7 @@ __device__ __forceinline__ void bucket_sort_lds(const unsigned long long *__rest
         }
     }
     __syncthreads();
+    return prefix;
 }
 
 template <typename Idx>
@@ -249,8 +257,7 @@ __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restri
                                                           int *__restrict__ tu, int *__restrict__ tp, int *__restrict__ tn,
                                                           int *__restrict__ torig, int *__restrict__ flags) {
     extern __shared__ unsigned long long lds[];  // kin[cap] | out[cap] | cnt[1<<shift] (ints)
-    __shared__ int scratch[1];
-    __shared__ int wave_tot[kSortBlock / 64];
+    __shared__ int wave_tot[kSortBlock / 64], wave_pre[kSortBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_u;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_u);
     // the buckets of one batch gather p[] / n[] from the same 2 x 4B x B bytes: keep them on one XCD's L2
@@ -258,12 +265,9 @@ __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restri
     const int64_t b = lb / nbk;
     const int bucket = lb % nbk;
     const int count = min(cnt_u[lb], cap_u);
-    const int prefix = bucket_prefix(cnt_u + b * nbk, bucket, cap_u, scratch);
     if (count == 0) return;
-    const unsigned long long *src = ubuf + (int64_t)lb * cap_u;
-    for (int j = threadIdx.x; j < count; j += kSortBlock) kin[j] = src[j];
-    __syncthreads();
-    bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_u, bin_bits, flags);
+    const int prefix = bucket_sort_lds(ubuf + (int64_t)lb * cap_u, cnt_u + b * nbk, bucket, cap_u, kin, out, cnt, wave_tot,
+                                       wave_pre, count, shift_u, bin_bits, flags);
     for (int r = threadIdx.x; r < count; r += kSortBlock) {
         const unsigned long long kv = out[r];
         const uint32_t orig = (uint32_t)kv;
@@ -287,8 +291,7 @@ __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t 
                                                           int *__restrict__ oc_item, int *__restrict__ oc_src, int *__restrict__ tp,
                                                           int *__restrict__ tn, int *__restrict__ flags) {
     extern __shared__ unsigned long long lds[];
-    __shared__ int scratch[1];
-    __shared__ int wave_tot[kSortBlock / 64];
+    __shared__ int wave_tot[kSortBlock / 64], wave_pre[kSortBlock / 64];
     unsigned long long *kin = lds, *out = lds + cap_i;
     int *cnt = reinterpret_cast<int *>(lds + 2 * cap_i);
     // the buckets of one batch set flag bits all over the batch's tp[] / tn[]: keep them on one XCD's L2
@@ -296,12 +299,9 @@ __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t 
     const int64_t b = lb / nbk;
     const int bucket = lb % nbk;
     const int count = min(cnt_i[lb], cap_i);
-    const int prefix = bucket_prefix(cnt_i + b * nbk, bucket, cap_i, scratch);
     if (count == 0) return;
-    const unsigned long long *src = ibuf + (int64_t)lb * cap_i;
-    for (int j = threadIdx.x; j < count; j += kSortBlock) kin[j] = src[j];
-    __syncthreads();
-    bucket_sort_lds(kin, out, cnt, wave_tot, count, shift_i, bin_bits, flags);
+    const int prefix = bucket_sort_lds(ibuf + (int64_t)lb * cap_i, cnt_i + b * nbk, bucket, cap_i, kin, out, cnt, wave_tot,
+                                       wave_pre, count, shift_i, bin_bits, flags);
     const int64_t base = 2 * b * B + prefix;
     for (int r = threadIdx.x; r < count; r += kSortBlock) {
         const unsigned long long kv = out[r];
@@ -343,11 +343,13 @@ static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_
     hipLaunchKernelGGL((fast_user_scatter<Idx>), dim3((unsigned)(L.nb * tiles_u)), dim3(kBlock), 0, stream, u, n, B, tiles_u,
                        L.nbk, n_users, L.shift_u, L.cap_u, cnt_u, ubuf, flags);
     WR_LAUNCH_CHECK("fast_user_scatter");
-    // bins per bucket: about one composite per bin (twice the mean bucket population, power of two), never more
-    // bins than distinct low-bit patterns
+    // bins per bucket: capacity / 4 (capacity = twice the mean bucket population -> about two composites per bin;
+    // A/B at the headline shape: 1 per bin 7.0 us of plan per batch, 2 per bin 6.35, 4 per bin 6.6), never more bins
+    // than distinct low-bit patterns
     auto bins_for = [](int cap, unsigned shift) {
         unsigned b = 0;
         while ((1 << b) < cap) ++b;
+        b = b > kBinShift + 4 ? b - kBinShift : b;
         return b < shift ? b : shift;
     };
     const unsigned bb_u = bins_for(L.cap_u, L.shift_u), bb_i = bins_for(L.cap_i, L.shift_i);

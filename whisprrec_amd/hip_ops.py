@@ -299,8 +299,8 @@ class BprmfTables:
     def run_sgd(self, plan, first, count, lr, losses=None, phase_events=None):
         """`count` consecutive steps starting at batch `first` (native inner loop of BaseRunner.fit, l2 = 0).
 
-        phase_events: optional list of 3*count ``torch.cuda.Event(enable_timing=True)`` recorded around the two
-        kernels of every step (per-kernel timing for bench.py)."""
+        phase_events: optional list of 4*count ``torch.cuda.Event(enable_timing=True)`` or None entries: per step the
+        start / stop events of its two phases (include/whisprrec_hip.h; bench.py's per-kernel timing)."""
         L = abi.lib()
         ws = self._ws(plan.batch_size)
         if losses is None:
@@ -308,10 +308,13 @@ class BprmfTables:
         hot = plan.hot_struct()
         ev = None
         if phase_events is not None:
-            if len(phase_events) != 3 * count:
-                raise ValueError("phase_events must hold 3 events per step")
+            if len(phase_events) != 4 * count:
+                raise ValueError("phase_events must hold 4 events per step")
             handles = []
             for e in phase_events:
+                if e is None:
+                    handles.append(None)
+                    continue
                 if not e.cuda_event:  # torch creates the hipEvent_t lazily on first record
                     e.record()
                 handles.append(e.cuda_event)
