@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of two builds of libwhisprrec_hip.so on the headline step (run on the GPU box): per-kernel durations from HIP
-events around the kernels, several repetitions interleaved.  usage: ab_step.py [--shape USERS,ITEMS]... libA.so libB.so"""
+events around the kernels, several repetitions interleaved.  usage: ab_step.py [--shape USERS,ITEMS[,D]]... libA.so libB.so"""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -12,7 +12,7 @@ import torch
 from whisprrec_amd import hip_ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(3407)
-nU, nI = int(sys.argv[2]), int(sys.argv[3]); D = 64; B = 65536; NB = 64
+nU, nI = int(sys.argv[2]), int(sys.argv[3]); D = int(sys.argv[4]); B = 65536; NB = 64
 U = torch.randn(nU, D, generator=g, device=dev) * 0.01; I = torch.randn(nI, D, generator=g, device=dev) * 0.01
 u = torch.randint(0, nU, (NB * B,), generator=g, device=dev, dtype=torch.int32)
 p = torch.randint(0, nI, (NB * B,), generator=g, device=dev, dtype=torch.int32)
@@ -46,6 +46,6 @@ libs = argv
 for shape in shapes:
     for rnd in range(2):
         for lib in libs:
-            r = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(lib), shape[0], shape[1]], capture_output=True, text=True)
+            r = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(lib), shape[0], shape[1], shape[2] if len(shape) > 2 else "64"], capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             print(shape, os.path.basename(lib), line[-1] if line else r.stderr[-400:], flush=True)

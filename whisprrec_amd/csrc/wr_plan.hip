@@ -95,16 +95,13 @@ __global__ __launch_bounds__(kBlock) void plan_unpack_item(const Key *__restrict
 constexpr int kHotRun = 32;     // must match wr_bpr.hip
 constexpr int kHotPiece = 256;
 
-// One thread per sorted position: the head of a run longer than kHotRun finds the run's end by binary search in its
-// batch's (ascending) key array and appends the run, cut into pieces of kHotPiece, to the batch's hot lists.
+// The head of a run longer than kHotRun finds the run's end by binary search in its batch's (ascending) key array and
+// appends the run, cut into pieces of kHotPiece, to the batch's hot lists.
 // mult = 2 for the item occurrences (2B positions per batch), 1 for the user-sorted triplets (B per batch).
-__global__ __launch_bounds__(kBlock) void plan_hot_runs_kernel(const int *__restrict__ keys, int64_t n, int64_t B, int mult,
-                                                                int64_t cap_pieces, int64_t cap_runs, int *__restrict__ piece_q,
-                                                                int *__restrict__ piece_len, int *__restrict__ run_q,
-                                                                int *__restrict__ run_first, int *__restrict__ run_np,
-                                                                int *__restrict__ counts, int count_stride) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= mult * n) return;
+__device__ __forceinline__ void hot_run_at(const int *__restrict__ keys, int64_t i, int64_t n, int64_t B, int mult,
+                                           int64_t cap_pieces, int64_t cap_runs, int *__restrict__ piece_q,
+                                           int *__restrict__ piece_len, int *__restrict__ run_q, int *__restrict__ run_first,
+                                           int *__restrict__ run_np, int *__restrict__ counts, int count_stride) {
     const int64_t b = i / (mult * B);
     const int64_t base = mult * b * B;
     const int64_t Bb = (b * B + B <= n) ? B : (n - b * B);
@@ -131,6 +128,31 @@ __global__ __launch_bounds__(kBlock) void plan_hot_runs_kernel(const int *__rest
     run_q[b * cap_runs + ridx] = q0;
     run_first[b * cap_runs + ridx] = first;
     run_np[b * cap_runs + ridx] = np;
+}
+
+// One thread per four sorted positions.  Almost no position starts a hot run, so the common case is decided from two
+// 16-byte loads (positions i..i+3 and i+kHotRun..i+kHotRun+3): a key that differs from the key kHotRun positions on
+// cannot head a run that long.  Groups that may hold one (or that touch a batch's end) take the exact per-position path.
+__global__ __launch_bounds__(kBlock) void plan_hot_runs_kernel(const int *__restrict__ keys, int64_t n, int64_t B, int mult,
+                                                                int64_t cap_pieces, int64_t cap_runs, int *__restrict__ piece_q,
+                                                                int *__restrict__ piece_len, int *__restrict__ run_q,
+                                                                int *__restrict__ run_first, int *__restrict__ run_np,
+                                                                int *__restrict__ counts, int count_stride) {
+    static_assert(kHotRun % 4 == 0, "the far load must stay 16-byte aligned");
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    const int64_t total = mult * n;
+    if (i >= total) return;
+    if ((reinterpret_cast<uintptr_t>(keys) & 15) == 0 && i + 3 + kHotRun < total) {
+        const int4 a = *reinterpret_cast<const int4 *>(keys + i);
+        const int4 f = *reinterpret_cast<const int4 *>(keys + i + kHotRun);
+        // within a batch keys ascend, so keys[i] == keys[i + kHotRun] is necessary for a run head at i; across a batch
+        // boundary the test can only err towards the exact path
+        if (a.x != f.x && a.y != f.y && a.z != f.z && a.w != f.w) return;
+    }
+    for (int j = 0; j < 4; ++j)
+        if (i + j < total)
+            hot_run_at(keys, i + j, n, B, mult, cap_pieces, cap_runs, piece_q, piece_len, run_q, run_first, run_np, counts,
+                       count_stride);
 }
 
 struct PlanLayout {
@@ -245,7 +267,7 @@ int32_t wr_bprmf_plan_hot_runs(const int32_t *keys, int32_t kind, int64_t n_trip
     wr_bprmf_hot_caps(batch_size, kind, &cp, &cr);
     const int mult = kind == 0 ? 2 : 1;
     const int64_t total = mult * n_triplets;
-    hipLaunchKernelGGL(plan_hot_runs_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(plan_hot_runs_kernel, dim3((unsigned)((total + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), keys, n_triplets, batch_size, mult, cp, cr, piece_q, piece_len,
                        run_q, run_first, run_np, counts + (kind == 0 ? 0 : 2), 4);
     WR_LAUNCH_CHECK("plan_hot_runs_kernel");

@@ -64,7 +64,10 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
     return true;
 }
 
-constexpr int kTile = 4096;       // elements of one batch handled by one scatter workgroup
+#ifndef WR_PLAN_TILE
+#define WR_PLAN_TILE 4096
+#endif
+constexpr int kTile = WR_PLAN_TILE;       // elements of one batch handled by one scatter workgroup
 constexpr unsigned kBinShift = 2;   // counting-sort bins per bucket = capacity >> kBinShift
 constexpr int kMaxGroup = 32;     // longest run of equal rows a single thread orders by insertion (else: overflow)
 

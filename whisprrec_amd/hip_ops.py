@@ -153,20 +153,29 @@ class BatchPlan:
         if builder == "auto" and _FAST_BACKOFF.get(backoff_key, 0) > 0:
             _FAST_BACKOFF[backoff_key] -= 1
             builder = "generic"
+        self.meta_host = None
         if builder in ("auto", "fast"):
             nbytes = abi.check_size(L.wr_bprmf_plan_fast_workspace_bytes(*args), "wr_bprmf_plan_fast_workspace_bytes")
             if nbytes > 0:
                 ws = workspace(dev, ws_tag + "_fast").get(nbytes)
+                sides = self._hot_arrays(dev) if hot else None
                 fn = L.wr_bprmf_plan_build_fast_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_i32
                 abi.check(fn(_p(u), _p(p), _p(n), *args, _p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig),
                              _p(self.oc_item), _p(self.oc_src), _p(self.flags), _p(ws), ws.numel(), _stream()),
                           "wr_bprmf_plan_build_fast")
-                if int(self.flags[1].item()) == 0:   # one sync of the building stream per chunk of batches
+                # ONE read-back per plan: the overflow flag travels with the hot-run counts (the hot-run scan is bounds-safe
+                # for any key values; after an overflow its output is thrown away with the plan)
+                if hot:
+                    self._plan_hot_runs(dev, sides)
+                else:
+                    self.meta_host = self.meta.cpu()
+                if int(self.meta_host[1]) == 0:
                     self.builder = "fast"
                 elif builder == "fast":
                     raise abi.WhisprRecHipError("fast plan builder: bucket overflow (skewed ids)")
                 else:
-                    self.flags.zero_()
+                    self.meta.zero_()
+                    self.meta_host, self.hot = None, None
                     _FAST_BACKOFF[backoff_key] = 32
             elif builder == "fast":
                 raise abi.WhisprRecHipError("fast plan builder not applicable to this batch size")
@@ -178,30 +187,38 @@ class BatchPlan:
                          _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(), _stream()),
                       "wr_bprmf_plan_build")
             self.builder = "generic"
-        self.meta_host = None
-        if hot:
-            self._plan_hot_runs(dev)
+            if hot:
+                self._plan_hot_runs(dev)
         if validate:
             self.validate()
 
-    def _plan_hot_runs(self, dev):
-        """Cuts table rows with more than 32 occurrences in a batch (item rows: runs of oc_item; user rows: runs of tu) into
-        pieces for the many-workgroup path (power-law ids); one device-to-host copy of the small meta tensor tells whether
-        there are any."""
+    def _hot_arrays(self, dev):
+        """list arrays of the hot-run scan, allocated BEFORE the plan kernels are enqueued so that the scan follows the build
+        on the stream without a host-side allocation between them"""
         L = abi.lib()
         i32 = dict(dtype=torch.int32, device=dev)
-        counts = self.meta[2:]
         sides = []
-        for kind, keys in ((0, self.oc_item), (1, self.tu)):
+        for kind in (0, 1):
             cp, cr = ctypes.c_int64(0), ctypes.c_int64(0)
             L.wr_bprmf_hot_caps(self.batch_size, kind, ctypes.addressof(cp), ctypes.addressof(cr))
             cp, cr = cp.value, cr.value
             arrs = [torch.empty(self.n_batches * cp, **i32), torch.empty(self.n_batches * cp, **i32),
                     torch.empty(self.n_batches * cr, **i32), torch.empty(self.n_batches * cr, **i32),
                     torch.empty(self.n_batches * cr, **i32)]
+            sides.append((arrs, cp, cr))
+        return sides
+
+    def _plan_hot_runs(self, dev, sides=None):
+        """Cuts table rows with more than 32 occurrences in a batch (item rows: runs of oc_item; user rows: runs of tu) into
+        pieces for the many-workgroup path (power-law ids); one device-to-host copy of the small meta tensor tells whether
+        there are any."""
+        L = abi.lib()
+        counts = self.meta[2:]
+        if sides is None:
+            sides = self._hot_arrays(dev)
+        for (kind, keys), (arrs, _, _) in zip(((0, self.oc_item), (1, self.tu)), sides):
             abi.check(L.wr_bprmf_plan_hot_runs(_p(keys), kind, self.n_triplets, self.batch_size, *[_p(a) for a in arrs],
                                                _p(counts), _stream()), "wr_bprmf_plan_hot_runs")
-            sides.append((arrs, cp, cr))
         self.meta_host = self.meta.cpu()
         counts_host = self.meta_host[2:].contiguous()
         if int(counts_host.sum().item()) > 0:
