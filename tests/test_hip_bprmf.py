@@ -484,3 +484,35 @@ def test_long_runs_with_and_without_hot_list(ops, dev, hot):
     tabs2.grads(plan, 0, gU, gI)
     rU, rI, _ = oracle.bpr_dense_grads(U, I, u, p, n)
     assert rel_err(gU.cpu().numpy(), rU) < TOL and rel_err(gI.cpu().numpy(), rI) < TOL
+
+
+@pytest.mark.parametrize("zipf", [False, True])
+def test_phase_events_attached_to_dispatches(ops, dev, zipf):
+    """wr_bprmf_run_sgd's timing hooks (include/whisprrec_hip.h): four events per step attached to the kernels as start / stop
+    events, any of them None; they must not change the result, and the intervals must be ordered and positive — also when the
+    phases have several kernels (hot rows: pieces + combine)."""
+    rng = np.random.RandomState(5)
+    nU, nI, D, B, NB = 3000, 2000, 64, 4096, 3
+    U = (rng.standard_normal((nU, D)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((nI, D)) * 0.1).astype(np.float32)
+    u, p, n = rng.randint(0, nU, NB * B), rng.randint(0, nI, NB * B), rng.randint(1, nI, NB * B)
+    if zipf:
+        p[: NB * B // 2] = 7          # a hot item row in every batch
+        u[::3] = 11                   # and a hot user row
+    plan = ops.BatchPlan(T(u.astype(np.int32), dev), T(p.astype(np.int32), dev), T(n.astype(np.int32), dev), B, nU, nI)
+    assert (plan.hot is not None) == zipf
+    ref = ops.BprmfTables(T(U, dev), T(I, dev))
+    l_ref = ref.run_sgd(plan, 0, NB, 0.1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * NB)]
+    ev[4] = None                      # holes are allowed
+    tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+    l_ev = tabs.run_sgd(plan, 0, NB, 0.1, phase_events=ev)
+    torch.cuda.synchronize()
+    assert torch.equal(tabs.U, ref.U) and torch.equal(tabs.I, ref.I) and torch.equal(l_ev, l_ref)
+    for k in range(NB):
+        if ev[4 * k] is not None:
+            assert ev[4 * k].elapsed_time(ev[4 * k + 1]) > 0             # user phase
+        assert ev[4 * k + 2].elapsed_time(ev[4 * k + 3]) > 0             # item phase
+        assert ev[4 * k + 1].elapsed_time(ev[4 * k + 3]) > 0             # user phase ends before the item phase does
+    with pytest.raises(ValueError):
+        tabs.run_sgd(plan, 0, NB, 0.1, phase_events=ev[:3 * NB])
