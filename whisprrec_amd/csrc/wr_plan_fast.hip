@@ -24,7 +24,7 @@
 namespace wr {
 
 constexpr int kMaxBuckets = 1024;  // row-range buckets per batch: 256 up to B = 128 K, 1024 beyond
-constexpr int kMaxCap = 4096;    // largest bucket handled in LDS (2 x 32 KiB of 8-byte composites + counters)
+constexpr int kMaxCap = 4096;    // largest bucket handled by one workgroup (32 KiB of 8-byte composites in LDS, 16 per thread in registers)
 
 struct FastLayout {
     int nbk;                  // buckets per batch (power of two)
@@ -69,7 +69,10 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
 #define WR_PLAN_TILE 4096
 #endif
 constexpr int kTile = WR_PLAN_TILE;       // elements of one batch handled by one scatter workgroup
-constexpr unsigned kBinShift = 2;   // counting-sort bins per bucket = capacity >> kBinShift
+#ifndef WR_PLAN_BINSHIFT
+#define WR_PLAN_BINSHIFT 2
+#endif
+constexpr unsigned kBinShift = WR_PLAN_BINSHIFT;   // counting-sort bins per bucket = capacity >> kBinShift
 constexpr int kMaxGroup = 32;     // longest run of equal rows a single thread orders by insertion (else: overflow)
 
 // Appends a tile's composites to their buckets.  Ranks inside the tile come from LDS atomics and ONE global atomic per
@@ -203,33 +206,47 @@ __device__ __forceinline__ int pow2_ceil(int x) {
 #endif
 constexpr int kSortBlock = WR_SORT_BLOCK;   // threads of a bucket-sort workgroup (one bucket each)
 
-// Sorts the composites of one bucket (global `src`, `count` of them) ascending into the LDS array `out` and returns the
-// exclusive prefix of this bucket's count inside its batch (sum of the capped counts of the buckets before it):
-//   counting sort on the top `bin_bits` of the `low_bits` row bits that vary inside a bucket (about two composites per
-//   bin: fewer counters to clear, scan and walk than elements), then every bin's run is ordered on the full composite by
-//   one thread (insertion sort; runs are short in any non-degenerate batch).  `cnt` has 1 << bin_bits ints.  Runs longer
-//   than kMaxGroup raise the overflow flag.  A workgroup's lifetime is a chain of barriers and memory round trips, and
-//   16 K workgroups per plan chunk wait on it: the prefix's loads travel with the composites' and its partial sums share
-//   the barriers the sort needs anyway.
-__device__ __forceinline__ int bucket_sort_lds(const unsigned long long *__restrict__ src, const int *__restrict__ cnt_batch,
-                                               int bucket, int cap, unsigned long long *__restrict__ kin,
-                                               unsigned long long *__restrict__ out, int *__restrict__ cnt,
-                                               int *__restrict__ wave_tot, int *__restrict__ wave_pre, int count,
-                                               unsigned low_bits, unsigned bin_bits, int *__restrict__ flags) {
-    const int nbin = 1 << bin_bits;
-    const unsigned down = low_bits - bin_bits;
-    const unsigned mask = (unsigned)nbin - 1u;
+// One bucket per workgroup; every thread keeps its (up to PER) composites in registers from load to output.
+//   1. the capped counts of the buckets before this one are summed (the bucket's prefix inside its batch) while the bin
+//      counters are cleared; the composites are loaded and histogrammed on the top `bin_bits` of the `low_bits` row bits
+//      that vary inside a bucket (about two composites per bin: fewer counters to clear and scan than composites);
+//      `early(k, composite)` runs right behind the load — the user sort issues its p[] / n[] gathers there, so that they
+//      fly during the LDS phases instead of forming a fourth memory round trip at the end (22 of 66 us);
+//   2. exclusive scan of the bin counters, placement of the composites into `out` grouped by bin (LDS atomics);
+//   3. rank_in_bin(): every composite counts the smaller composites of its bin (unique composites: the counts are the
+//      ranks) — its sorted position — and its thread writes the outputs for that position straight from registers.
+//      One thread per COMPOSITE with independent LDS reads: one thread per BIN running an insertion sort (serial,
+//      dependent LDS traffic, the rest of the wave idle behind the longest bin) took 21 of the item sort's 70 us.
+// Bins longer than kMaxGroup raise the overflow flag (degenerate batch: the caller rebuilds with the generic builder).
+// A workgroup's lifetime is a chain of barriers and memory round trips, and 16 K workgroups per plan chunk wait on it.
+struct BinMap {
+    unsigned down, mask;
+    __device__ __forceinline__ int of(unsigned long long kv) const { return (int)(((unsigned)(kv >> 32) >> down) & mask); }
+};
+
+template <int PER, typename Early>
+__device__ __forceinline__ int bucket_bins(const unsigned long long *__restrict__ src, const int *__restrict__ cnt_batch,
+                                           int bucket, int cap, unsigned long long *__restrict__ out, int *__restrict__ cnt,
+                                           int *__restrict__ wave_tot, int *__restrict__ wave_pre, int count, int nbin,
+                                           const BinMap bm, unsigned long long (&kv)[PER], Early early) {
     int a = 0;
     for (int j = threadIdx.x; j < bucket; j += kSortBlock) a += min(cnt_batch[j], cap);
     for (int j = threadIdx.x; j < nbin; j += kSortBlock) cnt[j] = 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);   // integer sum: order irrelevant
     if ((threadIdx.x & 63) == 0) wave_pre[threadIdx.x >> 6] = a;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int j = threadIdx.x + k * kSortBlock;
+        kv[k] = (j < count) ? src[j] : ~0ull;
+    }
     __syncthreads();
-    for (int j = threadIdx.x; j < count; j += kSortBlock) {
-        const unsigned long long kv = src[j];
-        kin[j] = kv;
-        atomicAdd(&cnt[((unsigned)(kv >> 32) >> down) & mask], 1);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if ((int)threadIdx.x + k * kSortBlock < count) {
+            early(k, kv[k]);
+            atomicAdd(&cnt[bm.of(kv[k])], 1);
+        }
     }
     __syncthreads();
     int prefix = 0;
@@ -258,99 +275,119 @@ __device__ __forceinline__ int bucket_sort_lds(const unsigned long long *__restr
             run += c;
         }
     __syncthreads();
-    for (int j = threadIdx.x; j < count; j += kSortBlock) {
-        const unsigned long long kv = kin[j];
-        out[atomicAdd(&cnt[((unsigned)(kv >> 32) >> down) & mask], 1)] = kv;
-    }
-    __syncthreads();
-    // after placement cnt[b] is the END of bin b; its start is the end of bin b-1
-    for (int bin = threadIdx.x; bin < nbin; bin += kSortBlock) {
-        const int r = bin ? cnt[bin - 1] : 0;
-        const int m = cnt[bin] - r;
-        if (m < 2) continue;
-        if (m > kMaxGroup) {
-            flags[1] = 1;
-            continue;
-        }
-        for (int a = 1; a < m; ++a) {  // insertion sort of out[r .. r+m)
-            const unsigned long long x = out[r + a];
-            int bpos = a - 1;
-            while (bpos >= 0 && out[r + bpos] > x) {
-                out[r + bpos + 1] = out[r + bpos];
-                --bpos;
-            }
-            out[r + bpos + 1] = x;
-        }
-    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if ((int)threadIdx.x + k * kSortBlock < count) out[atomicAdd(&cnt[bm.of(kv[k])], 1)] = kv[k];
     __syncthreads();
     return prefix;
 }
 
-template <typename Idx>
+// After placement cnt[b] is the END of bin b; its start is the end of bin b-1.  Returns the sorted position of `kv` inside
+// the bucket (-1: its bin is longer than kMaxGroup) and the number of composites of the bin with the same row id.
+__device__ __forceinline__ int rank_in_bin(const unsigned long long *__restrict__ out, const int *__restrict__ cnt,
+                                           const BinMap bm, unsigned long long kv, int &same_row) {
+    const int bin = bm.of(kv);
+    const int lo = bin ? cnt[bin - 1] : 0;
+    const int hi = cnt[bin];
+    same_row = 1;
+    if (hi - lo == 1) return lo;
+    if (hi - lo > kMaxGroup) return -1;
+    int pos = lo, same = 0;
+    for (int j = lo; j < hi; ++j) {
+        const unsigned long long o = out[j];
+        pos += (o < kv) ? 1 : 0;
+        same += ((unsigned)(o >> 32) == (unsigned)(kv >> 32)) ? 1 : 0;
+    }
+    same_row = same;
+    return pos;
+}
+
+template <typename Idx, int PER>
 __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restrict__ p, const Idx *__restrict__ nn, int64_t n,
                                                           int64_t B, int nbk, int64_t n_items, int cap_u, unsigned shift_u,
                                                           unsigned bin_bits,
                                                           const int *__restrict__ cnt_u, const unsigned long long *__restrict__ ubuf,
                                                           int *__restrict__ tu, int *__restrict__ tp, int *__restrict__ tn,
                                                           int *__restrict__ torig, int *__restrict__ flags) {
-    extern __shared__ unsigned long long lds[];  // kin[cap] | out[cap] | cnt[1<<shift] (ints)
+    extern __shared__ unsigned long long lds[];  // out[cap] | cnt[1 << bin_bits] (ints)
     __shared__ int wave_tot[kSortBlock / 64], wave_pre[kSortBlock / 64];
-    unsigned long long *kin = lds, *out = lds + cap_u;
-    int *cnt = reinterpret_cast<int *>(lds + 2 * cap_u);
+    unsigned long long *out = lds;
+    int *cnt = reinterpret_cast<int *>(lds + cap_u);
     // the buckets of one batch gather p[] / n[] from the same 2 x 4B x B bytes: keep them on one XCD's L2
     const unsigned lb = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int64_t b = lb / nbk;
     const int bucket = lb % nbk;
     const int count = min(cnt_u[lb], cap_u);
     if (count == 0) return;
-    const int prefix = bucket_sort_lds(ubuf + (int64_t)lb * cap_u, cnt_u + b * nbk, bucket, cap_u, kin, out, cnt, wave_tot,
-                                       wave_pre, count, shift_u, bin_bits, flags);
-    for (int r = threadIdx.x; r < count; r += kSortBlock) {
-        const unsigned long long kv = out[r];
-        const uint32_t orig = (uint32_t)kv;
+    const BinMap bm{shift_u - bin_bits, (1u << bin_bits) - 1u};
+    unsigned long long kv[PER];
+    Idx pv[PER], nv[PER];
+    const int prefix = bucket_bins<PER>(ubuf + (int64_t)lb * cap_u, cnt_u + b * nbk, bucket, cap_u, out, cnt, wave_tot, wave_pre,
+                                        count, 1 << bin_bits, bm, kv, [&](int k, unsigned long long c) {
+                                            pv[k] = p[(uint32_t)c];
+                                            nv[k] = nn[(uint32_t)c];
+                                        });
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if ((int)threadIdx.x + k * kSortBlock >= count) continue;
+        int same;
+        const int r = rank_in_bin(out, cnt, bm, kv[k], same);
+        if (r < 0) {
+            flags[1] = 1;
+            continue;
+        }
         const int64_t t = b * B + prefix + r;  // position in the user-sorted batch
-        int64_t pi = (int64_t)p[orig], ni = (int64_t)nn[orig];
+        int64_t pi = (int64_t)pv[k], ni = (int64_t)nv[k];
         if (pi < 0 || pi >= n_items || ni < 0 || ni >= n_items) {
             flags[0] = 1;
             pi = (pi < 0 || pi >= n_items) ? 0 : pi;
             ni = (ni < 0 || ni >= n_items) ? 0 : ni;
         }
-        tu[t] = (int)(kv >> 32);
+        tu[t] = (int)(kv[k] >> 32);
         tp[t] = (int)pi;
         tn[t] = (int)ni;
-        if (torig) torig[t] = (int)orig;
+        if (torig) torig[t] = (int)(uint32_t)kv[k];
     }
 }
 
+template <int PER>
 __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t B, int nbk, int cap_i, unsigned shift_i,
                                                           unsigned bin_bits,
                                                           const int *__restrict__ cnt_i, const unsigned long long *__restrict__ ibuf,
                                                           int *__restrict__ oc_item, int *__restrict__ oc_src, int *__restrict__ tp,
                                                           int *__restrict__ tn, int *__restrict__ flags) {
-    extern __shared__ unsigned long long lds[];
+    extern __shared__ unsigned long long lds[];  // out[cap] | cnt[1 << bin_bits] (ints)
     __shared__ int wave_tot[kSortBlock / 64], wave_pre[kSortBlock / 64];
-    unsigned long long *kin = lds, *out = lds + cap_i;
-    int *cnt = reinterpret_cast<int *>(lds + 2 * cap_i);
+    unsigned long long *out = lds;
+    int *cnt = reinterpret_cast<int *>(lds + cap_i);
     // the buckets of one batch set flag bits all over the batch's tp[] / tn[]: keep them on one XCD's L2
     const unsigned lb = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int64_t b = lb / nbk;
     const int bucket = lb % nbk;
     const int count = min(cnt_i[lb], cap_i);
     if (count == 0) return;
-    const int prefix = bucket_sort_lds(ibuf + (int64_t)lb * cap_i, cnt_i + b * nbk, bucket, cap_i, kin, out, cnt, wave_tot,
-                                       wave_pre, count, shift_i, bin_bits, flags);
+    const BinMap bm{shift_i - bin_bits, (1u << bin_bits) - 1u};
+    unsigned long long kv[PER];
+    const int prefix = bucket_bins<PER>(ibuf + (int64_t)lb * cap_i, cnt_i + b * nbk, bucket, cap_i, out, cnt, wave_tot, wave_pre,
+                                        count, 1 << bin_bits, bm, kv, [](int, unsigned long long) {});
     const int64_t base = 2 * b * B + prefix;
-    for (int r = threadIdx.x; r < count; r += kSortBlock) {
-        const unsigned long long kv = out[r];
-        const int item = (int)(kv >> 32);
-        const uint32_t lo = (uint32_t)kv;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if ((int)threadIdx.x + k * kSortBlock >= count) continue;
+        int same;
+        const int r = rank_in_bin(out, cnt, bm, kv[k], same);
+        if (r < 0) {
+            flags[1] = 1;
+            continue;
+        }
+        const int item = (int)(kv[k] >> 32);
+        const uint32_t lo = (uint32_t)kv[k];
         const int side = (int)(lo >> 31);
         const int tloc = (int)(lo & 0x7fffffffu);
         oc_item[base + r] = item;
         oc_src[base + r] = (tloc << 1) | side;
-        // equal items always share a bucket, so neighbours inside the sorted bucket decide "several occurrences"
-        const bool shared = (r > 0 && (int)(out[r - 1] >> 32) == item) || (r + 1 < count && (int)(out[r + 1] >> 32) == item);
-        if (shared) {
+        // equal items always share a bucket AND a bin: another composite of the bin with this item = "several occurrences"
+        if (same > 1) {
             int *dst = side ? tn : tp;
             dst[b * B + tloc] |= (int)0x80000000;  // one writer per (triplet, side)
         }
@@ -390,16 +427,30 @@ static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_
         return b < shift ? b : shift;
     };
     const unsigned bb_u = bins_for(L.cap_u, L.shift_u), bb_i = bins_for(L.cap_i, L.shift_i);
-    const size_t lds_u = (size_t)L.cap_u * 16 + ((size_t)4 << bb_u);
-    const size_t lds_i = (size_t)L.cap_i * 16 + ((size_t)4 << bb_i);
-    hipLaunchKernelGGL((fast_user_sort<Idx>), dim3(gb), dim3(kSortBlock), lds_u, stream, p, nn, n, B, L.nbk, n_items, L.cap_u,
-                       L.shift_u, bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags);
+    const size_t lds_u = (size_t)L.cap_u * 8 + ((size_t)4 << bb_u);
+    const size_t lds_i = (size_t)L.cap_i * 8 + ((size_t)4 << bb_i);
+    // composites per thread of a bucket workgroup (registers): instantiations for the capacities that occur
+    const int per_u = (L.cap_u + kSortBlock - 1) / kSortBlock, per_i = (L.cap_i + kSortBlock - 1) / kSortBlock;
+#define WR_USER_SORT(PER_)                                                                                                 \
+    hipLaunchKernelGGL((fast_user_sort<Idx, PER_>), dim3(gb), dim3(kSortBlock), lds_u, stream, p, nn, n, B, L.nbk, n_items,  \
+                       L.cap_u, L.shift_u, bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags)
+    if (per_u <= 3) WR_USER_SORT(3);
+    else if (per_u <= 5) WR_USER_SORT(5);
+    else if (per_u <= 9) WR_USER_SORT(9);
+    else WR_USER_SORT(kMaxCap / kSortBlock);
+#undef WR_USER_SORT
     WR_LAUNCH_CHECK("fast_user_sort");
     hipLaunchKernelGGL(fast_item_scatter, dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B, tiles_i,
                        L.nbk, n_items, L.shift_i, L.cap_i, cnt_i, ibuf, flags);
     WR_LAUNCH_CHECK("fast_item_scatter");
-    hipLaunchKernelGGL(fast_item_sort, dim3(gb), dim3(kSortBlock), lds_i, stream, n, B, L.nbk, L.cap_i, L.shift_i, bb_i, cnt_i, ibuf,
-                       oc_item, oc_src, tp, tn, flags);
+#define WR_ITEM_SORT(PER_)                                                                                                 \
+    hipLaunchKernelGGL((fast_item_sort<PER_>), dim3(gb), dim3(kSortBlock), lds_i, stream, n, B, L.nbk, L.cap_i, L.shift_i,   \
+                       bb_i, cnt_i, ibuf, oc_item, oc_src, tp, tn, flags)
+    if (per_i <= 3) WR_ITEM_SORT(3);
+    else if (per_i <= 5) WR_ITEM_SORT(5);
+    else if (per_i <= 9) WR_ITEM_SORT(9);
+    else WR_ITEM_SORT(kMaxCap / kSortBlock);
+#undef WR_ITEM_SORT
     WR_LAUNCH_CHECK("fast_item_sort");
     return WR_OK;
 }
