@@ -10,6 +10,7 @@ from whisprrec_amd import hip_ops
 dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t_end = time.time() + budget
+t_note = time.time()
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 n_cases = worst = 0
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -81,4 +82,7 @@ while time.time() < t_end:
     except hip_ops.abi.WhisprRecHipError:
         pass                                   # bucket overflow / not applicable: "auto" falls back
     n_cases += 1
+    if time.time() - t_note > 30:             # a run silent for minutes is taken to be hung on the GPU pool
+        t_note = time.time()
+        print("stress_parity: %d cases so far" % n_cases, flush=True)
 print("stress_parity: %d random cases ok, worst table rel err %.2e" % (n_cases, worst))

@@ -16,13 +16,18 @@
 //   F3 item scatter : same tiling over the batch's [positives | negatives] occurrences:
 //                     (item<<32 | side<<31 | sorted index) appended to bucket (batch, item >> shift_i)
 //   F4 item sort    : like F2; writes oc_item/oc_src, flags rows with several occurrences in tp/tn
-// 256 buckets per batch (1024 for batches beyond 128 K), any table size.  Buckets have a fixed capacity (2x the mean + 64); if any bucket overflows (skewed ids) flags[1] is set and the
+// 256 buckets per batch (1024 for batches beyond 128 K), any table size.  Buckets have a fixed capacity (2x the mean + 64); if any bucket overflows (skewed ids: already a Zipf(0.3) popularity
+// over id-sorted items does) flags[1] is set and the
 // caller must rebuild with the generic builder — never a wrong plan.  Ties are impossible (composites are unique), so
 // the unstable bucket placement does not leak into the result.
 #include "wr_common.h"
 
 namespace wr {
 
+#ifndef WR_PLAN_CAPX
+#define WR_PLAN_CAPX 2
+#endif
+constexpr int kCapFactor = WR_PLAN_CAPX;   // bucket capacity = kCapFactor x the mean bucket population + 64
 constexpr int kMaxBuckets = 1024;  // row-range buckets per batch: 256 up to B = 128 K, 1024 beyond
 constexpr int kMaxCap = 4096;    // largest bucket handled by one workgroup (32 KiB of 8-byte composites in LDS, 16 per thread in registers)
 
@@ -53,8 +58,8 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
     L.nbk = 1 << bbits;
     L.shift_u = L.user_bits > bbits ? L.user_bits - bbits : 0;
     L.shift_i = L.item_bits > bbits ? L.item_bits - bbits : 0;
-    const int64_t cu = 2 * ((B + L.nbk - 1) / L.nbk) + 64;
-    const int64_t ci = 2 * ((2 * B + L.nbk - 1) / L.nbk) + 64;
+    const int64_t cu = kCapFactor * ((B + L.nbk - 1) / L.nbk) + 64;
+    const int64_t ci = kCapFactor * ((2 * B + L.nbk - 1) / L.nbk) + 64;
     if (cu > kMaxCap || ci > kMaxCap) return false;
     L.cap_u = (int)cu;
     L.cap_i = (int)ci;
@@ -73,7 +78,7 @@ constexpr int kTile = WR_PLAN_TILE;       // elements of one batch handled by on
 #define WR_PLAN_BINSHIFT 2
 #endif
 constexpr unsigned kBinShift = WR_PLAN_BINSHIFT;   // counting-sort bins per bucket = capacity >> kBinShift
-constexpr int kMaxGroup = 32;     // longest run of equal rows a single thread orders by insertion (else: overflow)
+constexpr int kMaxGroup = 256;    // longest bin ordered by ranking (m reads per composite of a bin of m; else: overflow)
 
 // Appends a tile's composites to their buckets.  Ranks inside the tile come from LDS atomics and ONE global atomic per
 // non-empty (tile, bucket) reserves the range; the composites are then grouped by bucket in LDS and written out slot by
