@@ -11,8 +11,9 @@
 //   F1 user scatter : tiles of 4096 triplets; (user<<32 | original index) appended to bucket (batch, user >> shift_u);
 //                     ranks inside a tile from LDS atomics, ONE global atomic per (tile, bucket) reserves the range, the
 //                     tile is grouped by bucket in LDS and written out in runs of consecutive slots
-//   F2 user sort    : one workgroup per bucket: LDS counting sort on the low row bits + insertion sort of the (short)
-//                     runs of equal rows; writes tu/tp/tn/torig at the bucket's prefix
+//   F2 user sort    : one workgroup per bucket, composites in registers: counting sort into bins of the low row bits
+//                     (LDS), sorted position = bin start + number of smaller composites in the bin; every thread
+//                     writes tu/tp/tn/torig for its own composites at the bucket's prefix
 //   F3 item scatter : same tiling over the batch's [positives | negatives] occurrences:
 //                     (item<<32 | side<<31 | sorted index) appended to bucket (batch, item >> shift_i)
 //   F4 item sort    : like F2; writes oc_item/oc_src, flags rows with several occurrences in tp/tn
