@@ -114,6 +114,17 @@ int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users
                                 const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int32_t *neg_items,
                                 int32_t *err_flag, void *stream);
 
+/* Epoch shuffle on the device — the row order DataLoader(shuffle=True) gives an epoch (src/helpers/BaseRunner.py:188-193):
+ * out_k[i] = col_k[perm(i)] for up to three index columns (NULL pairs are skipped), order_out[i] = perm(i) if not NULL.
+ * perm is a keyed bijection of [0, n) evaluated per row (alternating Feistel network on ceil(log2 n) bits, splitmix64
+ * round function keyed by (seed, epoch), cycle walking): no sort and no order array are needed.  Reproducible, equal to
+ * oracle.epoch_permutation bit for bit; NOT the reference's torch.randperm stream (the bit-exact host path stays
+ * available, whisprrec_amd/runner.py epoch_order).  Outputs must not alias inputs. */
+int32_t wr_epoch_shuffle_i64(const int64_t *col0, const int64_t *col1, const int64_t *col2, int64_t n, uint64_t seed,
+                             uint64_t epoch, int64_t *out0, int64_t *out1, int64_t *out2, int64_t *order_out, void *stream);
+int32_t wr_epoch_shuffle_i32(const int32_t *col0, const int32_t *col1, const int32_t *col2, int64_t n, uint64_t seed,
+                             uint64_t epoch, int32_t *out0, int32_t *out1, int32_t *out2, int64_t *order_out, void *stream);
+
 /* Long runs ("hot rows": a table row with more than 32 occurrences in one batch, e.g. power-law ids).  Optional second
  * part of a plan: every such run is cut into pieces of at most 256 positions so that the step can work on a hot row with
  * many workgroups instead of one 16-lane team (still in a fixed order: reproducible).  Two sides: kind 0 = item rows (runs of

@@ -92,10 +92,7 @@ def c2_epoch_case(n_inter=100_000_000, nU=1_000_000, nI=1_000_000, D=64, B=65536
         torch.cuda.synchronize(); t0 = time.perf_counter()
         neg, err = hip_ops.sample_negatives(users, nU, nI, ptr, idx, 3407, epoch)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        g.manual_seed(3407 * 1000003 + epoch)
-        order = torch.randperm(n_inter, device=dev, generator=g)
-        u, p, n = users[order], items[order], neg[order]
-        del order
+        u, p, n = hip_ops.epoch_shuffle([users, items, neg], 3407, epoch)     # keyed bijection per row (wr_epoch_shuffle)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         losses = torch.empty(nb, dtype=torch.float32, device=dev)
         pipe.run(pipe.plan(U, [(I, u, p, n)], B), 0, 0.05, losses)

@@ -76,3 +76,60 @@ def test_user_who_clicked_everything_is_flagged():
                                         torch.from_numpy(idx).to(dev), 5, 0)
     assert int(err.item()) == 2
     assert neg[1].item() != 3 and neg[2].item() != 3
+
+
+# ----------------------------------------------------------------------------------------------- epoch shuffle
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 4097, 65536, 100003])
+def test_epoch_shuffle_matches_oracle_bit_exact(dtype, n):
+    """wr_epoch_shuffle: out_k[i] = col_k[perm(i)] with perm = oracle.epoch_permutation, a bijection of [0, n) — the
+    device's epoch order (reference: DataLoader(shuffle=True), BaseRunner.py:188-193)."""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(n)
+    cols = [rng.randint(0, 1 << 30, n) for _ in range(3)]
+    perm = oracle.epoch_permutation(n, 3407, 5)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    outs, order = hip_ops.epoch_shuffle([torch.from_numpy(c).to(dtype).to(dev) for c in cols], 3407, 5, want_order=True)
+    assert np.array_equal(order.cpu().numpy(), perm)
+    for c, o in zip(cols, outs):
+        assert o.dtype == dtype and np.array_equal(o.cpu().numpy(), c[perm])
+    # fewer columns, no order; another epoch gives another order; the same call twice the same one
+    (o0,) = hip_ops.epoch_shuffle([torch.from_numpy(cols[0]).to(dtype).to(dev)], 3407, 5)
+    assert torch.equal(o0, outs[0])
+    if n >= 1000:
+        (o1,) = hip_ops.epoch_shuffle([torch.from_numpy(cols[0]).to(dtype).to(dev)], 3407, 6)
+        assert not torch.equal(o1, o0)
+
+
+def test_epoch_shuffle_full_size_is_a_permutation():
+    """C2 scale (100 M rows, BASELINE.json configs[1]): the order is a bijection (every row exactly once) and the three
+    columns travel together; sampled positions equal the oracle's permutation."""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    n = 100_000_000
+    base = torch.arange(n, dtype=torch.int32, device=dev)
+    outs, order = hip_ops.epoch_shuffle([base, base + 1, base * 2 % 1000003], 11, 3, want_order=True)
+    assert int(order.min()) == 0 and int(order.max()) == n - 1
+    seen = torch.zeros(n, dtype=torch.uint8, device=dev)
+    seen[order] = 1
+    assert int(seen.sum(dtype=torch.int64)) == n
+    assert torch.equal(outs[0].long(), order) and torch.equal(outs[1].long(), order + 1)
+    assert torch.equal(outs[2].long(), order * 2 % 1000003)
+    # the network is evaluated per row: the oracle restates a sample of positions
+    probe = np.array([0, 1, 2, 12345, 65536, n // 2, n - 2, n - 1])
+    got = order.cpu().numpy()[probe]
+    ref = oracle.epoch_permutation_at(probe, n, 11, 3)
+    assert np.array_equal(got, ref)
+
+
+def test_epoch_shuffle_rejects_bad_arguments():
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    a = torch.arange(10, device=dev)
+    with pytest.raises(ValueError):
+        hip_ops.epoch_shuffle([a, a[:5]], 1, 1)
+    with pytest.raises(TypeError):
+        hip_ops.epoch_shuffle([a.float()], 1, 1)
+    with pytest.raises(ValueError):
+        hip_ops.epoch_shuffle([], 1, 1)

@@ -183,3 +183,21 @@ def test_g6_evaluate_method(g6):
     res = oracle.evaluate_method(g6["predictions"], [5, 10, 20], ["NDCG", "HR", "RECALL", "PRECISION"])
     for k, v in zip(g6["keys"], g6["values"]):
         assert abs(res[str(k)] - v) < 1e-12
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64, 1000, 4097, 100003])
+def test_epoch_permutation_is_a_keyed_bijection(n):
+    """oracle.epoch_permutation — the restatement of the device's epoch order (wr_epoch_shuffle; reference counterpart:
+    DataLoader(shuffle=True), BaseRunner.py:188-193): every row exactly once, another key another order, subsets of
+    positions evaluate to the same values, and no visible structure (what a shuffle is for)."""
+    p = oracle.epoch_permutation(n, 3407, 1)
+    assert p.dtype == np.int64 and np.array_equal(np.sort(p), np.arange(n))
+    assert np.array_equal(p, oracle.epoch_permutation(n, 3407, 1))
+    if n >= 64:
+        probe = np.array([0, 1, n // 2, n - 1])
+        assert np.array_equal(oracle.epoch_permutation_at(probe, n, 3407, 1), p[probe])
+    if n >= 1000:
+        q = oracle.epoch_permutation(n, 3407, 2)
+        assert (p == q).mean() < 0.01 and (p == np.arange(n)).mean() < 0.01
+        assert abs(np.corrcoef(np.arange(n), p)[0, 1]) < 0.1
+        assert abs(np.abs(np.diff(p)).mean() / n - 1 / 3) < 0.03      # consecutive rows land far apart

@@ -1,4 +1,5 @@
-// wr_sampler.hip — on-device epoch preparation: negative sampling with rejection against the user's train set.
+// wr_sampler.hip — on-device epoch preparation: negative sampling with rejection against the user's train set, and the
+// epoch shuffle (second half of the file).
 //
 // Device counterpart of GeneralModel.Dataset.actions_before_epoch (reference src/models/BaseModel.py:167-177): one negative
 // per training row, uniform over [1, n_items) — item 0 is never drawn, like the reference (:168) — redrawn while it is in
@@ -67,6 +68,70 @@ __global__ __launch_bounds__(kBlock) void sample_negatives_kernel(const Idx *__r
     neg[i] = (Idx)cand;
 }
 
+// ----------------------------------------------------------------------------------------------- epoch shuffle
+// Device counterpart of DataLoader(shuffle=True) (reference src/helpers/BaseRunner.py:188-193): the epoch's rows in a fresh
+// random order.  The reference draws torch.randperm on the host; torch.randperm on the device sorts 100 M random keys
+// (14 ms at C2 scale, a fifth of the whole epoch).  Here the order is a keyed bijection evaluated per row — no sort, no order
+// array: out[i] = in[perm(i)], perm = alternating Feistel network on ceil(log2 n) bits (the two halves take turns being
+// XORed with a splitmix64 hash of the other half, the round number and the (seed, epoch) key; kShuffleRounds rounds) with
+// cycle walking (re-apply until the value is < n; the domain is < 2n, so < 2 evaluations on average).  Rows are
+// independent; the result equals oracle.epoch_permutation bit for bit.  Like the device sampler it is NOT the reference's
+// RNG stream: the bit-exact host path stays available.
+constexpr int kShuffleRounds = 8;
+
+__host__ __device__ __forceinline__ uint64_t shuffle_index(uint64_t i, uint64_t n, unsigned bits, uint64_t key) {
+    const unsigned a = bits >> 1, b = bits - a;              // widths of the high and the low half (b >= a >= 1)
+    const uint64_t mask_a = (uint64_t(1) << a) - 1, mask_b = (uint64_t(1) << b) - 1;
+    uint64_t x = i;
+    do {
+        uint64_t hi = x >> b, lo = x & mask_b;
+#pragma unroll
+        for (int r = 0; r < kShuffleRounds; ++r) {
+            if ((r & 1) == 0) hi ^= mix64(key ^ (lo * 0xD1B54A32D192ED03ull + (uint64_t)r)) & mask_a;
+            else lo ^= mix64(key ^ (hi * 0xD1B54A32D192ED03ull + (uint64_t)r)) & mask_b;
+        }
+        x = (hi << b) | lo;
+    } while (x >= n);
+    return x;
+}
+
+static inline unsigned shuffle_bits(int64_t n) {
+    unsigned bits = 2;
+    while (bits < 62 && (int64_t(1) << bits) < n) ++bits;
+    return bits;
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void epoch_shuffle_kernel(const Idx *__restrict__ c0, const Idx *__restrict__ c1,
+                                                                const Idx *__restrict__ c2, int64_t n, unsigned bits,
+                                                                uint64_t key, Idx *__restrict__ o0, Idx *__restrict__ o1,
+                                                                Idx *__restrict__ o2, int64_t *__restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = (int64_t)shuffle_index((uint64_t)i, (uint64_t)n, bits, key);
+    if (c0) o0[i] = c0[j];
+    if (c1) o1[i] = c1[j];
+    if (c2) o2[i] = c2[j];
+    if (order) order[i] = j;
+}
+
+template <typename Idx>
+static int32_t epoch_shuffle(const Idx *c0, const Idx *c1, const Idx *c2, int64_t n, uint64_t seed, uint64_t epoch, Idx *o0,
+                             Idx *o1, Idx *o2, int64_t *order, void *stream) {
+    WR_REQUIRE(n >= 0 && n < (int64_t(1) << 62), WR_E_SHAPE, "shuffle: n=%lld out of range", (long long)n);
+    WR_REQUIRE((c0 == nullptr) == (o0 == nullptr) && (c1 == nullptr) == (o1 == nullptr) && (c2 == nullptr) == (o2 == nullptr),
+               WR_E_NULL, "shuffle: every input column needs its output column");
+    WR_REQUIRE(c0 || c1 || c2 || order, WR_E_NULL, "shuffle: nothing to do");
+    WR_REQUIRE((c0 == nullptr || c0 != o0) && (c1 == nullptr || c1 != o1) && (c2 == nullptr || c2 != o2), WR_E_NULL,
+               "shuffle: in-place permutation is not supported");
+    if (n == 0) return WR_OK;
+    const uint64_t key = mix64(mix64(seed ^ (epoch * 0x9E3779B97F4A7C15ull)) ^ 0x5DEECE66Dull);
+    hipLaunchKernelGGL((epoch_shuffle_kernel<Idx>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), c0, c1, c2, n, shuffle_bits(n), key, o0, o1, o2, order);
+    WR_LAUNCH_CHECK("epoch_shuffle_kernel");
+    return WR_OK;
+}
+
 }  // namespace wr
 
 using namespace wr;
@@ -97,6 +162,16 @@ int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users
                        seed, epoch, neg_items, err_flag);
     WR_LAUNCH_CHECK("sample_negatives_kernel");
     return WR_OK;
+}
+
+int32_t wr_epoch_shuffle_i64(const int64_t *col0, const int64_t *col1, const int64_t *col2, int64_t n, uint64_t seed,
+                             uint64_t epoch, int64_t *out0, int64_t *out1, int64_t *out2, int64_t *order_out, void *stream) {
+    return epoch_shuffle<int64_t>(col0, col1, col2, n, seed, epoch, out0, out1, out2, order_out, stream);
+}
+
+int32_t wr_epoch_shuffle_i32(const int32_t *col0, const int32_t *col1, const int32_t *col2, int64_t n, uint64_t seed,
+                             uint64_t epoch, int32_t *out0, int32_t *out1, int32_t *out2, int64_t *order_out, void *stream) {
+    return epoch_shuffle<int32_t>(col0, col1, col2, n, seed, epoch, out0, out1, out2, order_out, stream);
 }
 
 }  // extern "C"

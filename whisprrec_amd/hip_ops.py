@@ -379,6 +379,28 @@ def sample_negatives(users, n_users, n_items, clicked_ptr, clicked_idx, seed, ep
     return neg, err
 
 
+def epoch_shuffle(cols, seed, epoch, want_order=False):
+    """Device epoch shuffle (wr_epoch_shuffle): up to three 1-D index columns of one dtype (int64 or int32) and one length,
+    permuted by the same keyed bijection of the rows.  Returns the permuted columns (and the int64 order if asked)."""
+    cols = list(cols)
+    if not 1 <= len(cols) <= 3:
+        raise ValueError("one to three columns")
+    dt = cols[0].dtype
+    if dt not in (torch.int64, torch.int32):
+        raise TypeError("columns must be int64 or int32")
+    n = cols[0].numel()
+    cols = [_req(c.contiguous(), dt, "column", 1) for c in cols]
+    if any(c.numel() != n for c in cols):
+        raise ValueError("columns must have the same length")
+    outs = [torch.empty_like(c) for c in cols]
+    order = torch.empty(n, dtype=torch.int64, device=cols[0].device) if want_order else None
+    pad = [None] * (3 - len(cols))
+    fn = abi.lib().wr_epoch_shuffle_i64 if dt == torch.int64 else abi.lib().wr_epoch_shuffle_i32
+    abi.check(fn(*[_p(c) for c in cols + pad], n, int(seed), int(epoch), *[_p(o) for o in outs + pad], _p(order), _stream()),
+              "wr_epoch_shuffle")
+    return (outs, order) if want_order else outs
+
+
 def clicked_csr_from_pairs(users, items, n_users, n_items):
     """device (user, item) interaction pairs -> device CSR of each user's distinct items, ascending (the layout
     wr_sample_negatives and wr_rank_eval take).  One-off setup: torch sort/unique glue."""

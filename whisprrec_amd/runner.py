@@ -288,13 +288,15 @@ def make_hip_runner(base_runner_cls):
                 self._epoch_cache = (dataset, users, items, ptr, idx)
             _, users, items, ptr, idx = self._epoch_cache
             neg, err = hip_ops.sample_negatives(users, model.user_num, model.item_num, ptr, idx, self.seed, max(epoch, 0))
-            g = torch.Generator(device=dev)
-            g.manual_seed(self.seed * 1000003 + max(epoch, 0))
-            order = torch.randperm(users.numel(), device=dev, generator=g)
-            self._last_order = order
+            # the epoch's row order: a keyed bijection evaluated per row (wr_epoch_shuffle) — no 100 M-key sort as in
+            # torch.randperm, no order array unless the per-row histories of a sequential dataset have to follow it
+            sequential = "position" in dataset.data
+            cols = hip_ops.epoch_shuffle([users, items, neg], self.seed, max(epoch, 0), want_order=sequential)
+            if sequential:
+                cols, self._last_order = cols
             if int(err.item()) == 1:
                 raise IndexError("user id out of range in the training frame")
-            return users[order], items[order], neg[order]
+            return cols
 
         def evaluate(self, dataset, topks, metrics):
             """Full-ranking evaluation on the device when the model exposes its factor matrices (``eval_factors``): ranks
