@@ -184,12 +184,18 @@ def main():
     plan_stream = hip_ops.side_stream(dev)   # high priority: its own hardware queue, never serialised behind the steps
     main_stream = torch.cuda.current_stream(dev)
 
+    bucket_map = {"map": None}
+
     def build_plan(first_step, c, tag):
         """enqueue the plan build of steps [first_step, first_step+c) on the side stream; returns (plan, ready event)"""
         lo = first_step * B
         with torch.cuda.stream(plan_stream):
             plan = hip_ops.BatchPlan(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B, args.users, args.items,
-                                     validate=False, ws_tag="plan%d" % tag, builder=args.plan_builder)
+                                     validate=False, ws_tag="plan%d" % tag, builder=args.plan_builder,
+                                     bucket_map=bucket_map["map"] or None)
+            if plan.fast_overflowed and args.plan_builder == "auto":
+                # skewed ids (--zipf): balance the builder's buckets by the rows' share of the data, as PipelinedSgd does
+                bucket_map["map"] = hip_ops.BucketMap(u, p, args.users, args.items, B) if bucket_map["map"] is None else False
             ready = torch.cuda.Event()
             ready.record(plan_stream)
         return plan, ready

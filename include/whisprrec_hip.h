@@ -98,6 +98,35 @@ int32_t wr_bprmf_plan_build_fast_i32(const int32_t *u, const int32_t *p, const i
                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
                                      void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Bucket map for the hand-written plan builder on skewed ids.  The builder's first stage appends every triplet (item
+ * occurrence) to a (batch, row-range) bucket of FIXED capacity (twice the mean load + 64).  Without a map the ranges have
+ * equal width, and popularity-skewed ids overflow them (flags[1], rebuild with wr_bprmf_plan_build_*).  A map makes the
+ * ranges equal in expected LOAD instead: row_bucket[row] & 0xffff is the bucket of the row (buckets ascend with the rows,
+ * so the plan arrays are the same, bit for bit); a row heavy enough to fill a bucket on its own owns row_bucket[row] >> 16
+ * consecutive sub-buckets that split its occurrences by position in the batch.  Per bucket: first row, number of rows,
+ * and for the sub-buckets of a heavy row (index among them) | (their number << 16), else 0.  All arrays on the device.
+ * whisprrec_amd/hip_ops.py (BucketMap) derives a map from an epoch's id columns; either side may be NULL (equal widths). */
+typedef struct wr_bucket_side {
+    int32_t n_buckets;             /* 1..1024 */
+    const int32_t *row_bucket;     /* [n_rows] */
+    const int32_t *bucket_start;   /* [n_buckets] */
+    const int32_t *bucket_rows;    /* [n_buckets] */
+    const int32_t *bucket_sub;     /* [n_buckets] */
+} wr_bucket_side;
+
+int64_t wr_bprmf_plan_fast_mapped_workspace_bytes(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items,
+                                                  int32_t n_buckets_users, int32_t n_buckets_items);
+int32_t wr_bprmf_plan_build_fast_mapped_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                            int64_t batch_size, int64_t n_users, int64_t n_items,
+                                            const wr_bucket_side *map_users, const wr_bucket_side *map_items, int32_t *tu,
+                                            int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src,
+                                            int32_t *flags, void *workspace, int64_t workspace_bytes, void *stream);
+int32_t wr_bprmf_plan_build_fast_mapped_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                            int64_t batch_size, int64_t n_users, int64_t n_items,
+                                            const wr_bucket_side *map_users, const wr_bucket_side *map_items, int32_t *tu,
+                                            int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src,
+                                            int32_t *flags, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Epoch preparation on the device — GeneralModel.Dataset.actions_before_epoch (src/models/BaseModel.py:167-177):
  * one negative per training row, uniform over [1, n_items) (item 0 is never drawn, :168), redrawn while it is in the

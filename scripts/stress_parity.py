@@ -12,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t_end = time.time() + budget
 t_note = time.time()
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-n_cases = worst = 0
+n_cases = worst = n_mapped = 0
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 while time.time() < t_end:
     D = int(rng.choice([4, 8, 16, 20, 32, 64, 64, 64, 96, 128, 256]))
@@ -81,8 +81,17 @@ while time.time() < t_end:
             assert torch.equal(getattr(pf, nm), getattr(pg, nm)), ("builders", nm, D, nU, nI, B, kind)
     except hip_ops.abi.WhisprRecHipError:
         pass                                   # bucket overflow / not applicable: "auto" falls back
+    # ... and so does the bucket builder with a load-balanced map of these ids, whenever it does not overflow
+    bmap = hip_ops.BucketMap(T(u), T(p), nU, nI, B)
+    pm = hip_ops.BatchPlan(T(u), T(p), T(n), B, nU, nI, builder="auto", hot=False, bucket_map=bmap)
+    hip_ops._FAST_BACKOFF.clear()
+    if pm.builder == "fast+map":
+        n_mapped += 1
+        pg = hip_ops.BatchPlan(T(u), T(p), T(n), B, nU, nI, builder="generic", hot=False)
+        for nm in ("tu", "tp", "tn", "oc_item", "oc_src"):
+            assert torch.equal(getattr(pm, nm), getattr(pg, nm)), ("mapped builder", nm, D, nU, nI, B, kind)
     n_cases += 1
     if time.time() - t_note > 30:             # a run silent for minutes is taken to be hung on the GPU pool
         t_note = time.time()
         print("stress_parity: %d cases so far" % n_cases, flush=True)
-print("stress_parity: %d random cases ok, worst table rel err %.2e" % (n_cases, worst))
+print("stress_parity: %d random cases ok (%d with the mapped bucket builder), worst table rel err %.2e" % (n_cases, n_mapped, worst))

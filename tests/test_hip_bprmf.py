@@ -516,3 +516,93 @@ def test_phase_events_attached_to_dispatches(ops, dev, zipf):
         assert ev[4 * k + 1].elapsed_time(ev[4 * k + 3]) > 0             # user phase ends before the item phase does
     with pytest.raises(ValueError):
         tabs.run_sgd(plan, 0, NB, 0.1, phase_events=ev[:3 * NB])
+
+
+def _skewed_epoch(rng, nU, nI, N, user_a=1.1, item_a=0.9):
+    """power-law users and items whose popular ids sit at the low end of the id space (worst case for row-range buckets),
+    uniform negatives as the reference draws them (BaseModel.py:168)"""
+    u = np.minimum((rng.pareto(user_a, N) * 20).astype(np.int64), nU - 1)
+    p = np.minimum((rng.pareto(item_a, N) * 5).astype(np.int64), nI - 1)
+    n = rng.randint(1, nI, N)
+    perm = rng.permutation(N)            # batches are random samples of the epoch, as after DataLoader(shuffle=True)
+    return u[perm], p[perm], n[perm]
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("shape", [(50000, 80000, 4096, 20), (1 << 20, 1 << 20, 65536, 6), (3000, 1574, 2048, 33),
+                                   (200000, 200000, 16384, 9), (1000, 1000, 65536, 3)])
+def test_mapped_builder_agrees_with_generic_bitwise_on_skewed_ids(ops, dev, shape, dtype):
+    """hand-written builder with a bucket map (load-balanced row ranges, heavy rows split by position) against the radix-sort
+    builder on power-law ids, short last batch included: the same arrays bit for bit, without falling back"""
+    nU, nI, B, nb = shape
+    N = nb * B - B // 3
+    rng = np.random.RandomState(B + nb)
+    u, p, n = (x.astype(dtype) for x in _skewed_epoch(rng, nU, nI, N))
+    ud, pd, nd = T(u, dev), T(p, dev), T(n, dev)
+    bmap = ops.BucketMap(ud, pd, nU, nI, B)
+    a = ops.BatchPlan(ud, pd, nd, B, nU, nI, keep_orig=True, builder="generic")
+    b = ops.BatchPlan(ud, pd, nd, B, nU, nI, keep_orig=True, builder="auto", bucket_map=bmap)
+    if nU > 2000:      # tables smaller than the batch need more than 1024 buckets (most rows are heavy): no map, generic builder
+        assert bmap.users is not None and bmap.items is not None
+        assert b.builder == "fast+map", "the mapped builder overflowed"
+    for name in ("tu", "tp", "tn", "torig", "oc_item", "oc_src"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    _check_plan(b, u, p, n, B)
+    # the plain bucket builder gives up on these ids (that is what the map is for) ...
+    c = ops.BatchPlan(ud, pd, nd, B, nU, nI, builder="auto")
+    if B * 8 < min(nU, nI):
+        assert c.builder == "generic" and c.fast_overflowed
+    ops._FAST_BACKOFF.clear()
+    # ... and a map on one side only leaves the other side's equal-width buckets in place
+    uu = rng.randint(0, nU, N).astype(dtype)
+    half = ops.BucketMap(T(uu, dev), pd, nU, nI, B)
+    half.users = None
+    d = ops.BatchPlan(T(uu, dev), pd, nd, B, nU, nI, builder="auto", bucket_map=half)
+    e = ops.BatchPlan(T(uu, dev), pd, nd, B, nU, nI, builder="generic")
+    if d.builder == "fast+map":
+        for name in ("tu", "tp", "tn", "oc_item", "oc_src"):
+            assert torch.equal(getattr(d, name), getattr(e, name)), name
+    ops._FAST_BACKOFF.clear()
+
+
+def test_mapped_builder_overflow_falls_back(ops, dev):
+    """a map built from one epoch, batches that are NOT samples of it (every triplet on one cold row): overflow -> generic"""
+    nU = nI = 100000; B = 4096; N = 3 * B
+    rng = np.random.RandomState(3)
+    u, p, n = (x.astype(np.int32) for x in _skewed_epoch(rng, nU, nI, N))
+    bmap = ops.BucketMap(T(u, dev), T(p, dev), nU, nI, B)
+    u2 = np.full(N, 77777, np.int32); p2 = np.full(N, 55555, np.int32)
+    plan = ops.BatchPlan(T(u2, dev), T(p2, dev), T(n, dev), B, nU, nI, keep_orig=True, builder="auto", bucket_map=bmap)
+    assert plan.builder == "generic" and plan.fast_overflowed
+    _check_plan(plan, u2, p2, n, B)
+    ops._FAST_BACKOFF.clear()
+
+
+def test_pipelined_sgd_switches_to_the_bucket_map_on_skewed_ids(ops, dev):
+    """PipelinedSgd: the first chunk overflows the equal-width buckets, the following chunks run on the hand-written builder
+    with a map of the epoch; the trained tables equal those of per-batch generic plans bit for bit"""
+    nU, nI, D, B, nbat = 60000, 40000, 64, 4096, 10
+    rng = np.random.RandomState(9)
+    u, p, n = (x.astype(np.int32) for x in _skewed_epoch(rng, nU, nI, nbat * B))
+    U = (rng.standard_normal((nU, D)) * 0.1).astype(np.float32); I = (rng.standard_normal((nI, D)) * 0.1).astype(np.float32)
+    ops._FAST_BACKOFF.clear()
+    Ud, Id = T(U, dev), T(I, dev)
+    pipe = ops.PipelinedSgd(chunk=3)
+    h = pipe.plan(Ud, [(Id, T(u, dev), T(p, dev), T(n, dev))], B)
+    losses = torch.empty(nbat, dtype=torch.float32, device=dev)
+    seen = []
+    orig = ops.BatchPlan.__init__
+    def spy(self, *a, **k):
+        orig(self, *a, **k); seen.append(self.builder)
+    ops.BatchPlan.__init__ = spy
+    try:
+        pipe.run(h, 0, 0.05, losses)
+    finally:
+        ops.BatchPlan.__init__ = orig
+    torch.cuda.synchronize()
+    assert h["map"] and "fast+map" in seen, seen
+    ref = ops.BprmfTables(T(U, dev), T(I, dev))
+    plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, builder="generic")
+    l_ref = ref.run_sgd(plan, 0, nbat, 0.05)
+    assert torch.equal(ref.U, Ud) and torch.equal(ref.I, Id) and torch.equal(l_ref, losses)
+    ops._FAST_BACKOFF.clear()

@@ -25,6 +25,11 @@ SIGNATURES = {
     "wr_bprmf_plan_build_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_plan_fast_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    "wr_bprmf_plan_fast_mapped_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64, c_i32, c_i32]),
+    "wr_bprmf_plan_build_fast_mapped_i64": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_plan_build_fast_mapped_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_plan_build_fast_i64": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                              c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_plan_build_fast_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -86,6 +91,11 @@ class HotRuns(ctypes.Structure):
                 ("u_piece_q", c_vp), ("u_piece_len", c_vp), ("u_run_q", c_vp), ("u_run_first", c_vp), ("u_run_np", c_vp),
                 ("counts_host", c_vp), ("cap_pieces", c_i64), ("cap_runs", c_i64), ("cap_u_pieces", c_i64),
                 ("cap_u_runs", c_i64)]
+
+
+class BucketSide(ctypes.Structure):
+    """struct wr_bucket_side of include/whisprrec_hip.h"""
+    _fields_ = [("n_buckets", c_i32), ("row_bucket", c_vp), ("bucket_start", c_vp), ("bucket_rows", c_vp), ("bucket_sub", c_vp)]
 
 
 _lib = None

@@ -268,10 +268,14 @@ def make_bprmf(general_model_cls):
                 self._pipe.run(handle, 0, lr, losses)
                 return losses
             done = 0
+            bmap = None       # skewed ids: after the first bucket overflow the builder gets a load-balanced map of this epoch
             while done < nb:
                 c = min(chunk, nb - done)
                 lo, hi = done * batch_size, min(N, (done + c) * batch_size)
-                plan = hip_ops.BatchPlan(u[lo:hi], p[lo:hi], n[lo:hi], batch_size, self.user_num, self.item_num)
+                plan = hip_ops.BatchPlan(u[lo:hi], p[lo:hi], n[lo:hi], batch_size, self.user_num, self.item_num,
+                                         bucket_map=bmap or None)
+                if plan.fast_overflowed:
+                    bmap = hip_ops.BucketMap(u, p, self.user_num, self.item_num, batch_size) if bmap is None else False
                 if optimizer in ("SGD", "Adam"):
                     if opt is None or opt.name != optimizer or opt.lr != float(lr) or opt.l2 != float(l2):
                         if opt is not None and opt.adam_step > 0 and opt.name == optimizer:

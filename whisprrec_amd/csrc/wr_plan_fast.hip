@@ -33,7 +33,7 @@ constexpr int kMaxBuckets = 1024;  // row-range buckets per batch: 256 up to B =
 constexpr int kMaxCap = 4096;    // largest bucket handled by one workgroup (32 KiB of 8-byte composites in LDS, 16 per thread in registers)
 
 struct FastLayout {
-    int nbk;                  // buckets per batch (power of two)
+    int nbk_u, nbk_i;         // buckets per batch on each side (equal-width mode: a power of two; mapped mode: from the map)
     unsigned user_bits, item_bits, shift_u, shift_i;
     int cap_u, cap_i;         // bucket capacities (entries)
     int64_t nb;
@@ -46,9 +46,11 @@ static inline unsigned bits_for_rows(int64_t n_values) {
     return b == 0 ? 1 : b;
 }
 
-static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, FastLayout &L) {
+// map_u / map_i: bucket counts of a bucket map (0: equal-width row ranges on that side)
+static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, int map_u, int map_i, FastLayout &L) {
     if (n <= 0 || n >= (int64_t(1) << 31) || B <= 0 || B > (int64_t(1) << 24)) return false;
     if (n_users <= 0 || n_users >= (int64_t(1) << 31) || n_items <= 0 || n_items >= (int64_t(1) << 31)) return false;
+    if (map_u < 0 || map_u > kMaxBuckets || map_i < 0 || map_i > kMaxBuckets) return false;
     L.nb = (n + B - 1) / B;
     L.user_bits = bits_for_rows(n_users);
     L.item_bits = bits_for_rows(n_items);
@@ -56,20 +58,39 @@ static bool fast_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, 
 #define WR_PLAN_BBITS 8
 #endif
     const unsigned bbits = B > 131072 ? 10 : WR_PLAN_BBITS;
-    L.nbk = 1 << bbits;
+    const int nominal = 1 << bbits;   // the capacity follows the nominal bucket count: a map balances the load to that mean
+    if ((map_u || map_i) && bbits != WR_PLAN_BBITS) return false;   // maps are built for the 256-bucket regime
+    L.nbk_u = map_u ? map_u : nominal;
+    L.nbk_i = map_i ? map_i : nominal;
     L.shift_u = L.user_bits > bbits ? L.user_bits - bbits : 0;
     L.shift_i = L.item_bits > bbits ? L.item_bits - bbits : 0;
-    const int64_t cu = kCapFactor * ((B + L.nbk - 1) / L.nbk) + 64;
-    const int64_t ci = kCapFactor * ((2 * B + L.nbk - 1) / L.nbk) + 64;
+    const int64_t cu = kCapFactor * ((B + nominal - 1) / nominal) + 64;
+    const int64_t ci = kCapFactor * ((2 * B + nominal - 1) / nominal) + 64;
     if (cu > kMaxCap || ci > kMaxCap) return false;
     L.cap_u = (int)cu;
     L.cap_i = (int)ci;
-    L.cnt_bytes = align_up(2 * L.nb * L.nbk * 4, 256);
-    L.ubuf_bytes = align_up(L.nb * L.nbk * (int64_t)L.cap_u * 8, 256);
-    L.ibuf_bytes = align_up(L.nb * L.nbk * (int64_t)L.cap_i * 8, 256);
+    L.cnt_bytes = align_up(L.nb * (int64_t)(L.nbk_u + L.nbk_i) * 4, 256);
+    L.ubuf_bytes = align_up(L.nb * L.nbk_u * (int64_t)L.cap_u * 8, 256);
+    L.ibuf_bytes = align_up(L.nb * L.nbk_i * (int64_t)L.cap_i * 8, 256);
     L.total = L.cnt_bytes + L.ubuf_bytes + L.ibuf_bytes;
     return true;
 }
+
+// One side (users or items) of the bucket assignment as the kernels see it.  Equal-width mode (row_bucket == nullptr):
+// bucket = row >> shift.  Mapped mode (wr_bucket_side, include/whisprrec_hip.h): bucket = row_bucket[row] & 0xffff; a heavy
+// row — one that would overflow a bucket on its own — owns `row_bucket[row] >> 16` consecutive sub-buckets, which split
+// its occurrences by position in the batch (the order inside a row IS the position order, so the ranges keep it).
+struct SideDev {
+    int nbk;
+    unsigned shift;
+    const int *row_bucket, *start, *rows, *sub;
+    __device__ __forceinline__ int bucket_of(uint32_t row, uint32_t pos, uint32_t npos) const {
+        if (row_bucket == nullptr) return (int)(row >> shift);
+        const uint32_t e = (uint32_t)row_bucket[row];
+        const uint32_t nsub = e >> 16;
+        return (int)(e & 0xffffu) + (nsub ? (int)(((uint64_t)pos * nsub) / npos) : 0);
+    }
+};
 
 #ifndef WR_PLAN_TILE
 #define WR_PLAN_TILE 4096
@@ -88,7 +109,7 @@ constexpr int kMaxGroup = 256;    // longest bin ordered by ranking (m reads per
 // stores per wave instruction — took 18 of the kernel's 27 us (timing-only variants: no stores 9 us, no global atomics
 // 27 us).  `shift` recovers the bucket from a composite (row id in the high word).  Placement order inside a bucket is
 // arbitrary; the bucket sort fixes it.
-template <int PER_THREAD, typename KeyFn>
+template <int PER_THREAD, bool MAPPED, typename KeyFn>
 __device__ __forceinline__ void tile_scatter(int n_local, int nbk, unsigned shift, int *__restrict__ cnt_global,
                                              unsigned long long *__restrict__ buf, int cap, int *__restrict__ flags,
                                              KeyFn key_of) {
@@ -96,6 +117,7 @@ __device__ __forceinline__ void tile_scatter(int n_local, int nbk, unsigned shif
     __shared__ int delta[kMaxBuckets];   // per bucket: (reserved slot base in the bucket) - (offset inside the tile)
     __shared__ int wave_tot[kBlock / 64];
     __shared__ unsigned long long stage[kTile];
+    __shared__ unsigned short stage_bk[MAPPED ? kTile : 1];   // mapped mode: the bucket is not a function of the row bits
     for (int j = threadIdx.x; j < nbk; j += kBlock) hist[j] = 0;
     __syncthreads();
     unsigned long long key[PER_THREAD];
@@ -137,68 +159,73 @@ __device__ __forceinline__ void tile_scatter(int n_local, int nbk, unsigned shif
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k)
-        if (bucket[k] >= 0) stage[hist[bucket[k]] + rank[k]] = key[k];
+        if (bucket[k] >= 0) {
+            stage[hist[bucket[k]] + rank[k]] = key[k];
+            if (MAPPED) stage_bk[hist[bucket[k]] + rank[k]] = (unsigned short)bucket[k];
+        }
     __syncthreads();
     for (int sidx = threadIdx.x; sidx < n_local; sidx += kBlock) {
         const unsigned long long kv = stage[sidx];
-        const int bk = (int)((unsigned)(kv >> 32) >> shift);
+        const int bk = MAPPED ? (int)stage_bk[sidx] : (int)((unsigned)(kv >> 32) >> shift);
         const int slot = delta[bk] + sidx;
         if (slot < cap) buf[(int64_t)bk * cap + slot] = kv;
         else flags[1] = 1;
     }
 }
 
-template <typename Idx>
+template <typename Idx, bool MAPPED>
 __global__ __launch_bounds__(kBlock) void fast_user_scatter(const Idx *__restrict__ u, int64_t n, int64_t B, int tiles_per_batch,
-                                                             int nbk, int64_t n_users, unsigned shift_u, int cap_u,
-                                                             int *__restrict__ cnt_u,
+                                                             SideDev side, int64_t n_users, int cap_u, int *__restrict__ cnt_u,
                                                              unsigned long long *__restrict__ ubuf, int *__restrict__ flags) {
     const int64_t b = blockIdx.x / tiles_per_batch;
     const int tile = blockIdx.x % tiles_per_batch;
     const int64_t lo = b * B + (int64_t)tile * kTile;
     const int64_t batch_end = (b * B + B < n) ? (b * B + B) : n;
     const int n_local = (int)((lo + kTile <= batch_end) ? kTile : (batch_end > lo ? batch_end - lo : 0));
-    tile_scatter<kTile / kBlock>(n_local, nbk, shift_u, cnt_u + b * nbk, ubuf + b * nbk * (int64_t)cap_u, cap_u, flags,
-                                 [&](int e, int &bucket) {
-                                     const int64_t i = lo + e;
-                                     int64_t uu = (int64_t)u[i];
-                                     if (uu < 0 || uu >= n_users) {
-                                         flags[0] = 1;
-                                         uu = 0;
-                                     }
-                                     bucket = (int)(uu >> shift_u);
-                                     return ((unsigned long long)uu << 32) | (unsigned long long)(uint32_t)i;
-                                 });
+    const int nbk = side.nbk;
+    tile_scatter<kTile / kBlock, MAPPED>(n_local, nbk, side.shift, cnt_u + b * nbk, ubuf + b * nbk * (int64_t)cap_u, cap_u, flags,
+                                         [&](int e, int &bucket) {
+                                             const int64_t i = lo + e;
+                                             int64_t uu = (int64_t)u[i];
+                                             if (uu < 0 || uu >= n_users) {
+                                                 flags[0] = 1;
+                                                 uu = 0;
+                                             }
+                                             bucket = side.bucket_of((uint32_t)uu, (uint32_t)(i - b * B), (uint32_t)B);
+                                             return ((unsigned long long)uu << 32) | (unsigned long long)(uint32_t)i;
+                                         });
 }
 
 // Item occurrences of a tile of user-sorted triplets: composite (item, side, sorted index) — positives before negatives
 // for equal items, then by sorted triplet index: the order a stable sort of [positives | negatives] gives.
+template <bool MAPPED>
 __global__ __launch_bounds__(kBlock) void fast_item_scatter(const int *__restrict__ tp, const int *__restrict__ tn, int64_t n,
-                                                             int64_t B, int tiles_per_batch, int nbk, int64_t n_items,
-                                                             unsigned shift_i, int cap_i,
-                                                             int *__restrict__ cnt_i, unsigned long long *__restrict__ ibuf,
-                                                             int *__restrict__ flags) {
+                                                             int64_t B, int tiles_per_batch, SideDev side, int64_t n_items,
+                                                             int cap_i, int *__restrict__ cnt_i,
+                                                             unsigned long long *__restrict__ ibuf, int *__restrict__ flags) {
     const int64_t b = blockIdx.x / tiles_per_batch;
     const int tile = blockIdx.x % tiles_per_batch;
     const int64_t Bb = ((b * B + B < n) ? B : (n - b * B));
     const int64_t lo2 = (int64_t)tile * kTile;            // offset into the batch's 2*Bb occurrences: [pos | neg]
     const int n_local = (int)((lo2 + kTile <= 2 * Bb) ? kTile : (2 * Bb > lo2 ? 2 * Bb - lo2 : 0));
-    tile_scatter<kTile / kBlock>(n_local, nbk, shift_i, cnt_i + b * nbk, ibuf + b * nbk * (int64_t)cap_i, cap_i, flags,
-                                 [&](int e, int &bucket) {
-                                     const int64_t o = lo2 + e;
-                                     const int side = o >= Bb;
-                                     const int tloc = (int)(side ? o - Bb : o);
-                                     int item = (side ? tn : tp)[b * B + tloc];
-                                     // positions the user stage dropped after a bucket overflow were never written:
-                                     // keep every access in range (the plan is already flagged invalid)
-                                     if (item < 0 || item >= n_items) {
-                                         flags[1] = 1;
-                                         item = 0;
-                                     }
-                                     bucket = item >> shift_i;
-                                     return ((unsigned long long)(uint32_t)item << 32) | ((unsigned long long)side << 31) |
-                                            (unsigned long long)(uint32_t)tloc;
-                                 });
+    const int nbk = side.nbk;
+    tile_scatter<kTile / kBlock, MAPPED>(n_local, nbk, side.shift, cnt_i + b * nbk, ibuf + b * nbk * (int64_t)cap_i, cap_i, flags,
+                                         [&](int e, int &bucket) {
+                                             const int64_t o = lo2 + e;
+                                             const int sd = o >= Bb;
+                                             const int tloc = (int)(sd ? o - Bb : o);
+                                             int item = (sd ? tn : tp)[b * B + tloc];
+                                             // positions the user stage dropped after a bucket overflow were never written:
+                                             // keep every access in range (the plan is already flagged invalid)
+                                             if (item < 0 || item >= n_items) {
+                                                 flags[1] = 1;
+                                                 item = 0;
+                                             }
+                                             // position key of an occurrence: positives [0, B), negatives [B, 2B)
+                                             bucket = side.bucket_of((uint32_t)item, (uint32_t)(sd * B + tloc), (uint32_t)(2 * B));
+                                             return ((unsigned long long)(uint32_t)item << 32) | ((unsigned long long)sd << 31) |
+                                                    (unsigned long long)(uint32_t)tloc;
+                                         });
 }
 
 __device__ __forceinline__ int pow2_ceil(int x) {
@@ -226,9 +253,56 @@ constexpr int kSortBlock = WR_SORT_BLOCK;   // threads of a bucket-sort workgrou
 // Bins longer than kMaxGroup raise the overflow flag (degenerate batch: the caller rebuilds with the generic builder).
 // A workgroup's lifetime is a chain of barriers and memory round trips, and 16 K workgroups per plan chunk wait on it.
 struct BinMap {
-    unsigned down, mask;
-    __device__ __forceinline__ int of(unsigned long long kv) const { return (int)(((unsigned)(kv >> 32) >> down) & mask); }
+    int kind;   // 0: equal-width row range; 1: row range of a bucket map; 2: sub-bucket of a heavy row (bins over positions)
+    unsigned down, mask;                    // kind 0: bin = (row >> down) & mask
+    uint32_t start, nbin1;                  // kind 1: first row of the bucket; nbin - 1
+    unsigned long long scale;               // kind 1 / 2: ceil(nbin * 2^32 / extent): bin = (offset * scale) >> 32 (monotone)
+    uint32_t nsub, sidx, npos, pos_base, half;   // kind 2: position key = low word - pos_base (users), side * half + tloc (items)
+    __device__ __forceinline__ int of(unsigned long long kv) const {
+        const uint32_t row = (uint32_t)(kv >> 32);
+        if (kind == 0) return (int)((row >> down) & mask);
+        unsigned long long off;
+        if (kind == 1) {
+            off = row - start;
+        } else {
+            const uint32_t low = (uint32_t)kv;
+            const uint32_t pos = half ? (low >> 31) * half + (low & 0x7fffffffu) : low - pos_base;
+            off = (unsigned long long)pos * nsub - (unsigned long long)sidx * npos;   // in [0, npos): this sub-bucket's share
+        }
+        const uint32_t bin = (uint32_t)((off * scale) >> 32);
+        return (int)(bin < nbin1 ? bin : nbin1);
+    }
 };
+
+// bin mapping of bucket `bucket` of batch `b`; item_side: composites carry (side, sorted index) in the low word
+__device__ __forceinline__ BinMap make_binmap(const SideDev &side, int bucket, unsigned bin_bits, int64_t b, int64_t B,
+                                              bool item_side) {
+    BinMap bm{};
+    const uint32_t nbin = 1u << bin_bits;
+    bm.nbin1 = nbin - 1u;
+    if (side.row_bucket == nullptr) {
+        bm.kind = 0;
+        bm.down = side.shift - bin_bits;
+        bm.mask = nbin - 1u;
+        return bm;
+    }
+    const uint32_t sub = (uint32_t)side.sub[bucket];
+    if (sub == 0) {
+        bm.kind = 1;
+        bm.start = (uint32_t)side.start[bucket];
+        const unsigned long long width = (unsigned long long)max(side.rows[bucket], 1);
+        bm.scale = (((unsigned long long)nbin << 32) + width - 1) / width;
+        return bm;
+    }
+    bm.kind = 2;
+    bm.nsub = sub >> 16;
+    bm.sidx = sub & 0xffffu;
+    bm.npos = (uint32_t)(item_side ? 2 * B : B);
+    bm.half = item_side ? (uint32_t)B : 0u;
+    bm.pos_base = (uint32_t)(b * B);
+    bm.scale = (((unsigned long long)nbin << 32) + bm.npos - 1) / bm.npos;
+    return bm;
+}
 
 template <int PER, typename Early>
 __device__ __forceinline__ int bucket_bins(const unsigned long long *__restrict__ src, const int *__restrict__ cnt_batch,
@@ -310,8 +384,7 @@ __device__ __forceinline__ int rank_in_bin(const unsigned long long *__restrict_
 
 template <typename Idx, int PER>
 __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restrict__ p, const Idx *__restrict__ nn, int64_t n,
-                                                          int64_t B, int nbk, int64_t n_items, int cap_u, unsigned shift_u,
-                                                          unsigned bin_bits,
+                                                          int64_t B, SideDev side, int64_t n_items, int cap_u, unsigned bin_bits,
                                                           const int *__restrict__ cnt_u, const unsigned long long *__restrict__ ubuf,
                                                           int *__restrict__ tu, int *__restrict__ tp, int *__restrict__ tn,
                                                           int *__restrict__ torig, int *__restrict__ flags) {
@@ -320,12 +393,13 @@ __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restri
     unsigned long long *out = lds;
     int *cnt = reinterpret_cast<int *>(lds + cap_u);
     // the buckets of one batch gather p[] / n[] from the same 2 x 4B x B bytes: keep them on one XCD's L2
+    const int nbk = side.nbk;
     const unsigned lb = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int64_t b = lb / nbk;
     const int bucket = lb % nbk;
     const int count = min(cnt_u[lb], cap_u);
     if (count == 0) return;
-    const BinMap bm{shift_u - bin_bits, (1u << bin_bits) - 1u};
+    const BinMap bm = make_binmap(side, bucket, bin_bits, b, B, false);
     unsigned long long kv[PER];
     Idx pv[PER], nv[PER];
     const int prefix = bucket_bins<PER>(ubuf + (int64_t)lb * cap_u, cnt_u + b * nbk, bucket, cap_u, out, cnt, wave_tot, wave_pre,
@@ -357,8 +431,7 @@ __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restri
 }
 
 template <int PER>
-__global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t B, int nbk, int cap_i, unsigned shift_i,
-                                                          unsigned bin_bits,
+__global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t B, SideDev side, int cap_i, unsigned bin_bits,
                                                           const int *__restrict__ cnt_i, const unsigned long long *__restrict__ ibuf,
                                                           int *__restrict__ oc_item, int *__restrict__ oc_src, int *__restrict__ tp,
                                                           int *__restrict__ tn, int *__restrict__ flags) {
@@ -367,12 +440,17 @@ __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t 
     unsigned long long *out = lds;
     int *cnt = reinterpret_cast<int *>(lds + cap_i);
     // the buckets of one batch set flag bits all over the batch's tp[] / tn[]: keep them on one XCD's L2
+    const int nbk = side.nbk;
     const unsigned lb = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int64_t b = lb / nbk;
     const int bucket = lb % nbk;
     const int count = min(cnt_i[lb], cap_i);
     if (count == 0) return;
-    const BinMap bm{shift_i - bin_bits, (1u << bin_bits) - 1u};
+    const BinMap bm = make_binmap(side, bucket, bin_bits, b, B, true);
+    // a heavy row's occurrences are spread over its sub-buckets: "several occurrences" is decided over all of them
+    int row_total = 0;
+    if (bm.kind == 2)
+        for (uint32_t q = 0; q < bm.nsub; ++q) row_total += min(cnt_i[b * nbk + bucket - (int)bm.sidx + (int)q], cap_i);
     unsigned long long kv[PER];
     const int prefix = bucket_bins<PER>(ibuf + (int64_t)lb * cap_i, cnt_i + b * nbk, bucket, cap_i, out, cnt, wave_tot, wave_pre,
                                         count, 1 << bin_bits, bm, kv, [](int, unsigned long long) {});
@@ -393,65 +471,91 @@ __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t 
         oc_item[base + r] = item;
         oc_src[base + r] = (tloc << 1) | side;
         // equal items always share a bucket AND a bin: another composite of the bin with this item = "several occurrences"
-        if (same > 1) {
+        if (same > 1 || row_total > 1) {
             int *dst = side ? tn : tp;
             dst[b * B + tloc] |= (int)0x80000000;  // one writer per (triplet, side)
         }
     }
 }
 
+static int32_t check_side(const wr_bucket_side *m, const char *what) {
+    if (m == nullptr) return WR_OK;
+    WR_REQUIRE(m->n_buckets >= 1 && m->n_buckets <= kMaxBuckets, WR_E_RANGE, "bucket map (%s): %d buckets (1..%d)", what,
+               (int)m->n_buckets, kMaxBuckets);
+    WR_REQUIRE(m->row_bucket && m->bucket_start && m->bucket_rows && m->bucket_sub, WR_E_NULL, "bucket map (%s): NULL array", what);
+    return WR_OK;
+}
+
+static inline SideDev side_dev(const wr_bucket_side *m, int nbk, unsigned shift) {
+    if (m == nullptr) return SideDev{nbk, shift, nullptr, nullptr, nullptr, nullptr};
+    return SideDev{nbk, 0u, m->row_bucket, m->bucket_start, m->bucket_rows, m->bucket_sub};
+}
+
 template <typename Idx>
 static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_t n, int64_t B, int64_t n_users,
-                               int64_t n_items, int32_t *tu, int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item,
-                               int32_t *oc_src, int32_t *flags, void *workspace, int64_t workspace_bytes, void *stream_) {
+                               int64_t n_items, const wr_bucket_side *map_u, const wr_bucket_side *map_i, int32_t *tu,
+                               int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
+                               void *workspace, int64_t workspace_bytes, void *stream_) {
     WR_REQUIRE(u && p && nn, WR_E_NULL, "index arrays must not be NULL");
     WR_REQUIRE(tu && tp && tn && oc_item && oc_src && flags, WR_E_NULL, "plan output arrays / flags must not be NULL");
+    int32_t rc;
+    if ((rc = check_side(map_u, "users")) != WR_OK) return rc;
+    if ((rc = check_side(map_i, "items")) != WR_OK) return rc;
     FastLayout L;
-    WR_REQUIRE(fast_layout(n, B, n_users, n_items, L), WR_E_RANGE,
+    WR_REQUIRE(fast_layout(n, B, n_users, n_items, map_u ? map_u->n_buckets : 0, map_i ? map_i->n_buckets : 0, L), WR_E_RANGE,
                "fast plan builder not applicable to n=%lld, batch=%lld (use the generic builder)", (long long)n, (long long)B);
     WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= L.total, WR_E_WORKSPACE,
                "fast plan workspace %lld B < %lld B", (long long)workspace_bytes, (long long)L.total);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char *ws = reinterpret_cast<char *>(workspace);
     int *cnt_u = reinterpret_cast<int *>(ws);
-    int *cnt_i = cnt_u + L.nb * L.nbk;
+    int *cnt_i = cnt_u + L.nb * L.nbk_u;
     unsigned long long *ubuf = reinterpret_cast<unsigned long long *>(ws + L.cnt_bytes);
     unsigned long long *ibuf = reinterpret_cast<unsigned long long *>(ws + L.cnt_bytes + L.ubuf_bytes);
-    WR_HIP(hipMemsetAsync(cnt_u, 0, (size_t)(2 * L.nb * L.nbk * 4), stream));
+    WR_HIP(hipMemsetAsync(cnt_u, 0, (size_t)(L.nb * (int64_t)(L.nbk_u + L.nbk_i) * 4), stream));
     const int tiles_u = (int)((B + kTile - 1) / kTile), tiles_i = (int)((2 * B + kTile - 1) / kTile);
-    const unsigned gb = (unsigned)(L.nb * L.nbk);
-    hipLaunchKernelGGL((fast_user_scatter<Idx>), dim3((unsigned)(L.nb * tiles_u)), dim3(kBlock), 0, stream, u, n, B, tiles_u,
-                       L.nbk, n_users, L.shift_u, L.cap_u, cnt_u, ubuf, flags);
+    const unsigned gb_u = (unsigned)(L.nb * L.nbk_u), gb_i = (unsigned)(L.nb * L.nbk_i);
+    const SideDev su = side_dev(map_u, L.nbk_u, L.shift_u), si = side_dev(map_i, L.nbk_i, L.shift_i);
+    if (map_u)
+        hipLaunchKernelGGL((fast_user_scatter<Idx, true>), dim3((unsigned)(L.nb * tiles_u)), dim3(kBlock), 0, stream, u, n, B,
+                           tiles_u, su, n_users, L.cap_u, cnt_u, ubuf, flags);
+    else
+        hipLaunchKernelGGL((fast_user_scatter<Idx, false>), dim3((unsigned)(L.nb * tiles_u)), dim3(kBlock), 0, stream, u, n, B,
+                           tiles_u, su, n_users, L.cap_u, cnt_u, ubuf, flags);
     WR_LAUNCH_CHECK("fast_user_scatter");
     // bins per bucket: capacity / 4 (capacity = twice the mean bucket population -> about two composites per bin;
-    // A/B at the headline shape: 1 per bin 7.0 us of plan per batch, 2 per bin 6.35, 4 per bin 6.6), never more bins
-    // than distinct low-bit patterns
+    // A/B at the headline shape: 1 per bin 7.0 us of plan per batch, 2 per bin 6.35, 4 per bin 6.6); with equal-width
+    // buckets never more bins than distinct low-bit patterns
     auto bins_for = [](int cap, unsigned shift) {
         unsigned b = 0;
         while ((1 << b) < cap) ++b;
         b = b > kBinShift + 4 ? b - kBinShift : b;
         return b < shift ? b : shift;
     };
-    const unsigned bb_u = bins_for(L.cap_u, L.shift_u), bb_i = bins_for(L.cap_i, L.shift_i);
+    const unsigned bb_u = bins_for(L.cap_u, map_u ? 31u : L.shift_u), bb_i = bins_for(L.cap_i, map_i ? 31u : L.shift_i);
     const size_t lds_u = (size_t)L.cap_u * 8 + ((size_t)4 << bb_u);
     const size_t lds_i = (size_t)L.cap_i * 8 + ((size_t)4 << bb_i);
     // composites per thread of a bucket workgroup (registers): instantiations for the capacities that occur
     const int per_u = (L.cap_u + kSortBlock - 1) / kSortBlock, per_i = (L.cap_i + kSortBlock - 1) / kSortBlock;
 #define WR_USER_SORT(PER_)                                                                                                 \
-    hipLaunchKernelGGL((fast_user_sort<Idx, PER_>), dim3(gb), dim3(kSortBlock), lds_u, stream, p, nn, n, B, L.nbk, n_items,  \
-                       L.cap_u, L.shift_u, bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags)
+    hipLaunchKernelGGL((fast_user_sort<Idx, PER_>), dim3(gb_u), dim3(kSortBlock), lds_u, stream, p, nn, n, B, su, n_items,   \
+                       L.cap_u, bb_u, cnt_u, ubuf, tu, tp, tn, torig, flags)
     if (per_u <= 3) WR_USER_SORT(3);
     else if (per_u <= 5) WR_USER_SORT(5);
     else if (per_u <= 9) WR_USER_SORT(9);
     else WR_USER_SORT(kMaxCap / kSortBlock);
 #undef WR_USER_SORT
     WR_LAUNCH_CHECK("fast_user_sort");
-    hipLaunchKernelGGL(fast_item_scatter, dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B, tiles_i,
-                       L.nbk, n_items, L.shift_i, L.cap_i, cnt_i, ibuf, flags);
+    if (map_i)
+        hipLaunchKernelGGL((fast_item_scatter<true>), dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B,
+                           tiles_i, si, n_items, L.cap_i, cnt_i, ibuf, flags);
+    else
+        hipLaunchKernelGGL((fast_item_scatter<false>), dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B,
+                           tiles_i, si, n_items, L.cap_i, cnt_i, ibuf, flags);
     WR_LAUNCH_CHECK("fast_item_scatter");
 #define WR_ITEM_SORT(PER_)                                                                                                 \
-    hipLaunchKernelGGL((fast_item_sort<PER_>), dim3(gb), dim3(kSortBlock), lds_i, stream, n, B, L.nbk, L.cap_i, L.shift_i,   \
-                       bb_i, cnt_i, ibuf, oc_item, oc_src, tp, tn, flags)
+    hipLaunchKernelGGL((fast_item_sort<PER_>), dim3(gb_i), dim3(kSortBlock), lds_i, stream, n, B, si, L.cap_i, bb_i, cnt_i,  \
+                       ibuf, oc_item, oc_src, tp, tn, flags)
     if (per_i <= 3) WR_ITEM_SORT(3);
     else if (per_i <= 5) WR_ITEM_SORT(5);
     else if (per_i <= 9) WR_ITEM_SORT(9);
@@ -469,7 +573,14 @@ extern "C" {
 
 int64_t wr_bprmf_plan_fast_workspace_bytes(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items) {
     FastLayout L;
-    if (!fast_layout(n_triplets, batch_size, n_users, n_items, L)) return 0;  // 0: not applicable, use the generic builder
+    if (!fast_layout(n_triplets, batch_size, n_users, n_items, 0, 0, L)) return 0;  // 0: not applicable, use the generic builder
+    return L.total;
+}
+
+int64_t wr_bprmf_plan_fast_mapped_workspace_bytes(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items,
+                                                  int32_t n_buckets_users, int32_t n_buckets_items) {
+    FastLayout L;
+    if (!fast_layout(n_triplets, batch_size, n_users, n_items, n_buckets_users, n_buckets_items, L)) return 0;
     return L.total;
 }
 
@@ -477,16 +588,34 @@ int32_t wr_bprmf_plan_build_fast_i64(const int64_t *u, const int64_t *p, const i
                                      int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
                                      void *workspace, int64_t workspace_bytes, void *stream) {
-    return plan_build_fast<int64_t>(u, p, n, n_triplets, batch_size, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src,
-                                    flags, workspace, workspace_bytes, stream);
+    return plan_build_fast<int64_t>(u, p, n, n_triplets, batch_size, n_users, n_items, nullptr, nullptr, tu, tp, tn, torig,
+                                    oc_item, oc_src, flags, workspace, workspace_bytes, stream);
 }
 
 int32_t wr_bprmf_plan_build_fast_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
                                      int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
                                      void *workspace, int64_t workspace_bytes, void *stream) {
-    return plan_build_fast<int32_t>(u, p, n, n_triplets, batch_size, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src,
-                                    flags, workspace, workspace_bytes, stream);
+    return plan_build_fast<int32_t>(u, p, n, n_triplets, batch_size, n_users, n_items, nullptr, nullptr, tu, tp, tn, torig,
+                                    oc_item, oc_src, flags, workspace, workspace_bytes, stream);
+}
+
+int32_t wr_bprmf_plan_build_fast_mapped_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                            int64_t batch_size, int64_t n_users, int64_t n_items,
+                                            const wr_bucket_side *map_users, const wr_bucket_side *map_items, int32_t *tu,
+                                            int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src,
+                                            int32_t *flags, void *workspace, int64_t workspace_bytes, void *stream) {
+    return plan_build_fast<int64_t>(u, p, n, n_triplets, batch_size, n_users, n_items, map_users, map_items, tu, tp, tn, torig,
+                                    oc_item, oc_src, flags, workspace, workspace_bytes, stream);
+}
+
+int32_t wr_bprmf_plan_build_fast_mapped_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                            int64_t batch_size, int64_t n_users, int64_t n_items,
+                                            const wr_bucket_side *map_users, const wr_bucket_side *map_items, int32_t *tu,
+                                            int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src,
+                                            int32_t *flags, void *workspace, int64_t workspace_bytes, void *stream) {
+    return plan_build_fast<int32_t>(u, p, n, n_triplets, batch_size, n_users, n_items, map_users, map_items, tu, tp, tn, torig,
+                                    oc_item, oc_src, flags, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -111,6 +111,77 @@ def bpr_fwd(user_tab, item_tab, u, p, n, scores=True, coef=False):
 _FAST_BACKOFF = {}
 
 
+class BucketMap:
+    """Load-balanced row ranges for the hand-written plan builder on skewed ids (struct wr_bucket_side of
+    include/whisprrec_hip.h).  Built once per epoch from the id columns with array operations on the device: the expected
+    number of triplets (item occurrences) a row contributes to a batch is its share of the epoch's rows times the batch size
+    (+ the uniform negatives for items, reference BaseModel.py:167-177); consecutive rows are grouped until a bucket holds
+    the mean load, and a row that holds more than half of it on its own becomes one or more buckets of its own (its
+    occurrences split by position in the batch).  The buckets ascend with the rows, so the plan is the one every other
+    builder emits.  ``users`` / ``items`` are None when that side needs more than 1024 buckets (then: generic builder)."""
+
+    NOMINAL = 256        # the builder's bucket count (and capacity = 2 x mean + 64) in the regime maps are made for
+
+    def __init__(self, u, p, n_users, n_items, batch_size):
+        B, n = int(batch_size), u.numel()
+        dev = u.device
+        self.batch_size = B
+        lam_u = torch.bincount(u.long(), minlength=n_users)[:n_users].double() * (B / n)
+        lam_i = torch.bincount(p.long(), minlength=n_items)[:n_items].double() * (B / n)
+        if n_items > 1:                                      # negatives: uniform over [1, n_items)
+            lam_i[1:] += B / (n_items - 1)
+        self.users = self._side(lam_u, B / self.NOMINAL, dev)
+        self.items = self._side(lam_i, 2 * B / self.NOMINAL, dev)
+
+    @staticmethod
+    def _side(lam, mean, dev):
+        n_rows = lam.numel()
+        # heavy: more than half a bucket's mean load — or so many occurrences per batch that one bin of the bucket sort (bins
+        # separate ROWS in an ordinary bucket, at most 256 composites each) could not hold them; heavy rows get position bins
+        heavy = lam > min(mean / 2, 96.0)
+        w = torch.where(heavy, torch.zeros_like(lam), lam)
+        before = torch.cumsum(w, 0) - w                                   # load of the ordinary rows in front of each row
+        group = torch.floor(before / mean).long()
+        nsub = torch.where(heavy, torch.ceil(lam / mean), torch.zeros_like(lam)).long()
+        start = torch.ones(n_rows, dtype=torch.bool, device=dev)
+        if n_rows > 1:
+            start[1:] = (group[1:] != group[:-1]) | heavy[1:] | heavy[:-1]
+        extra = torch.zeros(n_rows, dtype=torch.long, device=dev)        # sub-buckets of the heavy row in front
+        if n_rows > 1:
+            extra[1:] = torch.clamp(nsub[:-1] - 1, min=0)
+        first = torch.cumsum(start.long() + extra, 0) - 1                 # id of the row's (first) bucket
+        n_buckets = int(first[-1].item()) + max(int(nsub[-1].item()), 1)
+        if n_buckets > 1024 or int(nsub.max().item()) >= 65536:
+            return None
+        row_bucket = (first | (nsub << 16)).to(torch.int32)
+        rows_at = torch.nonzero(start).flatten()                          # first row of every run of rows sharing a bucket
+        b_start = torch.zeros(n_buckets, dtype=torch.long, device=dev)
+        b_rows = torch.ones(n_buckets, dtype=torch.long, device=dev)
+        b_sub = torch.zeros(n_buckets, dtype=torch.long, device=dev)
+        ids = first[rows_at]
+        b_start[ids] = rows_at
+        ends = torch.cat([rows_at[1:], torch.tensor([n_rows], device=dev)])
+        b_rows[ids] = ends - rows_at
+        hrows = torch.nonzero(heavy).flatten()
+        if hrows.numel():
+            m = nsub[hrows]
+            rep = torch.repeat_interleave(torch.arange(hrows.numel(), device=dev), m)      # one entry per sub-bucket
+            q = torch.arange(rep.numel(), device=dev) - torch.repeat_interleave(torch.cumsum(m, 0) - m, m)
+            ids_h = first[hrows][rep] + q
+            b_start[ids_h] = hrows[rep]
+            b_rows[ids_h] = 1
+            b_sub[ids_h] = q | (m[rep] << 16)
+        arrs = [t.to(torch.int32).contiguous() for t in (row_bucket, b_start, b_rows, b_sub)]
+        return {"n_buckets": n_buckets, "arrays": arrs,
+                "struct": abi.BucketSide(n_buckets, *[a.data_ptr() for a in arrs])}
+
+    def record_stream(self, stream):
+        for side in (self.users, self.items):
+            if side is not None:
+                for a in side["arrays"]:
+                    a.record_stream(stream)
+
+
 class BatchPlan:
     """Sorted batches for the fused step (see include/whisprrec_hip.h, "Batch plan").
 
@@ -118,9 +189,11 @@ class BatchPlan:
     ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201)."""
 
     def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="auto",
-                 hot=True):
+                 hot=True, bucket_map=None):
         """builder: "auto" (default) = hand-written bucket/LDS-sort builder when applicable, generic radix-sort builder
-        otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one."""
+        otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one.
+        bucket_map: a BucketMap of the epoch these batches come from — load-balanced buckets for the hand-written builder
+        (skewed ids); ``fast_overflowed`` tells afterwards whether the hand-written builder was tried and gave up."""
         L = abi.lib()
         if u.dtype not in (torch.int64, torch.int32):
             raise TypeError("indices must be int64 or int32")
@@ -150,19 +223,34 @@ class BatchPlan:
         # "auto": ids skewed enough to overflow a bucket keep doing so chunk after chunk — after an overflow the next 32
         # plans of the same shape go straight to the radix-sort builder instead of paying for a failed attempt each
         backoff_key = (str(dev), self.batch_size, self.n_users, self.n_items)
-        if builder == "auto" and _FAST_BACKOFF.get(backoff_key, 0) > 0:
+        self.fast_overflowed = False
+        mapped = bucket_map is not None and (bucket_map.users is not None or bucket_map.items is not None) and \
+            bucket_map.batch_size == self.batch_size
+        if builder == "auto" and not mapped and _FAST_BACKOFF.get(backoff_key, 0) > 0:
             _FAST_BACKOFF[backoff_key] -= 1
             builder = "generic"
+            self.fast_overflowed = True
         self.meta_host = None
         if builder in ("auto", "fast"):
-            nbytes = abi.check_size(L.wr_bprmf_plan_fast_workspace_bytes(*args), "wr_bprmf_plan_fast_workspace_bytes")
+            if mapped:
+                mu, mi = bucket_map.users, bucket_map.items          # a side without a map keeps its equal-width buckets
+                nbytes = abi.check_size(L.wr_bprmf_plan_fast_mapped_workspace_bytes(*args, mu["n_buckets"] if mu else 0,
+                                                                                    mi["n_buckets"] if mi else 0),
+                                        "wr_bprmf_plan_fast_mapped_workspace_bytes")
+            else:
+                nbytes = abi.check_size(L.wr_bprmf_plan_fast_workspace_bytes(*args), "wr_bprmf_plan_fast_workspace_bytes")
             if nbytes > 0:
-                ws = workspace(dev, ws_tag + "_fast").get(nbytes)
+                ws = workspace(dev, ws_tag + ("_fastmap" if mapped else "_fast")).get(nbytes)
                 sides = self._hot_arrays(dev) if hot else None
-                fn = L.wr_bprmf_plan_build_fast_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_i32
-                abi.check(fn(_p(u), _p(p), _p(n), *args, _p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig),
-                             _p(self.oc_item), _p(self.oc_src), _p(self.flags), _p(ws), ws.numel(), _stream()),
-                          "wr_bprmf_plan_build_fast")
+                outs = (_p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.flags),
+                        _p(ws), ws.numel(), _stream())
+                if mapped:
+                    fn = L.wr_bprmf_plan_build_fast_mapped_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_mapped_i32
+                    abi.check(fn(_p(u), _p(p), _p(n), *args, ctypes.addressof(mu["struct"]) if mu else None,
+                                 ctypes.addressof(mi["struct"]) if mi else None, *outs), "wr_bprmf_plan_build_fast_mapped")
+                else:
+                    fn = L.wr_bprmf_plan_build_fast_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_i32
+                    abi.check(fn(_p(u), _p(p), _p(n), *args, *outs), "wr_bprmf_plan_build_fast")
                 # ONE read-back per plan: the overflow flag travels with the hot-run counts (the hot-run scan is bounds-safe
                 # for any key values; after an overflow its output is thrown away with the plan)
                 if hot:
@@ -170,13 +258,15 @@ class BatchPlan:
                 else:
                     self.meta_host = self.meta.cpu()
                 if int(self.meta_host[1]) == 0:
-                    self.builder = "fast"
+                    self.builder = "fast+map" if mapped else "fast"
                 elif builder == "fast":
                     raise abi.WhisprRecHipError("fast plan builder: bucket overflow (skewed ids)")
                 else:
                     self.meta.zero_()
                     self.meta_host, self.hot = None, None
-                    _FAST_BACKOFF[backoff_key] = 32
+                    self.fast_overflowed = True
+                    if not mapped:
+                        _FAST_BACKOFF[backoff_key] = 32
             elif builder == "fast":
                 raise abi.WhisprRecHipError("fast plan builder not applicable to this batch size")
         if self.builder is None:
@@ -508,7 +598,7 @@ class PipelinedSgd:
         u_all, p_all, n_all = (_join_views([s[j] for s in live]) for j in (1, 2, 3))
         n_items = max([s[0].shape[0] for s in live] or [1])
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
-             "at": 0, "tag": 0, "next": None, "cur": None}
+             "at": 0, "tag": 0, "next": None, "cur": None, "map": None}
         self.plan_stream.wait_stream(torch.cuda.current_stream(U.device))   # the index tensors are ready
         self._prefetch(h)
         return h
@@ -523,8 +613,14 @@ class PipelinedSgd:
         h["at"] += c
         lo, hi = first * B, min(h["u"].numel(), (first + c) * B)
         with torch.cuda.stream(self.plan_stream):
+            bmap = h["map"] if h["map"] else None
             plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
-                                      validate=False, ws_tag="rot%d" % h["tag"])
+                                      validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap)
+            if plan.fast_overflowed:
+                # skewed ids: equal-width buckets overflow chunk after chunk.  Balance the buckets by the rows' share of
+                # the epoch (one pass over the id columns) and use them from the next chunk on; if even those overflow
+                # (batches that are not random samples of the epoch), stay with the radix-sort builder.
+                h["map"] = self.ops.BucketMap(h["u"], h["p"], h["n_users"], h["n_items"], B) if h["map"] is None else False
             ready = torch.cuda.Event()
             ready.record(self.plan_stream)
         h["tag"] ^= 1
