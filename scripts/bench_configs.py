@@ -45,7 +45,9 @@ def bprmf_case(name, nU, nI, D, B, NB, opt="SGD", l2=0.0, zipf=0.0, lazy=False):
     u, p, n = synth(nU, nI, NB * B, zipf)
     tabs = hip_ops.BprmfTables(U, I)
     t0 = time.perf_counter(); plan = hip_ops.BatchPlan(u, p, n, B, nU, nI); torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
-    t0 = time.perf_counter(); plan = hip_ops.BatchPlan(u, p, n, B, nU, nI); torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
+    bmap = hip_ops.BucketMap(u, p, nU, nI, B) if plan.fast_overflowed else None    # skewed ids: load-balanced buckets
+    hip_ops._FAST_BACKOFF.clear()
+    t0 = time.perf_counter(); plan = hip_ops.BatchPlan(u, p, n, B, nU, nI, bucket_map=bmap); torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
     if lazy:
         st = hip_ops.LazyOptimizerState(tabs, opt, 1e-3 if opt == "Adam" else 0.05, l2)
         for k in range(NB):                                   # first pass: rows reach their steady-state replay lengths

@@ -17,9 +17,11 @@
 //   F3 item scatter : same tiling over the batch's [positives | negatives] occurrences:
 //                     (item<<32 | side<<31 | sorted index) appended to bucket (batch, item >> shift_i)
 //   F4 item sort    : like F2; writes oc_item/oc_src, flags rows with several occurrences in tp/tn
-// 256 buckets per batch (1024 for batches beyond 128 K), any table size.  Buckets have a fixed capacity (2x the mean + 64); if any bucket overflows (skewed ids: already a Zipf(0.3) popularity
-// over id-sorted items does) flags[1] is set and the
-// caller must rebuild with the generic builder — never a wrong plan.  Ties are impossible (composites are unique), so
+// 256 buckets per batch (1024 for batches beyond 128 K), any table size.  Buckets have a fixed capacity (2x the mean + 64);
+// if any bucket overflows flags[1] is set and the caller must rebuild with the generic builder — never a wrong plan.
+// Equal-width row ranges overflow on popularity-skewed ids (already a Zipf(0.3) popularity over id-sorted items does); with
+// a bucket map (wr_bucket_side: row ranges of equal expected load, heavy rows split by position into sub-buckets; see
+// SideDev / BinMap below) the same four kernels handle power-law ids and emit the same arrays.  Ties are impossible (composites are unique), so
 // the unstable bucket placement does not leak into the result.
 #include "wr_common.h"
 
