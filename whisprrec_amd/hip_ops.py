@@ -126,8 +126,9 @@ class BucketMap:
         B, n = int(batch_size), u.numel()
         dev = u.device
         self.batch_size = B
-        lam_u = torch.bincount(u.long(), minlength=n_users)[:n_users].double() * (B / n)
-        lam_i = torch.bincount(p.long(), minlength=n_items)[:n_items].double() * (B / n)
+        # (out-of-range ids are the plan's business — flags[0], IndexError at validate(); here they only must not break bincount)
+        lam_u = torch.bincount(u.long().clamp_(0, n_users - 1), minlength=n_users).double() * (B / n)
+        lam_i = torch.bincount(p.long().clamp_(0, n_items - 1), minlength=n_items).double() * (B / n)
         if n_items > 1:                                      # negatives: uniform over [1, n_items)
             lam_i[1:] += B / (n_items - 1)
         self.users = self._side(lam_u, B / self.NOMINAL, dev)
