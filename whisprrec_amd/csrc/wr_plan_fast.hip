@@ -230,12 +230,6 @@ __global__ __launch_bounds__(kBlock) void fast_item_scatter(const int *__restric
                                          });
 }
 
-__device__ __forceinline__ int pow2_ceil(int x) {
-    int p = 1;
-    while (p < x) p <<= 1;
-    return p;
-}
-
 #ifndef WR_SORT_BLOCK
 #define WR_SORT_BLOCK 256
 #endif
