@@ -588,6 +588,7 @@ def test_pipelined_sgd_switches_to_the_bucket_map_on_skewed_ids(ops, dev):
     ops._FAST_BACKOFF.clear()
     Ud, Id = T(U, dev), T(I, dev)
     pipe = ops.PipelinedSgd(chunk=3)
+    pipe.PLAN_TRIPLETS = 1               # plans of exactly 3 batches (the default would put this small epoch into one plan)
     h = pipe.plan(Ud, [(Id, T(u, dev), T(p, dev), T(n, dev))], B)
     losses = torch.empty(nbat, dtype=torch.float32, device=dev)
     seen = []

@@ -94,8 +94,9 @@ def test_virtual_ranks_epoch_equals_single_process(world, parts, chunk):
         try:
             main = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(main):
-                m = RotatingBprmf(nU, nI, D, dev, parts=parts, local=hip_ops.PipelinedSgd(chunk),
-                                  transport=LoopbackTransport(shared, rank))
+                local = hip_ops.PipelinedSgd(chunk)
+                local.PLAN_TRIPLETS = 1      # plans of exactly `chunk` batches: chunk ends fall inside and across the strata
+                m = RotatingBprmf(nU, nI, D, dev, parts=parts, local=local, transport=LoopbackTransport(shared, rank))
                 m.load_full(torch.from_numpy(U), torch.from_numpy(I))
                 t = lambda a: torch.from_numpy(a.astype(np.int32)).to(dev)
                 sched = [(t(u), t(p), t(n), steps_per_part) for (u, p, n) in strata[rank]]

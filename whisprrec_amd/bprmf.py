@@ -267,6 +267,7 @@ def make_bprmf(general_model_cls):
                 handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size)
                 self._pipe.run(handle, 0, lr, losses)
                 return losses
+            chunk = hip_ops.PipelinedSgd(chunk).chunk_batches(batch_size)   # small batches: more of them per plan
             done = 0
             bmap = None       # skewed ids: after the first bucket overflow the builder gets a load-balanced map of this epoch
             while done < nb:

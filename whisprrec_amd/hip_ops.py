@@ -569,15 +569,23 @@ def _join_views(ts):
 class PipelinedSgd:
     """Plain-SGD training over pre-ordered triplets with the plan build off the critical path.  The work is a list of
     segments (item table view + indices; one segment for a whole epoch on one GPU, one per part of the held block in the
-    stratified multi-GPU schedule).  Batches are planned ``chunk`` at a time on a side stream, one chunk ahead of the steps
+    stratified multi-GPU schedule).  Batches are planned a chunk at a time on a side stream, one chunk ahead of the steps
     (a plan depends only on the indices, never on the tables) — across segment boundaries too — and a segment's steps are
-    issued from native code (wr_bprmf_run_sgd)."""
+    issued from native code (wr_bprmf_run_sgd).  A chunk is at least ``chunk`` batches and at least PLAN_TRIPLETS triplets:
+    a plan costs a fixed ~0.2 ms of host time (allocations, one read-back), which 64 small batches do not amortise
+    (scripts/exp/small_batch_pace.py, us/step with 64 batches per plan -> with 4 M triplets per plan: B = 2,048 11.1 -> 8.8,
+    B = 16,384 17.8 -> 12.9; B = 65,536 is 64 batches either way)."""
+
+    PLAN_TRIPLETS = 1 << 22
 
     def __init__(self, chunk=64):
         import sys
         self.ops = sys.modules[__name__]
         self.chunk = int(chunk)
         self.plan_stream = None
+
+    def chunk_batches(self, batch_size):
+        return max(self.chunk, self.PLAN_TRIPLETS // max(int(batch_size), 1))
 
     def plan(self, U, segments, batch):
         """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order.
@@ -610,7 +618,7 @@ class PipelinedSgd:
             h["next"] = None
             return
         first, B = h["at"], h["B"]
-        c = min(self.chunk, h["nb"] - first)
+        c = min(self.chunk_batches(B), h["nb"] - first)
         h["at"] += c
         lo, hi = first * B, min(h["u"].numel(), (first + c) * B)
         with torch.cuda.stream(self.plan_stream):
@@ -647,7 +655,8 @@ class PipelinedSgd:
                 cur[1].record_stream(main)
                 h["cur"], h["next"] = cur, None
             base, plan, _ = cur
-            c = min(end, base + plan.n_batches) - pos
+            # at most 256 steps per native call: the next plan is built (host blocked for its read-back) while these run
+            c = min(min(end, base + plan.n_batches) - pos, 256)
             off = pos - sg["first"]
             sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[off:off + c])
             pos += c
