@@ -121,14 +121,20 @@ class BucketMap:
     builder emits.  ``users`` / ``items`` are None when that side needs more than 1024 buckets (then: generic builder)."""
 
     NOMINAL = 256        # the builder's bucket count (and capacity = 2 x mean + 64) in the regime maps are made for
+    SAMPLE = 1 << 21     # rows of the epoch the shares are estimated from
 
     def __init__(self, u, p, n_users, n_items, batch_size):
         B, n = int(batch_size), u.numel()
         dev = u.device
         self.batch_size = B
-        # (out-of-range ids are the plan's business — flags[0], IndexError at validate(); here they only must not break bincount)
-        lam_u = torch.bincount(u.long().clamp_(0, n_users - 1), minlength=n_users).double() * (B / n)
-        lam_i = torch.bincount(p.long().clamp_(0, n_items - 1), minlength=n_items).double() * (B / n)
+        # Row shares from a strided sample of at most SAMPLE rows: the buckets need the heavy rows' shares to a few percent
+        # and the light rows' only in sums over whole ranges, and torch.bincount's global atomics on 40 M power-law ids
+        # take 18 ms (one hot counter) against <1 ms on the sample.  (Out-of-range ids are the plan's business — flags[0],
+        # IndexError at validate(); here they only must not break bincount.)
+        step = max(1, n // self.SAMPLE)
+        us, ps = u[::step].long().clamp_(0, n_users - 1), p[::step].long().clamp_(0, n_items - 1)
+        lam_u = torch.bincount(us, minlength=n_users).double() * (B / us.numel())
+        lam_i = torch.bincount(ps, minlength=n_items).double() * (B / ps.numel())
         if n_items > 1:                                      # negatives: uniform over [1, n_items)
             lam_i[1:] += B / (n_items - 1)
         self.users = self._side(lam_u, B / self.NOMINAL, dev)
