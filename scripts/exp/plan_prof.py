@@ -9,7 +9,7 @@ import torch
 from whisprrec_amd import hip_ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(3407)
-nU = nI = 1_000_000; B = 65536; NB = 64
+nU = nI = 1_000_000; B = int(os.environ.get("PLAN_B", "65536")); NB = max(1, (64 * 65536) // B)
 u = torch.randint(0, nU, (NB * B,), generator=g, device=dev, dtype=torch.int32)
 p = torch.randint(0, nI, (NB * B,), generator=g, device=dev, dtype=torch.int32)
 n = torch.randint(1, nI, (NB * B,), generator=g, device=dev, dtype=torch.int32)

@@ -105,7 +105,8 @@ def test_plan_is_a_stable_sort(ops, dev, dtype):
 
 @pytest.mark.parametrize("shape", [(50, 70, 1000, 128), (1000, 3000, 20000, 4096), (1 << 20, 1 << 20, 3 * 65536 + 777, 65536),
                                    (943, 1574, 66016, 2048), (5, 7, 300, 64), (10_000_000, 12_345_678, 2 * 65536 + 5, 65536),
-                                   (3_000_000, 1_000_000, 2 * 262144 + 1000, 262144)])
+                                   (3_000_000, 1_000_000, 2 * 262144 + 1000, 262144),
+                                   (1_000_000, 1_000_000, 2 * 1048576 + 7, 1048576)])
 def test_fast_and_generic_builders_agree_bitwise(ops, dev, shape):
     """the hand-written bucket/LDS-sort builder must emit exactly the generic radix-sort builder's arrays"""
     nU, nI, N, B = shape

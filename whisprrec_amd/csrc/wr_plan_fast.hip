@@ -32,7 +32,7 @@ namespace wr {
 #endif
 constexpr int kCapFactor = WR_PLAN_CAPX;   // bucket capacity = kCapFactor x the mean bucket population + 64
 constexpr int kMaxBuckets = 1024;  // row-range buckets per batch: 256 up to B = 128 K, 1024 beyond
-constexpr int kMaxCap = 4096;    // largest bucket handled by one workgroup (32 KiB of 8-byte composites in LDS, 16 per thread in registers)
+constexpr int kMaxCap = 4608;    // largest bucket handled by one workgroup (36 KiB of 8-byte composites in LDS, 18 per thread in registers): B = 1,048,576 needs 4,160
 
 struct FastLayout {
     int nbk_u, nbk_i;         // buckets per batch on each side (equal-width mode: a power of two; mapped mode: from the map)
