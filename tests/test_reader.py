@@ -70,7 +70,12 @@ def test_full_ml100k_matches_the_training_golden(tmp_path):
                                          ("BPRMF", ["--lr", "1e-3", "--l2", "1e-6", "--lazy_optimizer", "1"]),
                                          ("LightGCN", ["--lr", "1e-3", "--gcn_layers", "2"]),
                                          ("SGL", ["--lr", "1e-3", "--type", "ED"]),
-                                         ("SASRec", ["--lr", "1e-3", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2"])])
+                                         ("SASRec", ["--lr", "1e-3", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2"]),
+                                         # device-side sampler + shuffle: the per-row histories must follow the device's order
+                                         ("SASRec", ["--lr", "1e-3", "--emb_size", "32", "--num_layers", "1", "--num_heads", "2",
+                                                     "--runner_name", "HipRunner", "--device_epoch_prep", "1"]),
+                                         ("LightGCN", ["--lr", "1e-3", "--gcn_layers", "2", "--runner_name", "HipRunner",
+                                                       "--device_epoch_prep", "1"])])
 def test_standalone_launcher_trains_from_an_inter_file(g8, tmp_path, model, extra):
     """python -m whisprrec_amd.main: .inter file -> reader -> model -> runner.train (dev evaluation, best checkpoint) ->
     test metrics, with the reference's command line (src/main.py)"""
