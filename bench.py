@@ -7,22 +7,27 @@ N=1 workload = BASELINE.json configs[1]: BPRMF, emb_size=64, synthetic 1M users 
 100M-interaction generator, seed 3407), batch 65,536 triplets, SGD, l2=0.  A "step" is one BaseRunner.fit iteration
 (zero_grad / predict / backward / optimizer.step, reference src/helpers/BaseRunner.py:196-199) over one batch: raw
 (u, p, n) int32 triplets resident in HBM -> sorted batch plan -> user-phase kernel -> item-phase kernel -> updated
-tables + loss.  Plan building is INSIDE the timed region (done per chunk of batches).
+tables + loss.  The step stream is the product's own pipeline (whisprrec_amd.hip_ops.PipelinedSgd): plans are built a
+chunk ahead on a side stream, INSIDE the timed region (K steps' worth of plan builds run between the two timestamps).
+
+N>1 (`python bench.py --gpus N` starts its own N ranks; under `torch.distributed.run` it uses the ranks it is given):
+tables row-sharded over N GPUs, RCCL over xGMI, both sharding modes in one run (see whisprrec_amd/rotating.py and
+whisprrec_amd/sharded.py); `--emb 128 --users 10000000 --items 10000000` is BASELINE.json configs[3].
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the 8 TB/s HBM peak using
 algorithmic bytes; `cpu_baseline` times the oracle's sparse SGD restatement on one host core.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 # dmabuf IPC only on this pool's hosts: RCCL / cross-process tensor sharing fails without it (set before HIP initialises)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
@@ -40,45 +45,59 @@ def parse():
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--emb", type=int, default=64)
     ap.add_argument("--lr", type=float, default=0.05)
-    ap.add_argument("--chunk", type=int, default=64, help="batches per plan build")
+    ap.add_argument("--chunk", type=int, default=0, help="batches per plan build (0: min(64, steps/2))")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent over items (0 = uniform, headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-events", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--plan-builder", default="auto", choices=["auto", "generic", "fast"])
     ap.add_argument("--interactions", type=int, default=100_000_000, help="interactions per epoch (sets the rotation period)")
-    ap.add_argument("--shard-mode", default="rotate", choices=["rotate", "alltoall"],
+    ap.add_argument("--shard-mode", default="both", choices=["both", "rotate", "alltoall"],
                     help="N>1: 'rotate' = stratified schedule, item blocks move round the ring (whisprrec_amd/rotating.py); "
-                         "'alltoall' = per-step row exchange (whisprrec_amd/sharded.py)")
+                         "'alltoall' = per-step row exchange (whisprrec_amd/sharded.py); 'both' = one after the other")
     ap.add_argument("--parts", type=int, default=2, help="rotate mode: parts per item block (overlap of transfer and compute)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even with one rank (testing)")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N>1 path (nccl = RCCL; gloo only for the CPU dry run of the launcher)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N>1 launcher rehearsal without GPUs: ranks rendezvous, barrier, and rank 0 prints the line's skeleton")
+    return ap.parse_args(argv)
 
 
-def synth_triplets(n, n_users, n_items, dev, seed, zipf=0.0):
-    """Synthetic interactions of configs[1]: uniform user / item ids (worst case for caches), negatives uniform in
-    [1, n_items) as in GeneralModel.Dataset.actions_before_epoch (reference src/models/BaseModel.py:168)."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    u = torch.randint(0, n_users, (n,), generator=g, device=dev, dtype=torch.int32)
-    if zipf > 0.0:
-        # inverse-CDF sampling of a Zipf(alpha) over item ranks (contention variant, not the headline)
-        r = torch.rand(n, generator=g, device=dev, dtype=torch.float64)
-        if abs(zipf - 1.0) < 1e-9:
-            p = torch.exp(r * np.log(n_items)).to(torch.int64) - 1
-        else:
-            a = 1.0 - zipf
-            p = (((n_items ** a - 1.0) * r + 1.0) ** (1.0 / a)).to(torch.int64) - 1
-        p = p.clamp_(0, n_items - 1).to(torch.int32)
-    else:
-        p = torch.randint(0, n_items, (n,), generator=g, device=dev, dtype=torch.int32)
-    neg = torch.randint(1, n_items, (n,), generator=g, device=dev, dtype=torch.int32)
-    return u, p, neg
+def plan_chunk(args):
+    """batches per plan: 64 in steady state; a short run (the driver's --steps 20) keeps two plans inside the timed region
+    so that the pipeline — next plan built beside the current plan's steps — is what gets measured"""
+    if args.chunk > 0:
+        return args.chunk
+    return max(1, min(64, args.steps // 2))
 
 
+# --------------------------------------------------------------------------------------------------- N>1 launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` as a plain command: start N ranks (one per GPU) as CHILD processes through
+    torch.distributed.run and relay their output.  Nothing in this parent process touches the GPU (no HIP call, no
+    torch.cuda query), and nothing is exec'ed: the parent waits and exits with the children's code."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------------------- CPU baselines
 def cpu_baseline(args, seconds):
     """Oracle's sparse SGD restatement (oracle/wr_oracle.c:orc_bprmf_step_sgd_sparse) on ONE host core, same table
     shapes, same batch size, same id distribution; bounded to ~`seconds` of CPU work."""
+    import numpy as np
     import oracle
     rng = np.random.RandomState(3407)
     U = (rng.standard_normal((args.users, args.emb)) * np.sqrt(2.0 / (args.users + args.emb))).astype(np.float32)
@@ -108,6 +127,7 @@ def cpu_torch_sequence(args, seconds):
     BPRLoss (src/utils/loss.py:38) + loss.backward() + torch.optim.SGD.step() (src/helpers/BaseRunner.py:196-199), dense
     gradients and all — restated with stock PyTorch CPU ops on the box's host cores (the reference's own files do not
     travel to the GPU box).  Same table shapes, batch size and id distribution; bounded to ~`seconds`."""
+    import torch
     torch.manual_seed(3407)
     ue = torch.nn.Embedding(args.users, args.emb)
     ie = torch.nn.Embedding(args.items, args.emb)
@@ -144,128 +164,99 @@ def cpu_torch_sequence(args, seconds):
             "host_cpus": os.cpu_count()}
 
 
-KEEP_PLANS = 2
+# --------------------------------------------------------------------------------------------------- N = 1
+def synth_triplets(n, n_users, n_items, dev, seed, zipf=0.0):
+    """Synthetic interactions of configs[1]: uniform user / item ids (worst case for caches), negatives uniform in
+    [1, n_items) as in GeneralModel.Dataset.actions_before_epoch (reference src/models/BaseModel.py:168)."""
+    import numpy as np
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    u = torch.randint(0, n_users, (n,), generator=g, device=dev, dtype=torch.int32)
+    if zipf > 0.0:
+        # inverse-CDF sampling of a Zipf(alpha) over item ranks (contention variant, not the headline)
+        r = torch.rand(n, generator=g, device=dev, dtype=torch.float64)
+        if abs(zipf - 1.0) < 1e-9:
+            p = torch.exp(r * np.log(n_items)).to(torch.int64) - 1
+        else:
+            a = 1.0 - zipf
+            p = (((n_items ** a - 1.0) * r + 1.0) ** (1.0 / a)).to(torch.int64) - 1
+        p = p.clamp_(0, n_items - 1).to(torch.int32)
+    else:
+        p = torch.randint(0, n_items, (n,), generator=g, device=dev, dtype=torch.int32)
+    neg = torch.randint(1, n_items, (n,), generator=g, device=dev, dtype=torch.int32)
+    return u, p, neg
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" %
-                             (args.gpus, args.gpus))
-    if args.gpus > 1 or args.force_sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if args.shard_mode == "rotate":
-            from whisprrec_amd import rotating
-            return rotating.bench_main(args, rank, world, local_rank)
-        from whisprrec_amd import sharded
-        return sharded.bench_main(args, rank, world, local_rank)
+def csrc_sha():
+    """hash of the step kernels' sources: a committed PMC traffic figure is only quoted for the kernels it was taken on"""
+    h = hashlib.sha256()
+    for f in ("wr_bpr.hip", "wr_common.h"):
+        with open(os.path.join(ROOT, "whisprrec_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
+
+def single_gpu(args, local_rank):
+    import numpy as np
+    import torch
     from whisprrec_amd import hip_ops
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B, D, K, W = args.batch, args.emb, args.steps, args.warmup
+    C = plan_chunk(args)
 
     # tables: N(0, 2/(rows+D)) = xavier_normal_ (reference src/models/init.py:25, BPRMF.py:40)
     g = torch.Generator(device=dev)
     g.manual_seed(3407)
     U = torch.randn(args.users, D, generator=g, device=dev) * float(np.sqrt(2.0 / (args.users + D)))
     I = torch.randn(args.items, D, generator=g, device=dev) * float(np.sqrt(2.0 / (args.items + D)))
-    tabs = hip_ops.BprmfTables(U, I)
-    u, p, n = synth_triplets((K + W) * B, args.users, args.items, dev, 3407, args.zipf)
+    # One step stream of W + K + C batches, consumed as warm-up | timed steps | one plan chunk nobody trains on.  Plans: the
+    # first covers the warm-up, then C batches each; a plan is built beside the steps of the plan before it.  So the plan of
+    # the first timed chunk is built during the warm-up — as in an epoch, where every plan but the first is built beside
+    # steps — and the timed region builds the plans of the chunks that FOLLOW its own chunks, the last of which is the spare
+    # one: K batches' worth of plan builds between the two timestamps, K steps trained.
+    u, p, n = synth_triplets((K + W + C) * B, args.users, args.items, dev, 3407, args.zipf)
+    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1)
+    losses_w = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
+    losses = torch.empty(K, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    handle = pipe.plan(U, [(I, u, p, n)], B, first_chunk=W if W > 0 else None)
+    if W > 0:
+        pipe.run_steps(handle, W, args.lr, losses_w)
     torch.cuda.synchronize()
 
-    plan_stream = hip_ops.side_stream(dev)   # high priority: its own hardware queue, never serialised behind the steps
-    main_stream = torch.cuda.current_stream(dev)
-
-    bucket_map = {"map": None}
-
-    def build_plan(first_step, c, tag):
-        """enqueue the plan build of steps [first_step, first_step+c) on the side stream; returns (plan, ready event)"""
-        lo = first_step * B
-        with torch.cuda.stream(plan_stream):
-            plan = hip_ops.BatchPlan(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B, args.users, args.items,
-                                     validate=False, ws_tag="plan%d" % tag, builder=args.plan_builder,
-                                     bucket_map=bucket_map["map"] or None)
-            if plan.fast_overflowed and args.plan_builder == "auto":
-                # skewed ids (--zipf): balance the builder's buckets by the rows' share of the data, as PipelinedSgd does
-                bucket_map["map"] = hip_ops.BucketMap(u, p, args.users, args.items, B) if bucket_map["map"] is None else False
-            ready = torch.cuda.Event()
-            ready.record(plan_stream)
-        return plan, ready
-
-    def run_range(first_step, count):
-        """plan + steps for global steps [first_step, first_step+count), chunk by chunk.  The plan of chunk c+1 is built
-        on a side stream while the steps of chunk c run (it depends only on the indices, never on the tables)."""
-        out = []
-        chunks = []
-        done = 0
-        while done < count:
-            c = min(args.chunk, count - done)
-            chunks.append((first_step + done, c))
-            done += c
-        plan_stream.wait_stream(main_stream)
-        nxt = build_plan(chunks[0][0], chunks[0][1], 0)
-        for i, (fs, c) in enumerate(chunks):
-            plan, ready = nxt
-            main_stream.wait_event(ready)
-            plan.validate()                                             # flags came back with the hot-run counts: no sync
-            plan.record_stream(main_stream)
-            # plans are kept for the first KEEP_PLANS chunks only (row statistics, per-kernel timing pass): holding every
-            # plan alive makes each build a fresh hipMalloc, and that call stalls the host long enough to drain the queue
-            out.append((plan if i < KEEP_PLANS else None, tabs.run_sgd(plan, 0, c, args.lr)))   # this chunk's steps first ...
-            if i + 1 < len(chunks):                                     # ... then build the next plan beside them
-                nxt = build_plan(chunks[i + 1][0], chunks[i + 1][1], (i + 1) % 2)
-        return out
-
-    run_range(0, W)
-    torch.cuda.synchronize()
-
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = run_range(W, K)
+    pipe.run_steps(handle, K, args.lr, losses)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
-    # per-kernel timing: HIP events recorded by the library on the launch stream around the two kernels of each
-    # step, on a second pass over the same (already planned) batches — outside the throughput measurement, so
-    # the event records do not sit in the timed region.
-    events = None
+    plan = handle["cur"][1]            # the plan of the last timed chunk: row statistics and the per-kernel timing pass
+    tabs = handle["segs"][0]["tabs"]
+    # per-kernel timing: HIP events that the library attaches to the dispatches of the two kernels of each step (the
+    # kernels' own start / end timestamps), on a second pass over already planned batches — outside the throughput
+    # measurement, so nothing extra sits in the timed region.
+    events, KP = None, 0
     if not args.no_phase_events:
-        KP = min(K, 64, res[0][0].n_batches)
+        KP = min(K, 64, plan.n_batches)
         events = [torch.cuda.Event(enable_timing=True) for _ in range(4 * KP)]
         for e in events:
             e.record()
         torch.cuda.synchronize()
-        tabs.run_sgd(res[0][0], 0, KP, args.lr, phase_events=events)
+        tabs.run_sgd(plan, 0, KP, args.lr, phase_events=events)
         torch.cuda.synchronize()
 
-    losses = torch.cat([r[1] for r in res]).cpu().numpy()
-    assert np.all(np.isfinite(losses)), "non-finite loss"
+    lv = losses.cpu().numpy()
+    assert np.all(np.isfinite(lv)), "non-finite loss"
     value = K * B / dt
 
     # unique rows per step (for algorithmic bytes with in-batch duplicates counted once, SURVEY.md §8d)
-    uniq_u = uniq_i = single_i = 0
-    n_stat = 0
-    for plan, _ in res:
-        if plan is None:
-            continue
-        nb = plan.n_batches
-        n_stat += nb
-        tu = plan.tu.view(nb, B)
-        oi = plan.oc_item.view(nb, 2 * B)
-        uniq_u += int((tu[:, 1:] != tu[:, :-1]).sum().item()) + nb
-        uniq_i += int((oi[:, 1:] != oi[:, :-1]).sum().item()) + nb
-        single_i += int((plan.tp >= 0).sum().item()) + int((plan.tn >= 0).sum().item())  # rows with one occurrence
-    uniq_u /= n_stat                   # averages over the first n_stat steps of the timed region
-    uniq_i /= n_stat
-    single_i /= n_stat
+    nb = plan.n_triplets // B          # whole batches of the plan
+    tu = plan.tu[:nb * B].view(nb, B)
+    oi = plan.oc_item[:2 * nb * B].view(nb, 2 * B)
+    uniq_u = (int((tu[:, 1:] != tu[:, :-1]).sum().item()) + nb) / nb
+    uniq_i = (int((oi[:, 1:] != oi[:, :-1]).sum().item()) + nb) / nb
+    single_i = (int((plan.tp[:nb * B] >= 0).sum().item()) + int((plan.tn[:nb * B] >= 0).sum().item())) / nb
     row = D * 4
     # Algorithmic bytes (SURVEY.md §8d): every unique row of the batch read once and written once + 12 B of indices
     # per triplet.  Split by who does it: the user phase reads all of them, writes the user rows and the
@@ -277,14 +268,12 @@ def main():
 
     roofline = None
     if events is not None:
-        # the dispatches' own start / end timestamps (events attached to the kernels by the library: what rocprofv3
-        # reports per dispatch; no marker packets in the stream)
         t_user = np.mean([events[4 * k].elapsed_time(events[4 * k + 1]) for k in range(KP)]) * 1e-3
         t_item = np.mean([events[4 * k + 2].elapsed_time(events[4 * k + 3]) for k in range(KP)]) * 1e-3
         if t_item >= t_user:
-            name, tk, bk = "bprmf_item_phase<16,1,true,0>", t_item, bytes_item
+            name, tk, bk = "bprmf_item_phase", t_item, bytes_item
         else:
-            name, tk, bk = "bprmf_user_phase<16,1,true,0>", t_user, bytes_user
+            name, tk, bk = "bprmf_user_phase", t_user, bytes_user
         ach = bk / tk / 1e9
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": None, "kernel": name, "kernel_us": tk * 1e6, "algorithmic_bytes_per_launch": bk,
@@ -300,16 +289,18 @@ def main():
                     "read_only_algorithmic_bytes_per_launch": row * (uniq_u + uniq_i) + 12 * B,
                     "read_only_GBs": (row * (uniq_u + uniq_i) + 12 * B) / t_user / 1e9,
                     "read_only_frac": (row * (uniq_u + uniq_i) + 12 * B) / t_user / 1e9 / HBM_PEAK_GBS}
-
-    if roofline is not None:
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE, separate passes: scripts/pmc_passes.sh); only valid for the configuration it was collected on.
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_configs1.json")
+        # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+        # passes: scripts/pmc_passes.sh) cannot run inside this process, so the figure comes from the committed summary — and
+        # only when that summary was taken on THESE kernel sources and this configuration; otherwise null.
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_configs1.json")
         if os.path.exists(pmc) and (B, D, args.users, args.items, args.zipf) == (65536, 64, 1_000_000, 1_000_000, 0.0):
-            for k, v in json.load(open(pmc)).items():
-                if roofline["kernel"].split("<")[0] in k:
-                    roofline["traffic"] = v["hbm_bytes"]
-                    roofline["traffic_source"] = "profiles/r01_pmc_traffic_configs1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            rec = json.load(open(pmc))
+            if rec.get("csrc_sha") == csrc_sha():
+                for k, v in rec.get("kernels", {}).items():
+                    if k.startswith(name):
+                        roofline["traffic"] = v["hbm_bytes"]
+                        roofline["traffic_source"] = "profiles/r02_pmc_traffic_configs1.json (rocprofv3 --pmc FETCH_SIZE / " \
+                                                     "WRITE_SIZE on kernel sources %s)" % rec["csrc_sha"]
     out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": 1, "steps": K,
            "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
@@ -317,14 +308,98 @@ def main():
                                   "plan build in timed region" % (D, args.users, args.items,
                                                                   "uniform" if args.zipf == 0 else "zipf(%.2f) item" % args.zipf, B),
                       "batch": B, "emb_size": D, "optimizer": "SGD", "l2": 0.0, "lr": args.lr,
-                      "plan_chunk_batches": args.chunk, "tables": "single GPU"},
-           "loss_first": float(losses[0]), "loss_last": float(losses[-1]),
+                      "plan_chunk_batches": C, "tables": "single GPU", "step_stream": "whisprrec_amd.hip_ops.PipelinedSgd"},
+           "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
            "roofline": roofline}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         out["cpu_baseline_torch"] = cpu_torch_sequence(args, max(4.0, args.cpu_seconds / 2))
     print(json.dumps(out))
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------- N > 1
+def multi_gpu(args, rank, world, local_rank):
+    """One rank per GPU (RCCL).  Runs the sharding mode(s) asked for back to back inside one process group and prints one
+    line: `value` is the stratified-rotation mode's unless only 'alltoall' was asked for; every mode's numbers are under
+    `modes`."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
+    if args.dry_run:
+        dist.init_process_group(args.backend if args.backend == "gloo" else "gloo")
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps(multi_line(args, world, {}, None, dry_run=True)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=dev)
+    modes = ["rotate", "alltoall"] if args.shard_mode == "both" else [args.shard_mode]
+    results = {}
+    for mode in modes:
+        if mode == "rotate":
+            from whisprrec_amd import rotating
+            res = rotating.bench_run(args, rank, world, dev)
+        else:
+            from whisprrec_amd import sharded
+            res = sharded.bench_run(args, rank, world, dev)
+        if rank == 0:
+            results[mode] = res
+        torch.cuda.synchronize()
+        dist.barrier()
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, min(args.cpu_seconds, 8.0))
+    if rank == 0:
+        print(json.dumps(multi_line(args, world, results, cpu)))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def multi_line(args, world, results, cpu, dry_run=False):
+    """the N>1 JSON line from the per-mode results (also the skeleton the CPU dry run of the launcher prints)"""
+    B, D = args.batch, args.emb
+    primary = "alltoall" if args.shard_mode == "alltoall" else "rotate"
+    head = results.get(primary, {})
+    out = {"metric": "BPR training triplets/sec", "value": head.get("value"), "unit": "triplets/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": head.get("ms_per_step"), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BPRMF emb_size=%d, synthetic %d users x %d items (uniform ids), batch %d per GPU (global "
+                                  "%d), SGD l2=0, tables row-sharded over %d GPUs, plan build and exchange in timed region"
+                                  % (D, args.users, args.items, B, B * world, world),
+                      "batch_per_gpu": B, "global_batch": B * world, "emb_size": D, "optimizer": "SGD", "l2": 0.0,
+                      "lr": args.lr, "rccl_world_size": world, "ranks": "one process per GPU, torch.distributed nccl (=RCCL)",
+                      "parallelism": head.get("parallelism", primary), "value_from_mode": primary,
+                      "sampling": head.get("sampling")},
+           "roofline": head.get("roofline"), "modes": results}
+    if dry_run:
+        out["dry_run"] = True
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args, argv)          # plain `python bench.py --gpus N`: start the N ranks ourselves
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        raise SystemExit("bench.py --gpus %d runs under WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 or args.force_sharded:
+        return multi_gpu(args, rank, world, local_rank)
+    return single_gpu(args, local_rank)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -595,13 +595,14 @@ def test_pipelined_sgd_switches_to_the_bucket_map_on_skewed_ids(ops, dev):
     seen = []
     orig = ops.BatchPlan.__init__
     def spy(self, *a, **k):
-        orig(self, *a, **k); seen.append(self.builder)
+        orig(self, *a, **k); seen.append(self)
     ops.BatchPlan.__init__ = spy
     try:
         pipe.run(h, 0, 0.05, losses)
     finally:
         ops.BatchPlan.__init__ = orig
     torch.cuda.synchronize()
+    seen = [pl.builder for pl in seen]      # plans are built deferred: the builder is known once they were used
     assert h["map"] and "fast+map" in seen, seen
     ref = ops.BprmfTables(T(U, dev), T(I, dev))
     plan = ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI, builder="generic")

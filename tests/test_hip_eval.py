@@ -20,8 +20,20 @@ def _mask_csr(rng, nU, nI, max_len):
     return ptr, np.concatenate(chunks) if chunks else np.zeros(1, np.int32)
 
 
+def test_embedding_sizes_beyond_the_lds_are_refused_not_launched():
+    """the LDS-operand kernel needs (128 + 32) * (D + 1) * 4 + 512 B: 164,992 B at D = 256, more than gfx950's 163,840 B per
+    workgroup — wr_rank_eval must say so (WR_E_RANGE) instead of failing at launch; HipRunner.evaluate then takes the host path"""
+    from whisprrec_amd import abi, hip_ops
+    dev = torch.device("cuda:0")
+    assert hip_ops.rank_eval_supports(252) and not hip_ops.rank_eval_supports(256) and hip_ops.rank_eval_supports(64)
+    z = torch.zeros(8, 256, device=dev)
+    i = torch.zeros(4, dtype=torch.int64, device=dev)
+    with pytest.raises(abi.WhisprRecHipError, match="D <= 252"):
+        hip_ops.rank_eval(z, z, i, i)
+
+
 @pytest.mark.parametrize("D,nI,n", [(64, 1574, 700), (32, 5000, 300), (128, 333, 200), (64, 40, 130), (16, 2100, 257), (8, 777, 129),
-                                    (24, 500, 100), (64, 4133, 1000)])
+                                    (24, 500, 100), (64, 4133, 1000), (192, 700, 150), (252, 600, 140)])
 def test_ranks_match_oracle(D, nI, n):
     from whisprrec_amd import hip_ops
     dev = torch.device("cuda:0")

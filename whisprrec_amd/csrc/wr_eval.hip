@@ -284,7 +284,12 @@ int32_t wr_rank_eval(const float *user_mat, int64_t n_user_rows, const float *it
     WR_REQUIRE(eval_user && eval_target && rank && target_score, WR_E_NULL, "rank_eval: NULL argument");
     WR_REQUIRE((mask_ptr == nullptr) == (mask_idx == nullptr), WR_E_NULL, "rank_eval: mask_ptr and mask_idx go together");
     WR_REQUIRE(n >= 0 && n < (int64_t(1) << 31), WR_E_SHAPE, "rank_eval: n out of range");
-    WR_REQUIRE(D <= 256, WR_E_RANGE, "rank_eval supports D <= 256 (LDS staging); got %d", D);
+    // D outside {8,16,32,64}: the LDS-operand kernel stages (kEvalRows + 32) rows of D + 1 floats + kEvalRows counters; a
+    // workgroup gets at most 160 KiB (163,840 B) on gfx950 -> D <= 252
+    const size_t lds_generic = ((size_t)(kEvalRows + 32) * (D + 1) + kEvalRows) * 4;
+    WR_REQUIRE(D == 64 || D == 32 || D == 16 || D == 8 || lds_generic <= 160 * 1024, WR_E_RANGE,
+               "rank_eval supports D <= 252 (LDS staging: %lld B needed, 163840 B per workgroup); got D=%d",
+               (long long)lds_generic, D);
     if (n == 0) return WR_OK;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     WR_HIP(hipMemsetAsync(rank, 0, (size_t)n * 4, stream));
@@ -302,7 +307,7 @@ int32_t wr_rank_eval(const float *user_mat, int64_t n_user_rows, const float *it
         else WR_EVAL_REGA(4);
 #undef WR_EVAL_REGA
     } else {
-        const size_t lds = ((size_t)(kEvalRows + 32) * (D + 1) + kEvalRows) * 4;
+        const size_t lds = lds_generic;
         if (lds > 64 * 1024)
             WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_rank_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -189,19 +189,84 @@ class BucketMap:
                     a.record_stream(stream)
 
 
+class PlanArena:
+    """Pre-sized home of ONE plan's arrays (sorted triplets, occurrence lists, hot-run lists, flags + counts and their
+    pinned host mirror), allocated once before a step stream starts.  A BatchPlan built into an arena makes no allocation
+    (`torch.empty` of a new size ends in hipMalloc, which stalls the host long enough to drain the queue) and its small
+    read-back is an asynchronous copy into pinned memory that is consumed when the plan is first used.  PipelinedSgd
+    keeps two arenas and alternates them: chunk c+1 is built while chunk c trains."""
+
+    def __init__(self, device, max_triplets, batch_size, hot=True, overlap_items=0):
+        N, B = int(max_triplets), int(batch_size)
+        self.device, self.max_triplets, self.batch_size = device, N, B
+        self.max_batches = (N + B - 1) // B
+        i32 = dict(dtype=torch.int32, device=device)
+        self.idx = torch.empty(7 * N, **i32)                       # tu | tp | tn | oc_item (2N) | oc_src (2N)
+        n_meta = BatchPlan.meta_len(self.max_batches)
+        self.meta = torch.zeros(n_meta, **i32)
+        self.meta_host = torch.zeros(n_meta, dtype=torch.int32, pin_memory=True)
+        self.hot_sides = None
+        if hot:
+            self.hot_sides = []
+            for kind in (0, 1):
+                cp, cr = hot_caps(B, kind)
+                buf = torch.empty(self.max_batches * (2 * cp + 3 * cr), **i32)
+                self.hot_sides.append((buf, cp, cr))
+        # overlap marks (wr_bprmf_plan_overlap_marks): per batch a bitmap of the item rows with several occurrences, a
+        # bitmask of the deferred run heads and their list
+        self.overlap = None
+        if overlap_items > 0:
+            words = (int(overlap_items) + 31) // 32
+            dwords = (B + 31) // 32
+            self.overlap = {"words": words, "dwords": dwords, "cap": overlap_def_cap(B),
+                            "bitmap": torch.empty(self.max_batches * words, **i32),
+                            "tdef": torch.empty(self.max_batches * dwords, **i32),
+                            "def_q": torch.empty(self.max_batches * overlap_def_cap(B), **i32)}
+        self.free = None      # event on the consuming stream: every step that reads this arena's arrays has run
+
+    def release_after(self, stream):
+        """the arena's arrays are read by work queued on `stream` up to here; the next build into it waits for that"""
+        self.free = torch.cuda.Event()
+        self.free.record(stream)
+
+
+def hot_caps(batch_size, kind):
+    cp, cr = ctypes.c_int64(0), ctypes.c_int64(0)
+    abi.lib().wr_bprmf_hot_caps(int(batch_size), kind, ctypes.addressof(cp), ctypes.addressof(cr))
+    return cp.value, cr.value
+
+
+def overlap_def_cap(batch_size):
+    """capacity of a batch's list of deferred user runs (overlapped step stream)"""
+    return max(256, int(batch_size) // 8)
+
+
 class BatchPlan:
     """Sorted batches for the fused step (see include/whisprrec_hip.h, "Batch plan").
 
     ``u, p, n`` are the epoch's triplets in batch order (int64 as in the reference, or int32); batch k is
-    ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201)."""
+    ``[k*batch_size, (k+1)*batch_size)``, the last one may be short (no drop_last, BaseRunner.py:201).
+
+    The small device-to-host read-back a plan needs (index-range flag, bucket-overflow flag of the hand-written builder,
+    hot-run counts) is either taken at once (default: the constructor returns a finished plan) or, with ``defer=True``,
+    queued as an asynchronous copy into pinned memory behind the build and consumed by ``finish()`` — which every consumer
+    of the plan's host-side state calls, and which costs nothing once the build has run."""
+
+    META_HEAD = 2
+
+    @staticmethod
+    def meta_len(n_batches):
+        """[0] index out of range, [1] fast-builder bucket overflow, then per batch the number of hot-run pieces and hot
+        runs (items, users: wr_bprmf_plan_hot_runs), then per batch the number of deferred user runs (overlap marks)"""
+        return BatchPlan.META_HEAD + 5 * int(n_batches)
 
     def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="auto",
-                 hot=True, bucket_map=None):
+                 hot=True, bucket_map=None, arena=None, defer=False):
         """builder: "auto" (default) = hand-written bucket/LDS-sort builder when applicable, generic radix-sort builder
         otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one.
         bucket_map: a BucketMap of the epoch these batches come from — load-balanced buckets for the hand-written builder
-        (skewed ids); ``fast_overflowed`` tells afterwards whether the hand-written builder was tried and gave up."""
-        L = abi.lib()
+        (skewed ids); ``fast_overflowed`` tells afterwards whether the hand-written builder was tried and gave up.
+        arena: a PlanArena to build into (no allocation); defer: do not wait for the read-back (see finish())."""
         if u.dtype not in (torch.int64, torch.int32):
             raise TypeError("indices must be int64 or int32")
         dt = u.dtype
@@ -215,114 +280,196 @@ class BatchPlan:
         self.n_triplets, self.batch_size = N, int(batch_size)
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.n_batches = (N + self.batch_size - 1) // self.batch_size
+        self._src = (u, p, n)
+        self._ws_tag, self._want_hot, self._bucket_map = ws_tag, bool(hot), bucket_map
+        self._stream = torch.cuda.current_stream(dev)
+        self.arena = arena
         i32 = dict(dtype=torch.int32, device=dev)
-        self.tu, self.tp, self.tn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
+        if arena is not None:
+            if arena.batch_size != self.batch_size or N > arena.max_triplets or (hot and arena.hot_sides is None):
+                raise ValueError("plan does not fit its arena")
+            if arena.free is not None:                       # steps that still read the arena's previous plan
+                self._stream.wait_event(arena.free)
+                arena.free = None
+            a, M = arena.idx, arena.max_triplets
+            self.tu, self.tp, self.tn = a[:N], a[M:M + N], a[2 * M:2 * M + N]
+            self.oc_item, self.oc_src = a[3 * M:3 * M + 2 * N], a[5 * M:5 * M + 2 * N]
+            self.meta = arena.meta[:self.meta_len(self.n_batches)]
+            self.meta.zero_()
+            self._pinned = arena.meta_host[:self.meta_len(self.n_batches)]
+        else:
+            self.tu, self.tp, self.tn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
+            self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
+            self.meta = torch.zeros(self.meta_len(self.n_batches), **i32)
+            self._pinned = None
         self.torig = torch.empty(N, **i32) if keep_orig else None
-        self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
-        # one small tensor read back per plan: [0] index out of range, [1] fast-builder bucket overflow, then per batch
-        # the number of hot-run pieces and hot runs (wr_bprmf_plan_hot_runs)
-        self.meta = torch.zeros(2 + 4 * self.n_batches, **i32)
         self.flags = self.meta[:2]
         self.err = self.flags[:1]
         self.hot = None
         self.builder = None
-        args = (N, self.batch_size, self.n_users, self.n_items)
+        self.overlap = None
+        self.meta_host = None
+        self.ready = None
+        self.fast_overflowed = False
+        self._finished = False
+        self._sides = None
+        self._tried = None           # "fast" / "fast+map": the hand-written builder ran and its overflow flag is pending
         # "auto": ids skewed enough to overflow a bucket keep doing so chunk after chunk — after an overflow the next 32
         # plans of the same shape go straight to the radix-sort builder instead of paying for a failed attempt each
-        backoff_key = (str(dev), self.batch_size, self.n_users, self.n_items)
-        self.fast_overflowed = False
-        mapped = bucket_map is not None and (bucket_map.users is not None or bucket_map.items is not None) and \
-            bucket_map.batch_size == self.batch_size
-        if builder == "auto" and not mapped and _FAST_BACKOFF.get(backoff_key, 0) > 0:
-            _FAST_BACKOFF[backoff_key] -= 1
+        self._backoff_key = (str(dev), self.batch_size, self.n_users, self.n_items)
+        mapped = self._mapped()
+        if builder == "auto" and not mapped and _FAST_BACKOFF.get(self._backoff_key, 0) > 0:
+            _FAST_BACKOFF[self._backoff_key] -= 1
             builder = "generic"
             self.fast_overflowed = True
-        self.meta_host = None
-        if builder in ("auto", "fast"):
-            if mapped:
-                mu, mi = bucket_map.users, bucket_map.items          # a side without a map keeps its equal-width buckets
-                nbytes = abi.check_size(L.wr_bprmf_plan_fast_mapped_workspace_bytes(*args, mu["n_buckets"] if mu else 0,
-                                                                                    mi["n_buckets"] if mi else 0),
-                                        "wr_bprmf_plan_fast_mapped_workspace_bytes")
-            else:
-                nbytes = abi.check_size(L.wr_bprmf_plan_fast_workspace_bytes(*args), "wr_bprmf_plan_fast_workspace_bytes")
-            if nbytes > 0:
-                ws = workspace(dev, ws_tag + ("_fastmap" if mapped else "_fast")).get(nbytes)
-                sides = self._hot_arrays(dev) if hot else None
-                outs = (_p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.flags),
-                        _p(ws), ws.numel(), _stream())
-                if mapped:
-                    fn = L.wr_bprmf_plan_build_fast_mapped_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_mapped_i32
-                    abi.check(fn(_p(u), _p(p), _p(n), *args, ctypes.addressof(mu["struct"]) if mu else None,
-                                 ctypes.addressof(mi["struct"]) if mi else None, *outs), "wr_bprmf_plan_build_fast_mapped")
-                else:
-                    fn = L.wr_bprmf_plan_build_fast_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_i32
-                    abi.check(fn(_p(u), _p(p), _p(n), *args, *outs), "wr_bprmf_plan_build_fast")
-                # ONE read-back per plan: the overflow flag travels with the hot-run counts (the hot-run scan is bounds-safe
-                # for any key values; after an overflow its output is thrown away with the plan)
-                if hot:
-                    self._plan_hot_runs(dev, sides)
-                else:
-                    self.meta_host = self.meta.cpu()
-                if int(self.meta_host[1]) == 0:
-                    self.builder = "fast+map" if mapped else "fast"
-                elif builder == "fast":
-                    raise abi.WhisprRecHipError("fast plan builder: bucket overflow (skewed ids)")
-                else:
-                    self.meta.zero_()
-                    self.meta_host, self.hot = None, None
-                    self.fast_overflowed = True
-                    if not mapped:
-                        _FAST_BACKOFF[backoff_key] = 32
-            elif builder == "fast":
+        self._builder_arg = builder
+        if builder in ("auto", "fast") and not self._build_fast():
+            if builder == "fast":
                 raise abi.WhisprRecHipError("fast plan builder not applicable to this batch size")
-        if self.builder is None:
-            nbytes = abi.check_size(L.wr_bprmf_plan_workspace_bytes(*args), "wr_bprmf_plan_workspace_bytes")
-            ws = workspace(dev, ws_tag).get(nbytes)  # distinct tags allow plan builds in flight on different streams
-            fn = L.wr_bprmf_plan_build_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_i32
-            abi.check(fn(_p(u), _p(p), _p(n), *args, _p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig),
-                         _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(), _stream()),
-                      "wr_bprmf_plan_build")
-            self.builder = "generic"
-            if hot:
-                self._plan_hot_runs(dev)
-        if validate:
-            self.validate()
+        if self._tried is None:
+            self._build_generic()
+        self._queue_readback()
+        if not defer:
+            self.finish()
+            if validate:
+                self.validate()
+
+    # ------------------------------------------------------------------ builders (enqueue only)
+    def _mapped(self):
+        bm = self._bucket_map
+        return bm is not None and (bm.users is not None or bm.items is not None) and bm.batch_size == self.batch_size
+
+    def _build_fast(self):
+        """enqueue the hand-written builder (+ hot-run scan); False when it does not apply to this shape"""
+        L = abi.lib()
+        u, p, n = self._src
+        dt, dev = u.dtype, u.device
+        args = (self.n_triplets, self.batch_size, self.n_users, self.n_items)
+        mapped = self._mapped()
+        if mapped:
+            mu, mi = self._bucket_map.users, self._bucket_map.items      # a side without a map keeps its equal-width buckets
+            nbytes = abi.check_size(L.wr_bprmf_plan_fast_mapped_workspace_bytes(*args, mu["n_buckets"] if mu else 0,
+                                                                                mi["n_buckets"] if mi else 0),
+                                    "wr_bprmf_plan_fast_mapped_workspace_bytes")
+        else:
+            nbytes = abi.check_size(L.wr_bprmf_plan_fast_workspace_bytes(*args), "wr_bprmf_plan_fast_workspace_bytes")
+        if nbytes <= 0:
+            return False
+        ws = workspace(dev, self._ws_tag + ("_fastmap" if mapped else "_fast")).get(nbytes)
+        if self._want_hot:
+            self._sides = self._hot_arrays(dev)      # before the plan kernels: no host-side allocation between build and scan
+        outs = (_p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.flags),
+                _p(ws), ws.numel(), _stream())
+        if mapped:
+            fn = L.wr_bprmf_plan_build_fast_mapped_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_mapped_i32
+            abi.check(fn(_p(u), _p(p), _p(n), *args, ctypes.addressof(mu["struct"]) if mu else None,
+                         ctypes.addressof(mi["struct"]) if mi else None, *outs), "wr_bprmf_plan_build_fast_mapped")
+        else:
+            fn = L.wr_bprmf_plan_build_fast_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_i32
+            abi.check(fn(_p(u), _p(p), _p(n), *args, *outs), "wr_bprmf_plan_build_fast")
+        self._tried = "fast+map" if mapped else "fast"
+        # the hot-run scan is bounds-safe for any key values; after an overflow its output is thrown away with the plan
+        if self._want_hot:
+            self._enqueue_hot_runs()
+        return True
+
+    def _build_generic(self):
+        L = abi.lib()
+        u, p, n = self._src
+        dev = u.device
+        args = (self.n_triplets, self.batch_size, self.n_users, self.n_items)
+        nbytes = abi.check_size(L.wr_bprmf_plan_workspace_bytes(*args), "wr_bprmf_plan_workspace_bytes")
+        ws = workspace(dev, self._ws_tag).get(nbytes)  # distinct tags allow plan builds in flight on different streams
+        fn = L.wr_bprmf_plan_build_i64 if u.dtype == torch.int64 else L.wr_bprmf_plan_build_i32
+        abi.check(fn(_p(u), _p(p), _p(n), *args, _p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig),
+                     _p(self.oc_item), _p(self.oc_src), _p(self.err), _p(ws), ws.numel(), _stream()),
+                  "wr_bprmf_plan_build")
+        self.builder = "generic"
+        self._tried = "generic"
+        if self._want_hot:
+            if self._sides is None:
+                self._sides = self._hot_arrays(dev)
+            self._enqueue_hot_runs()
 
     def _hot_arrays(self, dev):
-        """list arrays of the hot-run scan, allocated BEFORE the plan kernels are enqueued so that the scan follows the build
-        on the stream without a host-side allocation between them"""
-        L = abi.lib()
+        """list arrays of the hot-run scan: views of the arena, or fresh tensors"""
         i32 = dict(dtype=torch.int32, device=dev)
+        nb = self.n_batches
         sides = []
         for kind in (0, 1):
-            cp, cr = ctypes.c_int64(0), ctypes.c_int64(0)
-            L.wr_bprmf_hot_caps(self.batch_size, kind, ctypes.addressof(cp), ctypes.addressof(cr))
-            cp, cr = cp.value, cr.value
-            arrs = [torch.empty(self.n_batches * cp, **i32), torch.empty(self.n_batches * cp, **i32),
-                    torch.empty(self.n_batches * cr, **i32), torch.empty(self.n_batches * cr, **i32),
-                    torch.empty(self.n_batches * cr, **i32)]
+            if self.arena is not None:
+                buf, cp, cr = self.arena.hot_sides[kind]
+                m = self.arena.max_batches
+                arrs = [buf[:nb * cp], buf[m * cp:m * cp + nb * cp], buf[2 * m * cp:2 * m * cp + nb * cr],
+                        buf[2 * m * cp + m * cr:2 * m * cp + m * cr + nb * cr],
+                        buf[2 * m * cp + 2 * m * cr:2 * m * cp + 2 * m * cr + nb * cr]]
+            else:
+                cp, cr = hot_caps(self.batch_size, kind)
+                arrs = [torch.empty(nb * cp, **i32), torch.empty(nb * cp, **i32), torch.empty(nb * cr, **i32),
+                        torch.empty(nb * cr, **i32), torch.empty(nb * cr, **i32)]
             sides.append((arrs, cp, cr))
         return sides
 
-    def _plan_hot_runs(self, dev, sides=None):
+    def _enqueue_hot_runs(self):
         """Cuts table rows with more than 32 occurrences in a batch (item rows: runs of oc_item; user rows: runs of tu) into
-        pieces for the many-workgroup path (power-law ids); one device-to-host copy of the small meta tensor tells whether
-        there are any."""
+        pieces for the many-workgroup path (power-law ids); the per-batch counts travel with the plan's flags."""
         L = abi.lib()
-        counts = self.meta[2:]
-        if sides is None:
-            sides = self._hot_arrays(dev)
-        for (kind, keys), (arrs, _, _) in zip(((0, self.oc_item), (1, self.tu)), sides):
+        counts = self.meta[self.META_HEAD:self.META_HEAD + 4 * self.n_batches]
+        for (kind, keys), (arrs, _, _) in zip(((0, self.oc_item), (1, self.tu)), self._sides):
             abi.check(L.wr_bprmf_plan_hot_runs(_p(keys), kind, self.n_triplets, self.batch_size, *[_p(a) for a in arrs],
                                                _p(counts), _stream()), "wr_bprmf_plan_hot_runs")
-        self.meta_host = self.meta.cpu()
-        counts_host = self.meta_host[2:].contiguous()
-        if int(counts_host.sum().item()) > 0:
-            self.hot = {"sides": sides, "counts_host": counts_host}
+
+    def _queue_readback(self):
+        """ONE small read-back per plan: flags + hot-run counts (+ deferred-run counts).  With an arena it is an asynchronous
+        copy into pinned memory and an event; finish() waits for the event."""
+        if self._pinned is not None:
+            self._pinned.copy_(self.meta, non_blocking=True)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self._stream)
+
+    # ------------------------------------------------------------------ host-side completion
+    def _read_meta(self):
+        if self._pinned is not None:
+            self.ready.synchronize()
+            return self._pinned
+        return self.meta.cpu()
+
+    def finish(self):
+        """Makes the plan's host-side state final: waits for the read-back (no wait at all once the build has run, which is
+        the normal case one chunk ahead of the steps), falls back to the radix-sort builder after a bucket overflow, and
+        publishes the hot-run counts.  Idempotent.  A plan that has nothing to report (radix-sort builder, no hot-run scan)
+        is finished without any device-to-host traffic; its index-range flag is read by validate() on demand."""
+        if self._finished:
+            return self
+        mh = None
+        while self._tried in ("fast", "fast+map") or self._want_hot:
+            mh = self._read_meta()
+            if self._tried in ("fast", "fast+map") and int(mh[1]) != 0:
+                if self._builder_arg == "fast":
+                    raise abi.WhisprRecHipError("fast plan builder: bucket overflow (skewed ids)")
+                self.fast_overflowed = True
+                if self._tried == "fast":
+                    _FAST_BACKOFF[self._backoff_key] = 32
+                with torch.cuda.stream(self._stream):        # rebuild where the plan was built (rare: skewed ids without a map)
+                    self.meta.zero_()
+                    self._build_generic()
+                    self._queue_readback()
+                mh = None                                    # stale: the rebuilt plan reports again
+                continue
+            break
+        self.meta_host = mh
+        if self.builder is None:
+            self.builder = self._tried
+        if self._want_hot:
+            counts_host = mh[self.META_HEAD:self.META_HEAD + 4 * self.n_batches]
+            if int(counts_host.sum().item()) > 0:
+                self.hot = {"sides": self._sides, "counts_host": counts_host}
+        self._finished = True
+        return self
 
     def hot_struct(self, batch=None):
         """ctypes wr_hot_runs for the whole plan (batch=None) or for one batch; None when the plan has no hot runs."""
+        self.finish()
         if self.hot is None:
             return None
         k = 0 if batch is None else batch
@@ -334,9 +481,10 @@ class BatchPlan:
         return abi.HotRuns(*vals, self.hot["counts_host"].data_ptr() + 16 * k, cp0, cr0, cp1, cr1)
 
     def validate(self):
-        """nn.Embedding raises IndexError for out-of-range ids; so does the plan (one sync)."""
+        """nn.Embedding raises IndexError for out-of-range ids; so does the plan."""
+        self.finish()
         if self.meta_host is None:
-            self.meta_host = self.meta.cpu()
+            self.meta_host = self._read_meta()
         if int(self.meta_host[0].item()) != 0:
             raise IndexError("index out of range in batch (user_id >= n_users or item id >= n_items)")
 
@@ -345,12 +493,14 @@ class BatchPlan:
 
     def record_stream(self, stream):
         """A plan built on a side stream and consumed on `stream`: tell the caching allocator, so that dropping the plan
-        while its steps are still queued does not hand the arrays to the next build."""
+        while its steps are still queued does not hand the arrays to the next build.  (Arena plans: PlanArena.release_after.)"""
+        if self.arena is not None:
+            return
         ts = [self.tu, self.tp, self.tn, self.oc_item, self.oc_src, self.meta]
         if self.torig is not None:
             ts.append(self.torig)
-        if self.hot is not None:
-            for arrs, _, _ in self.hot["sides"]:
+        if self._sides is not None:
+            for arrs, _, _ in self._sides:
                 ts += arrs
         for t in ts:
             t.record_stream(stream)
@@ -523,6 +673,18 @@ def clicked_csr(train_clicked_set, n_users, device):
 
 
 # ----------------------------------------------------------------------------------------------- evaluation
+LDS_PER_WORKGROUP = 160 * 1024      # gfx950: 163,840 B per workgroup
+
+
+def rank_eval_supports(D):
+    """embedding sizes wr_rank_eval takes: the register-operand kernel for D in {8, 16, 32, 64}, otherwise the LDS-operand
+    kernel, which stages (128 + 32) rows of D + 1 floats and 128 counters — D <= 252 on gfx950's 160 KiB of LDS"""
+    D = int(D)
+    if D % 4 != 0 or D < 4:
+        return False
+    return D in (8, 16, 32, 64) or ((128 + 32) * (D + 1) + 128) * 4 <= LDS_PER_WORKGROUP
+
+
 def rank_eval(user_mat, item_tab, eval_user, eval_target, mask_ptr=None, mask_idx=None):
     """Rank of the ground-truth item among all (unmasked) items for every evaluation row (reference
     BaseRunner.interface + evaluate_method); returns (rank int32 [n], target_score fp32 [n])."""
@@ -577,25 +739,44 @@ class PipelinedSgd:
     segments (item table view + indices; one segment for a whole epoch on one GPU, one per part of the held block in the
     stratified multi-GPU schedule).  Batches are planned a chunk at a time on a side stream, one chunk ahead of the steps
     (a plan depends only on the indices, never on the tables) — across segment boundaries too — and a segment's steps are
-    issued from native code (wr_bprmf_run_sgd).  A chunk is at least ``chunk`` batches and at least PLAN_TRIPLETS triplets:
-    a plan costs a fixed ~0.2 ms of host time (allocations, one read-back), which 64 small batches do not amortise
-    (scripts/exp/small_batch_pace.py, us/step with 64 batches per plan -> with 4 M triplets per plan: B = 2,048 11.1 -> 8.8,
-    B = 16,384 17.8 -> 12.9; B = 65,536 is 64 batches either way)."""
+    issued from native code (wr_bprmf_run_sgd).  A chunk is at least ``chunk`` batches and at least PLAN_TRIPLETS triplets
+    (64 small batches do not amortise a plan's fixed host cost: scripts/exp/small_batch_pace.py, us/step with 64 batches per
+    plan -> with 4 M triplets per plan: B = 2,048 11.1 -> 8.8, B = 16,384 17.8 -> 12.9; B = 65,536 is 64 batches either way).
+
+    Nothing in the step stream waits on the host or allocates: plans are built into two pre-sized arenas (PlanArena) that
+    alternate, and a plan's flags and hot-run counts come back through an asynchronous copy into pinned memory that is read
+    when the plan's first step is queued — by then the build has long run, one chunk ahead (BatchPlan.finish)."""
 
     PLAN_TRIPLETS = 1 << 22
 
-    def __init__(self, chunk=64):
+    def __init__(self, chunk=64, min_triplets=None):
         import sys
         self.ops = sys.modules[__name__]
         self.chunk = int(chunk)
+        if min_triplets is not None:
+            self.PLAN_TRIPLETS = int(min_triplets)
         self.plan_stream = None
+        self._arenas = {}
 
     def chunk_batches(self, batch_size):
         return max(self.chunk, self.PLAN_TRIPLETS // max(int(batch_size), 1))
 
-    def plan(self, U, segments, batch):
+    def _arena_pair(self, device, B, nb_total):
+        """two arenas for plans of up to chunk_batches(B) batches of B triplets (never more than the work at hand), kept
+        across epochs"""
+        cap = min(self.chunk_batches(B), max(int(nb_total), 1)) * B
+        key = (str(device), B)
+        pair = self._arenas.get(key)
+        if pair is None or pair[0].max_triplets < cap:
+            pair = [self.ops.PlanArena(device, cap, B), self.ops.PlanArena(device, cap, B)]
+            self._arenas[key] = pair
+        return pair
+
+    def plan(self, U, segments, batch, first_chunk=None):
         """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order.
-        Only the last segment may end with a short batch."""
+        Only the last segment may end with a short batch.  first_chunk: batches in the first plan (default: a full chunk)
+        — lets a caller that consumes the stream piecewise (bench.py: warm-up, then timed steps) put a plan boundary where
+        its pieces meet."""
         if self.plan_stream is None:
             self.plan_stream = side_stream(U.device)
         B = int(batch)
@@ -612,66 +793,91 @@ class PipelinedSgd:
         # are consecutive views of one array (the usual case: slices of an epoch's arrays) are joined without a copy.
         u_all, p_all, n_all = (_join_views([s[j] for s in live]) for j in (1, 2, 3))
         n_items = max([s[0].shape[0] for s in live] or [1])
+        main = torch.cuda.current_stream(U.device)
+        arenas = self._arena_pair(U.device, B, first)
+        for a in arenas:                     # a previous handle may have left steps queued that read these arrays
+            a.release_after(main)
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
-             "at": 0, "tag": 0, "next": None, "cur": None, "map": None}
-        self.plan_stream.wait_stream(torch.cuda.current_stream(U.device))   # the index tensors are ready
+             "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
+             "first_chunk": int(first_chunk) if first_chunk else 0}
+        self.plan_stream.wait_stream(main)   # the index tensors are ready
         self._prefetch(h)
         return h
 
     def _prefetch(self, h):
-        """enqueue the plan of the next chunk of batches on the side stream"""
+        """enqueue the plan of the next chunk of batches on the side stream (no host wait, no allocation)"""
         if h["at"] >= h["nb"]:
             h["next"] = None
             return
         first, B = h["at"], h["B"]
         c = min(self.chunk_batches(B), h["nb"] - first)
+        if first == 0 and h["first_chunk"] > 0:
+            c = min(c, h["first_chunk"])
         h["at"] += c
         lo, hi = first * B, min(h["u"].numel(), (first + c) * B)
         with torch.cuda.stream(self.plan_stream):
             bmap = h["map"] if h["map"] else None
             plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
-                                      validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap)
-            if plan.fast_overflowed:
-                # skewed ids: equal-width buckets overflow chunk after chunk.  Balance the buckets by the rows' share of
-                # the epoch (one pass over the id columns) and use them from the next chunk on; if even those overflow
-                # (batches that are not random samples of the epoch), stay with the radix-sort builder.
-                h["map"] = self.ops.BucketMap(h["u"], h["p"], h["n_users"], h["n_items"], B) if h["map"] is None else False
-            ready = torch.cuda.Event()
-            ready.record(self.plan_stream)
+                                      validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap, arena=h["arenas"][h["tag"]],
+                                      defer=True)
         h["tag"] ^= 1
-        h["next"] = (first, plan, ready)
+        h["next"] = (first, plan)
 
-    def run(self, handle, seg, lr, losses):
-        """all steps of segment `seg` (segments must be run in order); losses: one slot per step"""
-        h = handle
-        sg = h["segs"][seg]
-        if sg["nb"] == 0:
-            return
+    def _take_next(self, h, pos, main):
+        """the prefetched plan becomes the current one: its read-back is consumed here (flags, hot-run counts)"""
+        if h["next"] is None:
+            self._prefetch(h)
+        cur = h["next"]
+        assert cur is not None and cur[0] == pos, "steps must be run in order"
+        plan = cur[1]
+        plan.validate()                      # finish(): waits for the build's event only if the build has not run yet
+        main.wait_event(plan.ready)
+        if plan.fast_overflowed:
+            # skewed ids: equal-width buckets overflow chunk after chunk.  Balance the buckets by the rows' share of
+            # the epoch (one pass over the id columns) and use them from the next chunk on; if even those overflow
+            # (batches that are not random samples of the epoch), stay with the radix-sort builder.
+            if plan._mapped():
+                h["map"] = False
+            elif h["map"] is None:
+                with torch.cuda.stream(self.plan_stream):
+                    h["map"] = self.ops.BucketMap(h["u"], h["p"], h["n_users"], h["n_items"], h["B"])
+        h["cur"], h["next"] = cur, None
+        return cur
+
+    def _run_span(self, h, sg, pos, end, lr, losses, loss_off):
+        """steps [pos, end) of the handle's batch sequence, all inside segment `sg`; losses[loss_off + k] for step pos + k"""
         main = torch.cuda.current_stream(sg["tabs"].U.device)
-        pos, end = sg["first"], sg["first"] + sg["nb"]
         while pos < end:
             cur = h["cur"]
             if cur is None or pos >= cur[0] + cur[1].n_batches:
-                if h["next"] is None:
-                    self._prefetch(h)
-                cur = h["next"]
-                assert cur is not None and cur[0] == pos, "segments must be run in order"
-                main.wait_event(cur[2])
-                cur[1].validate()                                           # flags came back with the hot-run counts: no sync
-                cur[1].record_stream(main)
-                h["cur"], h["next"] = cur, None
-            base, plan, _ = cur
-            # at most 256 steps per native call: the next plan is built (host blocked for its read-back) while these run
-            c = min(min(end, base + plan.n_batches) - pos, 256)
-            off = pos - sg["first"]
-            sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[off:off + c])
+                cur = self._take_next(h, pos, main)
+            base, plan = cur
+            c = min(min(end, base + plan.n_batches) - pos, 256)      # at most 256 steps per native call
+            sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
             pos += c
-            # Build the next plan beside the queued steps.  The build blocks the HOST for its duration (two small read-backs),
-            # so it is started only once enough steps of the current plan are queued to keep the GPU busy meanwhile — with
-            # short segments (a dozen steps) right after a plan change the queue would otherwise run dry.
-            queued = pos - base
-            if h["next"] is None and (queued >= min(32, (plan.n_batches + 1) // 2) or queued >= plan.n_batches):
-                self._prefetch(h)
+            loss_off += c
+            if pos >= base + plan.n_batches:
+                plan.arena.release_after(main)                       # every step that reads the plan's arrays is queued
+            if h["next"] is None:
+                self._prefetch(h)                                    # the next plan is built beside the queued steps
+        h["pos"] = pos
+
+    def run(self, handle, seg, lr, losses):
+        """all steps of segment `seg` (segments must be run in order); losses: one slot per step"""
+        sg = handle["segs"][seg]
+        if sg["nb"] == 0:
+            return
+        self._run_span(handle, sg, sg["first"], sg["first"] + sg["nb"], lr, losses, 0)
+
+    def run_steps(self, handle, count, lr, losses):
+        """the next `count` steps of a single-segment handle (a step stream consumed piecewise: warm-up, then the timed
+        steps of bench.py — the plan pipeline runs on across the calls, as it does inside an epoch)"""
+        assert len(handle["segs"]) == 1, "run_steps: single-segment handles"
+        sg = handle["segs"][0]
+        pos = handle["pos"]
+        if pos + count > sg["nb"]:
+            raise ValueError("run_steps: %d steps asked, %d left" % (count, sg["nb"] - pos))
+        self._run_span(handle, sg, pos, pos + count, lr, losses, 0)
 
 
 class LazyOptimizerState:

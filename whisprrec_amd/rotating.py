@@ -223,18 +223,37 @@ def stratum_steps(n_interactions, world, batch):
 
 
 # ---------------------------------------------------------------------------------------------------- bench (N > 1)
-def bench_main(args, rank, world, local_rank):
-    """bench.py --gpus N (N > 1): weak scaling, batch args.batch per GPU, stratified schedule.  The block rotation happens as
-    often as a full epoch of args.interactions interactions would require (every stratum_steps steps), inside the timed
-    region."""
-    import json
+SAMPLING_NOTE = ("stratified: a triplet's negative is drawn uniformly from the item block of its positive (a fixed "
+                 "pseudo-random 1/G of the items, i % G) and batches are drawn per (user shard, item block) stratum; the "
+                 "reference draws negatives from ALL items (src/models/BaseModel.py:168) — waived in this mode, kept in "
+                 "mode 'alltoall'; the arithmetic of a step (batch-synchronous SGD on the global batch) is unchanged")
+
+
+def dedup_step_bytes(u, p, n, B, D, steps=8):
+    """algorithmic bytes of one local step, in-batch duplicates counted once (the N=1 definition):
+    2*D*4*(unique users + unique items) + 12*B, averaged over the first `steps` whole batches of (u, p, n)"""
+    nb = min(int(steps), u.numel() // B)
+    if nb <= 0:
+        return float((6 * D * 4 + 12) * B), float(B), float(2 * B)
+    uu = ui = 0
+    for k in range(nb):
+        sl = slice(k * B, (k + 1) * B)
+        uu += torch.unique(u[sl]).numel()
+        ui += torch.unique(torch.cat([p[sl], n[sl]])).numel()
+    uu, ui = uu / nb, ui / nb
+    return 2.0 * D * 4 * (uu + ui) + 12.0 * B, uu, ui
+
+
+def bench_run(args, rank, world, dev):
+    """bench.py --gpus N (N > 1), mode 'rotate': weak scaling, batch args.batch per GPU, stratified schedule.  The block
+    rotation happens as often as a full epoch of args.interactions interactions would require (every stratum_steps steps),
+    inside the timed region.  The process group exists already; returns the result dict on rank 0."""
     import time
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", device_id=dev)
     B, D, K, W = args.batch, args.emb, args.steps, args.warmup
     S = stratum_steps(args.interactions, world, B)
-    model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts)
+    from .hip_ops import PipelinedSgd
+    chunk = args.chunk if args.chunk > 0 else max(1, min(64, K // 2))
+    model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts, local=PipelinedSgd(chunk))
     model.init_xavier(3407)
     g = torch.Generator(device=dev)
     g.manual_seed(3407 * 7919 + rank)
@@ -277,7 +296,8 @@ def bench_main(args, rank, world, local_rank):
     timed, _ = make_schedule(K, held_after)
     torch.cuda.synchronize()
 
-    run_schedule(warm)
+    if W > 0:
+        run_schedule(warm)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -290,27 +310,26 @@ def bench_main(args, rank, world, local_rank):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     losses = model.global_losses(local_losses)
     dt = float(dt.item())
-    if rank == 0:
-        lv = losses.cpu().numpy()
-        assert np.all(np.isfinite(lv)), "non-finite loss"
-        value = world * K * B / dt
-        step_bytes = (6 * D * 4 + 12) * B          # per GPU, upper bound (no in-batch duplicates)
-        block_mb = model.cap * D * 4 / 1e6
-        out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K,
-               "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BPRMF emb_size=%d, synthetic %d users x %d items (uniform ids), batch %d per GPU "
-                                      "(global %d), SGD l2=0; user rows sharded over %d GPUs, item-row blocks rotating "
-                                      "round the ring every %d steps (stratified schedule of a %d-interaction epoch), plan "
-                                      "build and rotation inside the timed region" %
-                                      (D, args.users, args.items, B, B * world, world, S, args.interactions),
-                          "batch_per_gpu": B, "global_batch": B * world, "emb_size": D, "optimizer": "SGD", "l2": 0.0,
-                          "lr": args.lr, "parallelism": "stratified-rotation x%d" % world, "steps_per_stratum": S,
-                          "block_MB": block_mb, "parts": model.parts},
-               "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
-               "roofline": {"bound": "hbm", "achieved": step_bytes * K / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                            "frac": step_bytes * K / dt / 1e9 / 8000.0, "traffic": None,
-                            "kernel": "whole step per GPU incl. block rotation (per-kernel numbers: N=1 run)"}}
-        print(json.dumps(out))
-    dist.barrier()
-    dist.destroy_process_group()
+    if rank != 0:
+        return None
+    lv = losses.cpu().numpy()
+    assert np.all(np.isfinite(lv)), "non-finite loss"
+    value = world * K * B / dt
+    step_bytes, uu, ui = dedup_step_bytes(timed[0][0], timed[0][1], timed[0][2], B, D)   # per GPU, duplicates counted once
+    block_mb = model.cap * D * 4 / 1e6
+    work_mb = (model.U.shape[0] * D * 4 + model.cap * D * 4) / 1e6
+    return {"value": value, "ms_per_step": dt / K * 1e3, "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
+            "parallelism": "stratified-rotation x%d" % world, "sampling": SAMPLING_NOTE,
+            "steps_per_stratum": S, "block_MB": block_mb, "parts": model.parts, "plan_chunk_batches": chunk,
+            "exchange": "one item block (%.0f MB) per rank moves to its ring neighbour every %d steps "
+                        "(batch_isend_irecv, 1 xGMI link per rank), no per-step collective" % (block_mb, S),
+            "roofline": {"bound": "hbm", "achieved": step_bytes * K / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": step_bytes * K / dt / 1e9 / 8000.0, "traffic": None,
+                         "kernel": "whole step per GPU incl. plan build and block rotation (per-kernel numbers: N=1 run)",
+                         "algorithmic_bytes_per_step_per_gpu": step_bytes, "uniq_users_per_step": uu,
+                         "uniq_items_per_step": ui,
+                         "definition": "2*D*4*(unique users + unique items of the local batch) + 12*B, as at N=1",
+                         "working_set_MB_per_gpu": work_mb,
+                         "note": "a rank trains on its user shard and ONE item block: %.0f MB here — %s the 256 MB Infinity "
+                                 "Cache, so this fraction is %s comparable with the HBM-bound N=1 figure"
+                                 % (work_mb, "inside" if work_mb < 256 else "beyond", "NOT" if work_mb < 256 else "")}}

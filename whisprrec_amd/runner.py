@@ -17,6 +17,8 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
+from . import abi
+
 
 def format_metric(result_dict):
     """'NDCG@10:0.1085,HR@10:0.2254'-style line (reference src/utils/utils.py:58-71, without its NumPy-2 breakage)."""
@@ -303,7 +305,8 @@ def make_hip_runner(base_runner_cls):
             from wr_rank_eval (MFMA score tiles + on-the-fly masking + counting), no [n_eval, n_items] matrix, no Python
             loop over rows (reference BaseRunner.py:218-258).  Otherwise the inherited host path."""
             model = dataset.model
-            if not hasattr(model, "eval_factors") or model.eval_factors()[0].shape[1] > 256:
+            from . import hip_ops
+            if not hasattr(model, "eval_factors") or not hip_ops.rank_eval_supports(model.eval_factors()[0].shape[1]):
                 return base_runner_cls.evaluate(self, dataset, topks, metrics)
             from . import hip_ops
             consume_loader_seed()                       # the evaluation DataLoader this replaces would draw its base seed
@@ -338,15 +341,18 @@ def make_hip_runner(base_runner_cls):
             cached = getattr(self, "_graph_cache", None)
             if cached is not None and cached[0] == key:
                 return cached[1], cached[2], cached[3], 0
+            # the three eager batches are ordinary training steps of this epoch: outside the try, so that a failed capture
+            # neither hides their errors nor lets the eager loop train them a second time
+            dev = cols[0].device
+            model.optimizer.prepare()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for i in range(3):
+                    eager_step(i * B)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            t_before = getattr(model.optimizer, "t", None)
             try:
-                dev = cols[0].device
-                model.optimizer.prepare()
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    for i in range(3):
-                        eager_step(i * B)
-                torch.cuda.current_stream(dev).wait_stream(side)
                 static = [torch.empty(B, dtype=c.dtype, device=dev) for c in cols]
                 batch = {"user_id": static[0], "pos_item": static[1], "neg_items": static[2].unsqueeze(1), "batch_size": B,
                          "phase": "train"}
@@ -356,15 +362,19 @@ def make_hip_runner(base_runner_cls):
                     static_loss = model.predict(batch)
                     static_loss.backward()
                     model.optimizer.step()
-                if hasattr(model.optimizer, "sync_step_count"):
-                    model.optimizer.t -= 1               # the captured step() call itself trained nothing
-                self._graph_cache = (key, g, static, static_loss)
-                return g, static, static_loss, 3 * B
-            except Exception as e:  # noqa: BLE001 - capture is an optimisation: fall back to the eager loop
+            except (RuntimeError, abi.WhisprRecHipError) as e:
+                # capture is an optimisation: the epoch goes on eagerly FROM THE FIRST UNTRAINED ROW.  A capture that died
+                # after the captured optimizer.step() call has bumped the host-side step count without training anything.
                 logging.warning("hipGraph capture of the training step failed (%r); continuing without graphs", e)
                 self.hip_graphs = 0
                 torch.cuda.synchronize()
-                return None
+                if t_before is not None:
+                    model.optimizer.t = t_before
+                return None, None, None, 3 * B
+            if hasattr(model.optimizer, "sync_step_count"):
+                model.optimizer.t -= 1               # the captured step() call itself trained nothing
+            self._graph_cache = (key, g, static, static_loss)
+            return g, static, static_loss, 3 * B
 
         def _epoch_columns(self, dataset, dev, epoch):
             """the epoch's (user, positive, negative) columns in batch order on the device"""
@@ -375,8 +385,11 @@ def make_hip_runner(base_runner_cls):
             dataset.actions_before_epoch()              # must happen before the shuffle draws, as in the reference
             order = epoch_order(len(dataset), self.batch_size)
             self._last_order = order
-            return [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64).reshape(len(dataset), -1)[:, 0][order]
-                    .to(dev) for k in ("user_id", "item_id", "neg_items")]
+            # --num_neg > 1: the reference flattens neg_items (BaseModel.py:176-177) and _get_feed_dict reads flat[i] (:157), so
+            # row i trains on flat[i], not on its own first draw; one value per row either way
+            n_rows = len(dataset)
+            return [torch.from_numpy(np.ascontiguousarray(dataset.data[k])).to(torch.int64).reshape(-1)[:n_rows][order].to(dev)
+                    for k in ("user_id", "item_id", "neg_items")]
 
         def _history_columns(self, dataset, dev):
             """[n, history_max] item histories (left-aligned, zero-padded like collate_batch's pad_sequence) and their lengths
@@ -446,22 +459,24 @@ def make_hip_runner(base_runner_cls):
                 model.optimizer.step()
                 losses.append(loss.detach().reshape(-1)[0])
 
-            lo = 0
-            graph = self._step_graph(model, cols, B, n, eager_step) if self.hip_graphs else None
-            if graph is not None:
-                g, static, static_loss, lo = graph
-                while lo + B <= n:                          # full batches: copy the indices in, replay the captured step
-                    for dst, src in zip(static, cols):
-                        dst.copy_(src[lo:lo + B])
-                    g.replay()
-                    losses.append(static_loss.detach().reshape(-1)[0].clone())
+            try:
+                lo = 0
+                graph = self._step_graph(model, cols, B, n, eager_step) if self.hip_graphs else None
+                if graph is not None:
+                    g, static, static_loss, lo = graph  # lo: first row not trained yet (a failed capture: g is None)
+                    while g is not None and lo + B <= n:    # full batches: copy the indices in, replay the captured step
+                        for dst, src in zip(static, cols):
+                            dst.copy_(src[lo:lo + B])
+                        g.replay()
+                        losses.append(static_loss.detach().reshape(-1)[0].clone())
+                        lo += B
+                    if g is not None and hasattr(model.optimizer, "sync_step_count"):
+                        model.optimizer.sync_step_count()
+                while lo < n:                               # no graph, or the short last batch
+                    eager_step(lo)
                     lo += B
-                if hasattr(model.optimizer, "sync_step_count"):
-                    model.optimizer.sync_step_count()
-            while lo < n:                                   # no graph, or the short last batch
-                eager_step(lo)
-                lo += B
-            model._trusted_indices = False
+            finally:
+                model._trusted_indices = False
             return float(torch.stack(losses).mean().cpu())
 
     HipRunner.__qualname__ = "HipRunner"

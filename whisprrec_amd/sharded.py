@@ -243,14 +243,13 @@ class ShardedBprmf:
 
 
 # ---------------------------------------------------------------------------------------------------- bench (N > 1)
-def bench_main(args, rank, world, local_rank):
-    """bench.py --gpus N (N > 1), launched by torch.distributed.run with one rank per GPU.  Weak scaling: every rank runs
-    batches of args.batch triplets whose users it owns; tables are row-sharded over the N GPUs."""
-    import json
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", device_id=dev)
+def bench_run(args, rank, world, dev):
+    """bench.py --gpus N (N > 1), mode 'alltoall': weak scaling, every rank runs batches of args.batch triplets whose users
+    it owns; tables are row-sharded over the N GPUs; negatives uniform over ALL items as in the reference
+    (src/models/BaseModel.py:168).  The process group exists already; returns the result dict on rank 0."""
+    from .rotating import dedup_step_bytes
     B, D, K, W = args.batch, args.emb, args.steps, args.warmup
+    chunk = args.chunk if args.chunk > 0 else max(1, min(64, K // 2))
     model = ShardedBprmf(args.users, args.items, D, dev)
     model.init_xavier(3407)
     g = torch.Generator(device=dev)
@@ -263,14 +262,15 @@ def bench_main(args, rank, world, local_rank):
     def run_range(first, count):
         out, done = [], 0
         while done < count:
-            c = min(args.chunk, count - done)
+            c = min(chunk, count - done)
             lo = (first + done) * B
             cp = model.plan_chunk(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B)
             out.append(model.run_chunk(cp, args.lr, global_batch=B * world))
             done += c
         return out
 
-    run_range(0, W)
+    if W > 0:
+        run_range(0, W)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -283,24 +283,23 @@ def bench_main(args, rank, world, local_rank):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     losses = model.global_losses(torch.cat(res))
     dt = float(dt.item())
-    if rank == 0:
-        lv = losses.cpu().numpy()
-        assert np.all(np.isfinite(lv)), "non-finite loss"
-        value = world * K * B / dt
-        step_bytes = (6 * D * 4 + 12) * B * world          # upper bound (no in-batch duplicates), all GPUs
-        out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K,
-               "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BPRMF emb_size=%d, synthetic %d users x %d items (uniform ids), batch %d per GPU "
-                                      "(global %d), SGD l2=0, tables row-sharded over %d GPUs, RCCL all-to-all of item "
-                                      "rows and gradient rows, plan build in timed region" %
-                                      (D, args.users, args.items, B, B * world, world),
-                          "batch_per_gpu": B, "global_batch": B * world, "emb_size": D, "optimizer": "SGD", "l2": 0.0,
-                          "lr": args.lr, "plan_chunk_batches": args.chunk, "tables": "row-sharded, cyclic"},
-               "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
-               "roofline": {"bound": "hbm", "achieved": step_bytes * K / dt / 1e9 / world, "peak": 8000.0, "unit": "GB/s",
-                            "frac": step_bytes * K / dt / 1e9 / world / 8000.0, "traffic": None,
-                            "kernel": "whole sharded step per GPU (exchange-bound; see DESIGN.md §6)"}}
-        print(json.dumps(out))
-    dist.barrier()
-    dist.destroy_process_group()
+    if rank != 0:
+        return None
+    lv = losses.cpu().numpy()
+    assert np.all(np.isfinite(lv)), "non-finite loss"
+    value = world * K * B / dt
+    lo = W * B
+    step_bytes, uu, ui = dedup_step_bytes(u[lo:], p[lo:], n[lo:], B, D)      # per GPU, duplicates counted once
+    link_mb = 2 * ui * (world - 1) / world * D * 4 / 1e6
+    return {"value": value, "ms_per_step": dt / K * 1e3, "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
+            "parallelism": "row-sharded tables x%d, RCCL all-to-all of item rows + gradient rows" % world,
+            "sampling": "reference rule: negatives uniform over all items (src/models/BaseModel.py:168)",
+            "plan_chunk_batches": chunk,
+            "exchange": "per step and rank: ~%.1f MB of item rows in and as many gradient-row bytes out over xGMI "
+                        "(2 x all_to_all_single), index exchange once per chunk" % link_mb,
+            "roofline": {"bound": "hbm", "achieved": step_bytes * K / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": step_bytes * K / dt / 1e9 / 8000.0, "traffic": None,
+                         "kernel": "whole sharded step per GPU (exchange-bound for N > 1; see DESIGN.md 6)",
+                         "algorithmic_bytes_per_step_per_gpu": step_bytes, "uniq_users_per_step": uu,
+                         "uniq_items_per_step": ui,
+                         "definition": "2*D*4*(unique users + unique items of the local batch) + 12*B, as at N=1"}}
