@@ -45,7 +45,7 @@ def parse(argv=None):
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--emb", type=int, default=64)
     ap.add_argument("--lr", type=float, default=0.05)
-    ap.add_argument("--chunk", type=int, default=0, help="batches per plan build (0: min(64, steps/2))")
+    ap.add_argument("--chunk", type=int, default=0, help="batches per plan build (0: min(64, steps))")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent over items (0 = uniform, headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-events", action="store_true")
@@ -64,11 +64,11 @@ def parse(argv=None):
 
 
 def plan_chunk(args):
-    """batches per plan: 64 in steady state; a short run (the driver's --steps 20) keeps two plans inside the timed region
-    so that the pipeline — next plan built beside the current plan's steps — is what gets measured"""
+    """batches per plan: 64, the training default; a run shorter than that (the driver's --steps 20) is one plan long — its
+    plan is built during the warm-up, and the plan of the chunk that would follow is built beside its steps"""
     if args.chunk > 0:
         return args.chunk
-    return max(1, min(64, args.steps // 2))
+    return max(1, min(64, args.steps))
 
 
 # --------------------------------------------------------------------------------------------------- N>1 launcher
@@ -221,7 +221,8 @@ def single_gpu(args, local_rank):
     losses_w = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
     losses = torch.empty(K, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    handle = pipe.plan(U, [(I, u, p, n)], B, first_chunk=W if W > 0 else None)
+    # the warm-up is two plans long when it can be, so that every host path of the pipeline has run twice before the clock starts
+    handle = pipe.plan(U, [(I, u, p, n)], B, first_chunk=[W - W // 2, W // 2] if W > 0 else None)
     if W > 0:
         pipe.run_steps(handle, W, args.lr, losses_w)
     torch.cuda.synchronize()

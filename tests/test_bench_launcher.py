@@ -65,7 +65,7 @@ def test_multi_gpu_line_carries_both_modes_and_the_single_gpu_definitions():
     json.dumps(line)
 
 
-def test_plan_chunk_keeps_two_plans_in_a_short_timed_region():
-    assert bench.plan_chunk(bench.parse(["--steps", "20", "--warmup", "5"])) == 10
+def test_plan_chunk_of_a_short_run_is_the_run():
+    assert bench.plan_chunk(bench.parse(["--steps", "20", "--warmup", "5"])) == 20
     assert bench.plan_chunk(bench.parse([])) == 64
     assert bench.plan_chunk(bench.parse(["--steps", "20", "--chunk", "7"])) == 7

@@ -202,14 +202,21 @@ __device__ __forceinline__ void finish_user_row(float *__restrict__ U, float *__
 
 // Each team works on SLOTS positions (t, t + seg, ...): the index loads of all slots are issued together, then the row
 // loads of all slots, then the slots are finished one after the other.  (Launched with SLOTS = 1; see launch_step.)
-template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT>
+// DEF selects which run heads a launch works on (overlapped step stream, wr_bprmf_run_sgd_overlap):
+//   0  every head (the ordinary step);
+//   1  every head whose bit in `dmask` is clear — the runs that read no item row the PREVIOUS batch's item phase is still
+//      rewriting, so this launch may run beside that item phase;
+//   2  the heads listed in `dlist` (the deferred runs: positions in ascending order), one team each.
+template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT, int DEF = 0>
 __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? 8 : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
                                                             const int *__restrict__ tn, int B, float lr, float l2,
                                                             float *__restrict__ Z, float *__restrict__ partials,
                                                             float *__restrict__ gradU, int *__restrict__ stampU,
                                                             float *__restrict__ gradI, int *__restrict__ stampI,
-                                                            int step_id, float denom, AdamArgs ad) {
+                                                            int step_id, float denom, AdamArgs ad,
+                                                            const int *__restrict__ dmask,
+                                                            const int *__restrict__ dlist, int n_list) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
@@ -227,10 +234,24 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
         t0[s] = team + s * seg;
         head[s] = false;
         uu[s] = unext[s] = praw0[s] = nraw0[s] = 0;
-        if (team < seg && t0[s] < B) {
+        if constexpr (DEF == 2) {
+            // a listed head: its position comes from the list, everything else as below (one more dependent load, on a
+            // launch of a few dozen workgroups)
+            if (team < n_list) {
+                const int t = dlist[team];
+                t0[s] = t;
+                const int u = tu[t], un = tu[min(t + 1, B - 1)];
+                praw0[s] = tp[t];
+                nraw0[s] = tn[t];
+                uu[s] = u;
+                unext[s] = (t + 1 < B) ? un : ~u;
+                head[s] = true;
+            }
+        } else if (team < seg && t0[s] < B) {
             const int t = t0[s];
             const int u = tu[t], uprev = tu[max(t - 1, 0)], un = tu[min(t + 1, B - 1)];
             const int uhot = SKIP_HOT ? tu[min(t + kHotRun, B - 1)] : 0;
+            const int dm = DEF == 1 ? dmask[t >> 5] : 0;
             praw0[s] = tp[t];
             nraw0[s] = tn[t];
             uu[s] = u;
@@ -238,6 +259,7 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
             head[s] = (t == 0) || (uprev != u);   // first position of a run of equal users
             // users with more than kHotRun triplets in the batch are cut into pieces by the plan (bprmf_user_hot_*)
             if (SKIP_HOT && t + kHotRun < B && uhot == u) head[s] = false;
+            if (DEF == 1 && ((dm >> (t & 31)) & 1)) head[s] = false;   // a deferred run: the list launch does it
         }
     }
     Row<NV> ur[SLOTS], pr0[SLOTS], nr0[SLOTS];
@@ -722,10 +744,12 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     do {                                                                                                                  \
         if (have_hot_u)                                                                                                   \
             WR_LAUNCH((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, true>), gridA, 0, ev(0), none, U, I, D, tu, tp,         \
-                      tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad);            \
+                      tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad,             \
+                      (const int *)nullptr, (const int *)nullptr, 0);                                                     \
         else                                                                                                              \
             WR_LAUNCH((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, false>), gridA, 0, ev(0), ev(1), U, I, D, tu,             \
-                      tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad);        \
+                      tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad,         \
+                      (const int *)nullptr, (const int *)nullptr, 0);                                                     \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
@@ -777,6 +801,77 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
         WR_LAUNCH_CHECK("bprmf_item_hot_*");
     }
 #undef WR_LAUNCH
+    return WR_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- overlapped step stream
+// The item phase of step k is ~5 us of latency on ~8 K rows (two dependent round trips), serialised behind the user phase
+// by the kernel boundary.  Here it runs on a second stream BESIDE the user phase of step k+1: the plan marks the user runs
+// of batch k+1 that read an item row the item phase of step k rewrites (rows with several occurrences in batch k: ~1.6 % of
+// the triplets at the headline shape) — those "deferred" runs wait for that item phase (DEF = 2 launch on the second
+// stream), every other run of batch k+1 touches none of its rows (DEF = 1 launch).  Per step:
+//     main stream :  [wait D(k-1)]  user phase of the undeferred runs of batch k                          -> event A(k)
+//     side stream :  user phase of the deferred runs of batch k  -> event D(k);  [wait A(k)]  item phase of batch k
+// D(k-1) lies behind the item phase of step k-2 and the deferred runs of step k-1 on the side stream, so the main launch of
+// step k starts once everything it may read is final; the stash / loss partials are double-buffered by step parity (the
+// item phase of step k reads buffer k % 2 while the user phase of step k+1 fills the other).  Every table row still has
+// exactly one writer per step and the same summation order: the tables come out bit-identical to the ordinary step's.
+template <int T, int NV, bool FULL>
+static int32_t launch_overlap_steps(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
+                                    const int32_t *oc_item, const int32_t *oc_src, int64_t n_triplets, int64_t batch_size,
+                                    int64_t first_batch, int64_t n_batches, float lr, float *loss_out, const int32_t *tdef,
+                                    const int32_t *def_q, const int32_t *def_count_host, int64_t def_cap, void *workspace,
+                                    hipStream_t sa, hipStream_t sb, hipEvent_t *ev, int n_ev) {
+    const int64_t ws_one = step_ws_bytes(batch_size, D);
+    const StepWs w2[2] = {carve_step_ws(workspace, batch_size, D),
+                          carve_step_ws(reinterpret_cast<char *>(workspace) + ws_one, batch_size, D)};
+    const int64_t dwords = (batch_size + 31) / 32;
+    const dim3 block(kBlock);
+    const AdamArgs ad{};
+    // events: ev[0] = entry / exit join, then R slots of (A, D)
+    const int R = (n_ev - 1) / 2;
+    hipEvent_t ev_join = ev[0];
+    WR_HIP(hipEventRecord(ev_join, sa));            // the side stream starts behind everything queued on the main stream
+    WR_HIP(hipStreamWaitEvent(sb, ev_join, 0));
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t b = first_batch + k;
+        const int64_t off = b * batch_size;
+        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
+        const StepWs &w = w2[k & 1];
+        hipEvent_t evA = ev[1 + 2 * (k % R)], evD = ev[2 + 2 * (k % R)];
+        const int n_def = (k == 0) ? 0 : def_count_host[b];     // the first batch of a call follows a join: nothing to defer
+        const dim3 gridA((unsigned)n_blocks_for(Bk, D));
+        const dim3 gridD((unsigned)n_blocks_for(n_def, D));
+        const dim3 gridB((unsigned)((2 * Bk + kItemTile - 1) / kItemTile));
+        if (k > 0) WR_HIP(hipStreamWaitEvent(sa, ev[2 + 2 * ((k - 1) % R)], 0));   // D(k-1)
+        if (n_def > 0)
+            hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 1>), gridA, block, 0, sa, U, I, D, tu + off, tp + off,
+                               tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr, (float *)nullptr,
+                               (int *)nullptr, 0, (float)Bk, ad, tdef + b * dwords, (const int *)nullptr, 0);
+        else
+            hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 0>), gridA, block, 0, sa, U, I, D, tu + off, tp + off,
+                               tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr, (float *)nullptr,
+                               (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, (const int *)nullptr, 0);
+        WR_LAUNCH_CHECK("bprmf_user_phase (overlap, main)");
+        WR_HIP(hipEventRecord(evA, sa));
+        if (n_def > 0) {
+            hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 2>), gridD, block, 0, sb, U, I, D, tu + off, tp + off,
+                               tn + off, (int)Bk, lr, 0.f, w.Z, w.partials + gridA.x, (float *)nullptr, (int *)nullptr,
+                               (float *)nullptr, (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, def_q + b * def_cap,
+                               n_def);
+            WR_LAUNCH_CHECK("bprmf_user_phase (overlap, deferred)");
+        }
+        WR_HIP(hipEventRecord(evD, sb));
+        WR_HIP(hipStreamWaitEvent(sb, evA, 0));
+        hipLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, 0, false>), gridB, block, 0, sb, I, D, oc_item + 2 * off,
+                           oc_src + 2 * off, (int)(2 * Bk), w.Z, lr, 0.f, (float *)nullptr, (int *)nullptr, 0, w.partials,
+                           (int)(gridA.x + (n_def > 0 ? gridD.x : 0u)), (float)Bk, loss_out ? loss_out + k : nullptr, 0,
+                           (const unsigned long long *)nullptr, (int)gridB.x, (const int *)nullptr, (const int *)nullptr,
+                           (float *)nullptr, ad);
+        WR_LAUNCH_CHECK("bprmf_item_phase (overlap)");
+    }
+    WR_HIP(hipEventRecord(ev_join, sb));            // the caller's stream continues behind the last item phase
+    WR_HIP(hipStreamWaitEvent(sa, ev_join, 0));
     return WR_OK;
 }
 
@@ -935,6 +1030,43 @@ int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float 
     return launch_step<2>(user_shard, const_cast<float *>(item_rows), D, tu, tp, tn, oc_item, oc_src, B, lr, 0.f, nullptr,
                           grad_slots, nullptr, nullptr, 0, loss_partial, workspace, reinterpret_cast<hipStream_t>(stream_),
                           nullptr, (float)global_batch, hot_of(hot, 0));
+}
+
+int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                                 const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                                 const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                                 int64_t n_batches, float lr, float *loss_out, const int32_t *tdef, const int32_t *def_q,
+                                 const int32_t *def_count_host, int64_t def_cap, void *workspace, int64_t workspace_bytes,
+                                 void *stream_main, void *stream_side, void *const *events, int32_t n_events) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, batch_size)) != WR_OK) return rc;
+    WR_REQUIRE(tdef && def_q && def_count_host && events, WR_E_NULL, "overlap marks / events must not be NULL");
+    WR_REQUIRE(n_triplets > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(n_events >= 5, WR_E_RANGE, "wr_bprmf_run_sgd_overlap needs at least 5 events (got %d)", (int)n_events);
+    WR_REQUIRE(stream_main != stream_side, WR_E_RANGE, "the two streams must differ");
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 2 * step_ws_bytes(batch_size, D), WR_E_WORKSPACE,
+               "wr_bprmf_run_sgd_overlap: workspace %lld B < %lld B", (long long)workspace_bytes,
+               (long long)(2 * step_ws_bytes(batch_size, D)));
+    for (int64_t k = 1; k < n_batches; ++k) {       // the lists the launches are sized from must fit what the plan reserved
+        const int32_t c = def_count_host[first_batch + k];
+        WR_REQUIRE(c >= 0 && c <= def_cap, WR_E_RANGE, "batch %lld: %d deferred runs exceed the list capacity %lld",
+                   (long long)(first_batch + k), (int)c, (long long)def_cap);
+    }
+    for (int32_t j = 0; j < n_events; ++j) WR_REQUIRE(events[j] != nullptr, WR_E_NULL, "event %d is NULL", (int)j);
+    hipEvent_t *ev = reinterpret_cast<hipEvent_t *>(const_cast<void **>(events));
+    hipStream_t sa = reinterpret_cast<hipStream_t>(stream_main), sb = reinterpret_cast<hipStream_t>(stream_side);
+#define WR_CALL_OVL(T_, NV_, FULL_)                                                                                        \
+    return launch_overlap_steps<T_, NV_, FULL_>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, n_triplets, batch_size, \
+                                                first_batch, n_batches, lr, loss_out, tdef, def_q, def_count_host, def_cap, \
+                                                workspace, sa, sb, ev, (int)n_events)
+    WR_DISPATCH_D(D, WR_CALL_OVL);
+#undef WR_CALL_OVL
+    return WR_OK;
 }
 
 }  // extern "C"

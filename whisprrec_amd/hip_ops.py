@@ -261,12 +261,14 @@ class BatchPlan:
         return BatchPlan.META_HEAD + 5 * int(n_batches)
 
     def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="auto",
-                 hot=True, bucket_map=None, arena=None, defer=False):
+                 hot=True, bucket_map=None, arena=None, defer=False, overlap=False):
         """builder: "auto" (default) = hand-written bucket/LDS-sort builder when applicable, generic radix-sort builder
         otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one.
         bucket_map: a BucketMap of the epoch these batches come from — load-balanced buckets for the hand-written builder
         (skewed ids); ``fast_overflowed`` tells afterwards whether the hand-written builder was tried and gave up.
-        arena: a PlanArena to build into (no allocation); defer: do not wait for the read-back (see finish())."""
+        arena: a PlanArena to build into (no allocation); defer: do not wait for the read-back (see finish());
+        overlap: also compute the marks of the overlapped step stream (wr_bprmf_plan_overlap_marks; needs an arena created
+        with overlap_items) — ``self.overlap`` is then set by finish() when the plan qualifies (no hot rows, lists fit)."""
         if u.dtype not in (torch.int64, torch.int32):
             raise TypeError("indices must be int64 or int32")
         dt = u.dtype
@@ -282,6 +284,9 @@ class BatchPlan:
         self.n_batches = (N + self.batch_size - 1) // self.batch_size
         self._src = (u, p, n)
         self._ws_tag, self._want_hot, self._bucket_map = ws_tag, bool(hot), bucket_map
+        self._want_overlap = bool(overlap)
+        if overlap and (arena is None or arena.overlap is None or not hot):
+            raise ValueError("overlap marks need an arena with overlap_items and the hot-run scan")
         self._stream = torch.cuda.current_stream(dev)
         self.arena = arena
         i32 = dict(dtype=torch.int32, device=dev)
@@ -371,6 +376,8 @@ class BatchPlan:
         # the hot-run scan is bounds-safe for any key values; after an overflow its output is thrown away with the plan
         if self._want_hot:
             self._enqueue_hot_runs()
+        if self._want_overlap:
+            self._enqueue_overlap_marks()
         return True
 
     def _build_generic(self):
@@ -390,6 +397,8 @@ class BatchPlan:
             if self._sides is None:
                 self._sides = self._hot_arrays(dev)
             self._enqueue_hot_runs()
+        if self._want_overlap:
+            self._enqueue_overlap_marks()
 
     def _hot_arrays(self, dev):
         """list arrays of the hot-run scan: views of the arena, or fresh tensors"""
@@ -418,6 +427,16 @@ class BatchPlan:
         for (kind, keys), (arrs, _, _) in zip(((0, self.oc_item), (1, self.tu)), self._sides):
             abi.check(L.wr_bprmf_plan_hot_runs(_p(keys), kind, self.n_triplets, self.batch_size, *[_p(a) for a in arrs],
                                                _p(counts), _stream()), "wr_bprmf_plan_hot_runs")
+
+    def _enqueue_overlap_marks(self):
+        """marks of the overlapped step stream: which user runs of batch k+1 read an item row that step k's item phase
+        rewrites (index work only).  The first batch of a plan defers nothing: the stream joins at plan boundaries."""
+        o, nb = self.arena.overlap, self.n_batches
+        counts = self.meta[self.META_HEAD + 4 * nb:self.META_HEAD + 5 * nb]
+        abi.check(abi.lib().wr_bprmf_plan_overlap_marks(_p(self.tu), _p(self.tp), _p(self.tn), self.n_triplets,
+                                                        self.batch_size, self.n_items, None, _p(o["bitmap"]), _p(o["tdef"]),
+                                                        _p(o["def_q"]), o["cap"], _p(counts), _stream()),
+                  "wr_bprmf_plan_overlap_marks")
 
     def _queue_readback(self):
         """ONE small read-back per plan: flags + hot-run counts (+ deferred-run counts).  With an arena it is an asynchronous
@@ -464,6 +483,11 @@ class BatchPlan:
             counts_host = mh[self.META_HEAD:self.META_HEAD + 4 * self.n_batches]
             if int(counts_host.sum().item()) > 0:
                 self.hot = {"sides": self._sides, "counts_host": counts_host}
+        if self._want_overlap and self.hot is None:
+            o, nb = self.arena.overlap, self.n_batches
+            dc = mh[self.META_HEAD + 4 * nb:self.META_HEAD + 5 * nb]
+            if nb >= 2 and int(dc.min()) >= 0 and int(dc.max()) <= o["cap"]:
+                self.overlap = {"tdef": o["tdef"], "def_q": o["def_q"], "def_count_host": dc, "cap": o["cap"]}
         self._finished = True
         return self
 
@@ -504,6 +528,19 @@ class BatchPlan:
                 ts += arrs
         for t in ts:
             t.record_stream(stream)
+
+
+class OverlapEvents:
+    """the ring of hipEvent_t handles wr_bprmf_run_sgd_overlap orders its two streams with (caller-owned, like every other
+    resource of the C-ABI)"""
+
+    def __init__(self, device, n=9):
+        self.events = [torch.cuda.Event() for _ in range(n)]
+        with torch.cuda.device(device):
+            for e in self.events:
+                e.record()                       # torch creates the hipEvent_t lazily on first record
+        self.array = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.events])
+        self.n = n
 
 
 class BprmfTables:
@@ -589,6 +626,25 @@ class BprmfTables:
                                      ctypes.addressof(ev) if ev is not None else None,
                                      ctypes.addressof(hot) if hot is not None else None, _p(ws), ws.numel(), _stream()),
                   "wr_bprmf_run_sgd")
+        self.step_id += count
+        return losses
+
+    def run_sgd_overlap(self, plan, first, count, lr, losses, side, events):
+        """`count` consecutive steps like run_sgd, as the overlapped stream (wr_bprmf_run_sgd_overlap): item phase of step k
+        on stream `side` beside the user phase of step k+1 on the current stream.  plan.overlap must be set (BatchPlan
+        built with overlap=True that qualified).  events: OverlapEvents.  Same tables, bit for bit, as run_sgd."""
+        L = abi.lib()
+        o = plan.overlap
+        nbytes = 2 * abi.check_size(L.wr_bprmf_step_workspace_bytes(plan.batch_size, self.D), "wr_bprmf_step_workspace_bytes")
+        ws = workspace(self.dev, "step_overlap").get(nbytes)
+        if losses is None:
+            losses = torch.empty(count, dtype=torch.float32, device=self.dev)
+        abi.check(L.wr_bprmf_run_sgd_overlap(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(plan.tu),
+                                             _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets,
+                                             plan.batch_size, first, count, lr, _p(losses), _p(o["tdef"]), _p(o["def_q"]),
+                                             o["def_count_host"].data_ptr(), o["cap"], _p(ws), ws.numel(), _stream(),
+                                             side.cuda_stream, ctypes.addressof(events.array), events.n),
+                  "wr_bprmf_run_sgd_overlap")
         self.step_id += count
         return losses
 
@@ -748,11 +804,17 @@ class PipelinedSgd:
     when the plan's first step is queued — by then the build has long run, one chunk ahead (BatchPlan.finish)."""
 
     PLAN_TRIPLETS = 1 << 22
+    OVERLAP_MIN_BATCH = 8192      # below this a step is launch-bound and a third launch per step costs more than it hides
 
-    def __init__(self, chunk=64, min_triplets=None):
+    def __init__(self, chunk=64, min_triplets=None, overlap=True):
+        """overlap: run plans that qualify (no hot rows; B >= OVERLAP_MIN_BATCH) as the overlapped stream — item phase of
+        step k beside the user phase of step k+1 (wr_bprmf_run_sgd_overlap); same tables bit for bit"""
         import sys
         self.ops = sys.modules[__name__]
         self.chunk = int(chunk)
+        self.overlap = bool(overlap)
+        self.item_stream = None
+        self._ovl_events = None
         if min_triplets is not None:
             self.PLAN_TRIPLETS = int(min_triplets)
         self.plan_stream = None
@@ -761,22 +823,22 @@ class PipelinedSgd:
     def chunk_batches(self, batch_size):
         return max(self.chunk, self.PLAN_TRIPLETS // max(int(batch_size), 1))
 
-    def _arena_pair(self, device, B, nb_total):
+    def _arena_pair(self, device, B, nb_total, overlap_items):
         """two arenas for plans of up to chunk_batches(B) batches of B triplets (never more than the work at hand), kept
         across epochs"""
         cap = min(self.chunk_batches(B), max(int(nb_total), 1)) * B
-        key = (str(device), B)
+        key = (str(device), B, int(overlap_items))
         pair = self._arenas.get(key)
         if pair is None or pair[0].max_triplets < cap:
-            pair = [self.ops.PlanArena(device, cap, B), self.ops.PlanArena(device, cap, B)]
+            pair = [self.ops.PlanArena(device, cap, B, overlap_items=overlap_items) for _ in range(2)]
             self._arenas[key] = pair
         return pair
 
     def plan(self, U, segments, batch, first_chunk=None):
         """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order.
-        Only the last segment may end with a short batch.  first_chunk: batches in the first plan (default: a full chunk)
-        — lets a caller that consumes the stream piecewise (bench.py: warm-up, then timed steps) put a plan boundary where
-        its pieces meet."""
+        Only the last segment may end with a short batch.  first_chunk: batches in the first plan, or a list with the sizes
+        of the first few plans (default: full chunks) — lets a caller that consumes the stream piecewise (bench.py: warm-up,
+        then timed steps) put a plan boundary where its pieces meet."""
         if self.plan_stream is None:
             self.plan_stream = side_stream(U.device)
         B = int(batch)
@@ -794,12 +856,17 @@ class PipelinedSgd:
         u_all, p_all, n_all = (_join_views([s[j] for s in live]) for j in (1, 2, 3))
         n_items = max([s[0].shape[0] for s in live] or [1])
         main = torch.cuda.current_stream(U.device)
-        arenas = self._arena_pair(U.device, B, first)
+        use_overlap = self.overlap and B >= self.OVERLAP_MIN_BATCH and first >= 2
+        if use_overlap and self.item_stream is None:
+            self.item_stream = side_stream(U.device)
+            self._ovl_events = self.ops.OverlapEvents(U.device)
+        arenas = self._arena_pair(U.device, B, first, n_items if use_overlap else 0)
         for a in arenas:                     # a previous handle may have left steps queued that read these arrays
             a.release_after(main)
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
-             "first_chunk": int(first_chunk) if first_chunk else 0}
+             "overlap": use_overlap,
+             "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
         self.plan_stream.wait_stream(main)   # the index tensors are ready
         self._prefetch(h)
         return h
@@ -811,15 +878,15 @@ class PipelinedSgd:
             return
         first, B = h["at"], h["B"]
         c = min(self.chunk_batches(B), h["nb"] - first)
-        if first == 0 and h["first_chunk"] > 0:
-            c = min(c, h["first_chunk"])
+        if h["lead"]:
+            c = min(c, h["lead"].pop(0))
         h["at"] += c
         lo, hi = first * B, min(h["u"].numel(), (first + c) * B)
         with torch.cuda.stream(self.plan_stream):
             bmap = h["map"] if h["map"] else None
             plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
                                       validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap, arena=h["arenas"][h["tag"]],
-                                      defer=True)
+                                      defer=True, overlap=h["overlap"])
         h["tag"] ^= 1
         h["next"] = (first, plan)
 
@@ -853,7 +920,11 @@ class PipelinedSgd:
                 cur = self._take_next(h, pos, main)
             base, plan = cur
             c = min(min(end, base + plan.n_batches) - pos, 256)      # at most 256 steps per native call
-            sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
+            if plan.overlap is not None and c >= 2:
+                sg["tabs"].run_sgd_overlap(plan, pos - base, c, lr, losses[loss_off:loss_off + c], self.item_stream,
+                                           self._ovl_events)
+            else:
+                sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
             pos += c
             loss_off += c
             if pos >= base + plan.n_batches:

@@ -252,7 +252,7 @@ def bench_run(args, rank, world, dev):
     B, D, K, W = args.batch, args.emb, args.steps, args.warmup
     S = stratum_steps(args.interactions, world, B)
     from .hip_ops import PipelinedSgd
-    chunk = args.chunk if args.chunk > 0 else max(1, min(64, K // 2))
+    chunk = args.chunk if args.chunk > 0 else max(1, min(64, K))
     model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts, local=PipelinedSgd(chunk))
     model.init_xavier(3407)
     g = torch.Generator(device=dev)

@@ -249,7 +249,7 @@ def bench_run(args, rank, world, dev):
     (src/models/BaseModel.py:168).  The process group exists already; returns the result dict on rank 0."""
     from .rotating import dedup_step_bytes
     B, D, K, W = args.batch, args.emb, args.steps, args.warmup
-    chunk = args.chunk if args.chunk > 0 else max(1, min(64, K // 2))
+    chunk = args.chunk if args.chunk > 0 else max(1, min(64, K))
     model = ShardedBprmf(args.users, args.items, D, dev)
     model.init_xavier(3407)
     g = torch.Generator(device=dev)
