@@ -216,6 +216,10 @@ int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int6
  *   def_count_host (HOST memory, one int32 per batch of the plan) : their number — every value for batches
  *         (first_batch, first_batch + n_batches) must be in [0, def_cap] (WR_E_RANGE otherwise; the first batch of a call
  *         follows a join of the two streams and defers nothing).
+ *   def_count_dev (device memory, may be NULL): the same counts where the kernels can read them.  When given, nothing in
+ *         the call depends on host-side counts (the deferred launch is sized for def_cap and reads its length on the
+ *         device; def_count_host may then be NULL): the call can be captured into a hipGraph ONCE and replayed for every
+ *         plan that is built into the same arrays — one graph launch per plan instead of seven runtime calls per step.
  *   workspace >= 2 * wr_bprmf_step_workspace_bytes(batch_size, D) (stash and loss partials double-buffered by step parity).
  *   events: n_events >= 5 hipEvent_t handles created by the caller (hipEventDisableTiming is fine), used as a ring.
  * On entry the side stream is made to wait for everything queued on stream_main; on return stream_main is ordered behind
@@ -224,8 +228,9 @@ int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_t
                                  const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                                  const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
                                  int64_t n_batches, float lr, float *loss_out, const int32_t *tdef, const int32_t *def_q,
-                                 const int32_t *def_count_host, int64_t def_cap, void *workspace, int64_t workspace_bytes,
-                                 void *stream_main, void *stream_side, void *const *events, int32_t n_events);
+                                 const int32_t *def_count_host, const int32_t *def_count_dev, int64_t def_cap, void *workspace,
+                                 int64_t workspace_bytes, void *stream_main, void *stream_side, void *const *events,
+                                 int32_t n_events);
 
 /* Plan-time marks for wr_bprmf_run_sgd_overlap (index work only; call after the plan build, on the same stream).
  *   bitmap [n_batches * ceil(n_items/32)] (out): per batch, bit r = item row r has several occurrences in the batch;

@@ -101,6 +101,12 @@ def test_overlapped_steps_equal_ordinary_steps_bitwise(ops, nI, D):
         torch.cuda.synchronize()
         outs.append((tabs.U.clone(), tabs.I.clone(), losses.clone()))
     assert torch.equal(outs[0][0], ref.U) and torch.equal(outs[0][1], ref.I)           # same tables, bit for bit
+    # static form (launches sized for the lists' capacity, counts read on the device: what the hipGraph replays)
+    tabs = ops.BprmfTables(T(U, dev), T(I, dev))
+    l_static = tabs.run_sgd_overlap(plan, 0, nb, lr, None, side, ev, static=True)
+    torch.cuda.synchronize()
+    assert torch.equal(tabs.U, ref.U) and torch.equal(tabs.I, ref.I)
+    assert rel_err(l_static.cpu().numpy(), l_ref.cpu().numpy()) < 1e-6
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     assert rel_err(outs[0][2].cpu().numpy(), l_ref.cpu().numpy()) < 1e-6
     Uo, Io = U.copy(), I.copy()
@@ -125,24 +131,23 @@ def test_pipeline_picks_the_stream_per_plan_and_results_do_not_depend_on_it(ops,
     for overlap in (True, False):
         pipe = ops.PipelinedSgd(chunk=4, min_triplets=1, overlap=overlap)
         Ud, Id = T(U, dev), T(I, dev)
-        h = pipe.plan(Ud, [(Id, T(u, dev), T(p, dev), T(n, dev))], B)
+        h = pipe.plan(Ud, [(Id, T(u, dev), T(p, dev), T(n, dev))], B, lr=lr if case != "hot_rows" else None)
         losses = torch.empty(nb, dtype=torch.float32, device=dev)
-        seen = []
-        orig = ops.BprmfTables.run_sgd_overlap
-        def spy(self, *a, **k):
-            seen.append(a[2]); return orig(self, *a, **k)
-        ops.BprmfTables.run_sgd_overlap = spy
-        try:
-            pipe.run(h, 0, lr, losses)
-        finally:
-            ops.BprmfTables.run_sgd_overlap = orig
+        pipe.run(h, 0, lr, losses)
         torch.cuda.synchronize()
         res.append((Ud, Id, losses))
-        used.append(sum(seen))
-    assert used[1] == 0
-    assert (used[0] > 0) == (case == "qualifies"), (case, used)
+        used.append(dict(pipe.stats))
+    assert used[1]["graph_replays"] == 0 and used[1]["plain_calls"] == 3
+    # plans of 4, 4 and 3 batches: the two full ones replay the captured overlapped stream when they qualify
+    assert used[0]["graph_replays"] == (2 if case == "qualifies" else 0), (case, used)
+    assert used[0]["graph_replays"] + used[0]["plain_calls"] == 3
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert rel_err(res[0][2].cpu().numpy(), res[1][2].cpu().numpy()) < 1e-6
+    Uo, Io = U.copy(), I.copy()
+    ref = [oracle.bprmf_step_sgd(Uo, Io, u[k * B:(k + 1) * B], p[k * B:(k + 1) * B], n[k * B:(k + 1) * B], lr, 0.0)
+           for k in range(nb)]
+    assert rel_err(res[0][2].cpu().numpy(), np.asarray(ref)) < TOL
+    assert rel_err(res[0][0].cpu().numpy(), Uo) < TOL and rel_err(res[0][1].cpu().numpy(), Io) < TOL
 
 
 def test_overlap_entry_refuses_lists_beyond_capacity_and_missing_events(ops):

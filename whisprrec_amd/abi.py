@@ -48,7 +48,8 @@ SIGNATURES = {
     "wr_bprmf_run_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                  c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_run_sgd_overlap": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
-                                         c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32]),
+                                         c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
+                                         c_i32]),
     "wr_bprmf_plan_overlap_marks": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
                                             c_vp]),
     "wr_bprmf_grads": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,

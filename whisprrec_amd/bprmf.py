@@ -264,7 +264,7 @@ def make_bprmf(general_model_cls):
                 # stateless update: plans built on a side stream one chunk ahead of the steps, steps issued natively
                 if getattr(self, "_pipe", None) is None:
                     self._pipe = hip_ops.PipelinedSgd(chunk)
-                handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size)
+                handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size, lr=lr)
                 self._pipe.run(handle, 0, lr, losses)
                 return losses
             chunk = hip_ops.PipelinedSgd(chunk).chunk_batches(batch_size)   # small batches: more of them per plan

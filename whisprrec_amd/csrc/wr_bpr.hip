@@ -216,7 +216,8 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
                                                             float *__restrict__ gradI, int *__restrict__ stampI,
                                                             int step_id, float denom, AdamArgs ad,
                                                             const int *__restrict__ dmask,
-                                                            const int *__restrict__ dlist, int n_list) {
+                                                            const int *__restrict__ dlist, int n_list,
+                                                            const int *__restrict__ n_list_dev) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
@@ -237,7 +238,9 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
         if constexpr (DEF == 2) {
             // a listed head: its position comes from the list, everything else as below (one more dependent load, on a
             // launch of a few dozen workgroups)
-            if (team < n_list) {
+            // n_list_dev: the list's length lives in device memory (a captured launch is sized for the list's capacity)
+            const int nl = n_list_dev != nullptr ? min(*n_list_dev, n_list) : n_list;
+            if (team < nl) {
                 const int t = dlist[team];
                 t0[s] = t;
                 const int u = tu[t], un = tu[min(t + 1, B - 1)];
@@ -745,11 +748,11 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
         if (have_hot_u)                                                                                                   \
             WR_LAUNCH((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, true>), gridA, 0, ev(0), none, U, I, D, tu, tp,         \
                       tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad,             \
-                      (const int *)nullptr, (const int *)nullptr, 0);                                                     \
+                      (const int *)nullptr, (const int *)nullptr, 0, (const int *)nullptr);                               \
         else                                                                                                              \
             WR_LAUNCH((bprmf_user_phase<T_, NV_, FULL_, MODE, 1, false>), gridA, 0, ev(0), ev(1), U, I, D, tu,             \
                       tp, tn, (int)B, lr, l2, w.Z, w.partials, gradU, stamp_u, gradI, stamp_i, step_id, denom, ad,         \
-                      (const int *)nullptr, (const int *)nullptr, 0);                                                     \
+                      (const int *)nullptr, (const int *)nullptr, 0, (const int *)nullptr);                               \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_USER);
 #undef WR_CALL_USER
@@ -820,8 +823,8 @@ template <int T, int NV, bool FULL>
 static int32_t launch_overlap_steps(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
                                     const int32_t *oc_item, const int32_t *oc_src, int64_t n_triplets, int64_t batch_size,
                                     int64_t first_batch, int64_t n_batches, float lr, float *loss_out, const int32_t *tdef,
-                                    const int32_t *def_q, const int32_t *def_count_host, int64_t def_cap, void *workspace,
-                                    hipStream_t sa, hipStream_t sb, hipEvent_t *ev, int n_ev) {
+                                    const int32_t *def_q, const int32_t *def_count_host, const int32_t *def_count_dev,
+                                    int64_t def_cap, void *workspace, hipStream_t sa, hipStream_t sb, hipEvent_t *ev, int n_ev) {
     const int64_t ws_one = step_ws_bytes(batch_size, D);
     const StepWs w2[2] = {carve_step_ws(workspace, batch_size, D),
                           carve_step_ws(reinterpret_cast<char *>(workspace) + ws_one, batch_size, D)};
@@ -839,7 +842,11 @@ static int32_t launch_overlap_steps(float *U, float *I, int32_t D, const int32_t
         const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
         const StepWs &w = w2[k & 1];
         hipEvent_t evA = ev[1 + 2 * (k % R)], evD = ev[2 + 2 * (k % R)];
-        const int n_def = (k == 0) ? 0 : def_count_host[b];     // the first batch of a call follows a join: nothing to defer
+        // the first batch of a call follows a join: nothing to defer.  Static form (def_count_dev: the counts are read on
+        // the device, the deferred launch is sized for the list's capacity): nothing here depends on host-side counts, so
+        // the whole call can be captured into a hipGraph once and replayed for every plan built into the same arrays.
+        const bool is_static = def_count_dev != nullptr;
+        const int n_def = (k == 0) ? 0 : (is_static ? (int)def_cap : def_count_host[b]);
         const dim3 gridA((unsigned)n_blocks_for(Bk, D));
         const dim3 gridD((unsigned)n_blocks_for(n_def, D));
         const dim3 gridB((unsigned)((2 * Bk + kItemTile - 1) / kItemTile));
@@ -847,18 +854,20 @@ static int32_t launch_overlap_steps(float *U, float *I, int32_t D, const int32_t
         if (n_def > 0)
             hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 1>), gridA, block, 0, sa, U, I, D, tu + off, tp + off,
                                tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr, (float *)nullptr,
-                               (int *)nullptr, 0, (float)Bk, ad, tdef + b * dwords, (const int *)nullptr, 0);
+                               (int *)nullptr, 0, (float)Bk, ad, tdef + b * dwords, (const int *)nullptr, 0,
+                               (const int *)nullptr);
         else
             hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 0>), gridA, block, 0, sa, U, I, D, tu + off, tp + off,
                                tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr, (float *)nullptr,
-                               (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, (const int *)nullptr, 0);
+                               (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, (const int *)nullptr, 0,
+                               (const int *)nullptr);
         WR_LAUNCH_CHECK("bprmf_user_phase (overlap, main)");
         WR_HIP(hipEventRecord(evA, sa));
         if (n_def > 0) {
             hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 2>), gridD, block, 0, sb, U, I, D, tu + off, tp + off,
                                tn + off, (int)Bk, lr, 0.f, w.Z, w.partials + gridA.x, (float *)nullptr, (int *)nullptr,
                                (float *)nullptr, (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, def_q + b * def_cap,
-                               n_def);
+                               n_def, is_static ? def_count_dev + b : (const int *)nullptr);
             WR_LAUNCH_CHECK("bprmf_user_phase (overlap, deferred)");
         }
         WR_HIP(hipEventRecord(evD, sb));
@@ -1036,13 +1045,15 @@ int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_t
                                  const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                                  const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
                                  int64_t n_batches, float lr, float *loss_out, const int32_t *tdef, const int32_t *def_q,
-                                 const int32_t *def_count_host, int64_t def_cap, void *workspace, int64_t workspace_bytes,
-                                 void *stream_main, void *stream_side, void *const *events, int32_t n_events) {
+                                 const int32_t *def_count_host, const int32_t *def_count_dev, int64_t def_cap, void *workspace,
+                                 int64_t workspace_bytes, void *stream_main, void *stream_side, void *const *events,
+                                 int32_t n_events) {
     int32_t rc;
     if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
     if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
     if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, batch_size)) != WR_OK) return rc;
-    WR_REQUIRE(tdef && def_q && def_count_host && events, WR_E_NULL, "overlap marks / events must not be NULL");
+    WR_REQUIRE(tdef && def_q && (def_count_host || def_count_dev) && events, WR_E_NULL,
+               "overlap marks / events must not be NULL");
     WR_REQUIRE(n_triplets > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
     const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
     WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
@@ -1052,7 +1063,7 @@ int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_t
     WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 2 * step_ws_bytes(batch_size, D), WR_E_WORKSPACE,
                "wr_bprmf_run_sgd_overlap: workspace %lld B < %lld B", (long long)workspace_bytes,
                (long long)(2 * step_ws_bytes(batch_size, D)));
-    for (int64_t k = 1; k < n_batches; ++k) {       // the lists the launches are sized from must fit what the plan reserved
+    for (int64_t k = 1; def_count_host != nullptr && k < n_batches; ++k) {   // the lists must fit what the plan reserved
         const int32_t c = def_count_host[first_batch + k];
         WR_REQUIRE(c >= 0 && c <= def_cap, WR_E_RANGE, "batch %lld: %d deferred runs exceed the list capacity %lld",
                    (long long)(first_batch + k), (int)c, (long long)def_cap);
@@ -1062,8 +1073,8 @@ int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_t
     hipStream_t sa = reinterpret_cast<hipStream_t>(stream_main), sb = reinterpret_cast<hipStream_t>(stream_side);
 #define WR_CALL_OVL(T_, NV_, FULL_)                                                                                        \
     return launch_overlap_steps<T_, NV_, FULL_>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, n_triplets, batch_size, \
-                                                first_batch, n_batches, lr, loss_out, tdef, def_q, def_count_host, def_cap, \
-                                                workspace, sa, sb, ev, (int)n_events)
+                                                first_batch, n_batches, lr, loss_out, tdef, def_q, def_count_host,          \
+                                                def_count_dev, def_cap, workspace, sa, sb, ev, (int)n_events)
     WR_DISPATCH_D(D, WR_CALL_OVL);
 #undef WR_CALL_OVL
     return WR_OK;

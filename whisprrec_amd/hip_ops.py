@@ -299,12 +299,14 @@ class BatchPlan:
             a, M = arena.idx, arena.max_triplets
             self.tu, self.tp, self.tn = a[:N], a[M:M + N], a[2 * M:2 * M + N]
             self.oc_item, self.oc_src = a[3 * M:3 * M + 2 * N], a[5 * M:5 * M + 2 * N]
-            self.meta = arena.meta[:self.meta_len(self.n_batches)]
+            self._cap_batches = arena.max_batches            # the layout of the counts does not depend on this plan's size
+            self.meta = arena.meta
             self.meta.zero_()
-            self._pinned = arena.meta_host[:self.meta_len(self.n_batches)]
+            self._pinned = arena.meta_host
         else:
             self.tu, self.tp, self.tn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
             self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
+            self._cap_batches = self.n_batches
             self.meta = torch.zeros(self.meta_len(self.n_batches), **i32)
             self._pinned = None
         self.torig = torch.empty(N, **i32) if keep_orig else None
@@ -431,8 +433,8 @@ class BatchPlan:
     def _enqueue_overlap_marks(self):
         """marks of the overlapped step stream: which user runs of batch k+1 read an item row that step k's item phase
         rewrites (index work only).  The first batch of a plan defers nothing: the stream joins at plan boundaries."""
-        o, nb = self.arena.overlap, self.n_batches
-        counts = self.meta[self.META_HEAD + 4 * nb:self.META_HEAD + 5 * nb]
+        o, cb = self.arena.overlap, self._cap_batches
+        counts = self.meta[self.META_HEAD + 4 * cb:self.META_HEAD + 5 * cb]
         abi.check(abi.lib().wr_bprmf_plan_overlap_marks(_p(self.tu), _p(self.tp), _p(self.tn), self.n_triplets,
                                                         self.batch_size, self.n_items, None, _p(o["bitmap"]), _p(o["tdef"]),
                                                         _p(o["def_q"]), o["cap"], _p(counts), _stream()),
@@ -484,10 +486,11 @@ class BatchPlan:
             if int(counts_host.sum().item()) > 0:
                 self.hot = {"sides": self._sides, "counts_host": counts_host}
         if self._want_overlap and self.hot is None:
-            o, nb = self.arena.overlap, self.n_batches
-            dc = mh[self.META_HEAD + 4 * nb:self.META_HEAD + 5 * nb]
+            o, nb, cb = self.arena.overlap, self.n_batches, self._cap_batches
+            dc = mh[self.META_HEAD + 4 * cb:self.META_HEAD + 4 * cb + nb]
             if nb >= 2 and int(dc.min()) >= 0 and int(dc.max()) <= o["cap"]:
-                self.overlap = {"tdef": o["tdef"], "def_q": o["def_q"], "def_count_host": dc, "cap": o["cap"]}
+                self.overlap = {"tdef": o["tdef"], "def_q": o["def_q"], "def_count_host": dc, "cap": o["cap"],
+                                "def_count_dev": self.meta[self.META_HEAD + 4 * cb:self.META_HEAD + 5 * cb]}
         self._finished = True
         return self
 
@@ -629,21 +632,27 @@ class BprmfTables:
         self.step_id += count
         return losses
 
-    def run_sgd_overlap(self, plan, first, count, lr, losses, side, events):
+    def overlap_workspace(self, batch_size):
+        nbytes = 2 * abi.check_size(abi.lib().wr_bprmf_step_workspace_bytes(batch_size, self.D), "wr_bprmf_step_workspace_bytes")
+        return workspace(self.dev, "step_overlap").get(nbytes)
+
+    def run_sgd_overlap(self, plan, first, count, lr, losses, side, events, static=False, ws=None):
         """`count` consecutive steps like run_sgd, as the overlapped stream (wr_bprmf_run_sgd_overlap): item phase of step k
         on stream `side` beside the user phase of step k+1 on the current stream.  plan.overlap must be set (BatchPlan
-        built with overlap=True that qualified).  events: OverlapEvents.  Same tables, bit for bit, as run_sgd."""
+        built with overlap=True that qualified).  events: OverlapEvents.  Same tables, bit for bit, as run_sgd.
+        static: no host-side count enters the launches (the call may be captured into a hipGraph and replayed)."""
         L = abi.lib()
         o = plan.overlap
-        nbytes = 2 * abi.check_size(L.wr_bprmf_step_workspace_bytes(plan.batch_size, self.D), "wr_bprmf_step_workspace_bytes")
-        ws = workspace(self.dev, "step_overlap").get(nbytes)
+        if ws is None:
+            ws = self.overlap_workspace(plan.batch_size)
         if losses is None:
             losses = torch.empty(count, dtype=torch.float32, device=self.dev)
         abi.check(L.wr_bprmf_run_sgd_overlap(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(plan.tu),
                                              _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets,
                                              plan.batch_size, first, count, lr, _p(losses), _p(o["tdef"]), _p(o["def_q"]),
-                                             o["def_count_host"].data_ptr(), o["cap"], _p(ws), ws.numel(), _stream(),
-                                             side.cuda_stream, ctypes.addressof(events.array), events.n),
+                                             None if static else o["def_count_host"].data_ptr(),
+                                             _p(o["def_count_dev"]) if static else None, o["cap"], _p(ws), ws.numel(),
+                                             _stream(), side.cuda_stream, ctypes.addressof(events.array), events.n),
                   "wr_bprmf_run_sgd_overlap")
         self.step_id += count
         return losses
@@ -815,6 +824,8 @@ class PipelinedSgd:
         self.overlap = bool(overlap)
         self.item_stream = None
         self._ovl_events = None
+        self._graphs = {}
+        self.stats = {"graph_replays": 0, "plain_calls": 0}
         if min_triplets is not None:
             self.PLAN_TRIPLETS = int(min_triplets)
         self.plan_stream = None
@@ -834,7 +845,7 @@ class PipelinedSgd:
             self._arenas[key] = pair
         return pair
 
-    def plan(self, U, segments, batch, first_chunk=None):
+    def plan(self, U, segments, batch, first_chunk=None, lr=None):
         """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order.
         Only the last segment may end with a short batch.  first_chunk: batches in the first plan, or a list with the sizes
         of the first few plans (default: full chunks) — lets a caller that consumes the stream piecewise (bench.py: warm-up,
@@ -856,7 +867,10 @@ class PipelinedSgd:
         u_all, p_all, n_all = (_join_views([s[j] for s in live]) for j in (1, 2, 3))
         n_items = max([s[0].shape[0] for s in live] or [1])
         main = torch.cuda.current_stream(U.device)
-        use_overlap = self.overlap and B >= self.OVERLAP_MIN_BATCH and first >= 2
+        # the overlapped stream runs whole plans as hipGraph replays (its seven runtime calls per step would otherwise make
+        # the host the bottleneck): full chunks of a single-table handle
+        use_overlap = self.overlap and B >= self.OVERLAP_MIN_BATCH and len(segs) == 1 and \
+            first >= self.chunk_batches(B) >= 2
         if use_overlap and self.item_stream is None:
             self.item_stream = side_stream(U.device)
             self._ovl_events = self.ops.OverlapEvents(U.device)
@@ -867,9 +881,61 @@ class PipelinedSgd:
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
              "overlap": use_overlap,
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
+        if use_overlap:
+            self._capture_graphs(h, segs[0]["tabs"], lr)
         self.plan_stream.wait_stream(main)   # the index tensors are ready
         self._prefetch(h)
         return h
+
+    def _capture_graphs(self, h, tabs, lr=None):
+        """one hipGraph per arena: all steps of a full plan as the overlapped stream (static form: the launches read the
+        deferred-run counts on the device, so the same graph serves every plan built into that arena).  Captured before the
+        step stream starts; per learning rate (a kernel argument)."""
+        B, nb = h["B"], self.chunk_batches(h["B"])
+        for a in h["arenas"]:
+            key = (id(a), nb, tabs.U.data_ptr(), tabs.I.data_ptr(), tabs.D)
+            if key in self._graphs:
+                continue
+            stage = torch.empty(nb, dtype=torch.float32, device=tabs.dev)
+            ws = tabs.overlap_workspace(B)
+            M, cb = a.max_triplets, a.max_batches
+            idx, o = a.idx, a.overlap
+            head = BatchPlan.META_HEAD
+            # the arena's arrays as a full plan sees them (BatchPlan.__init__)
+            shell = type("ArenaPlan", (), {})()
+            shell.tu, shell.tp, shell.tn = idx[:nb * B], idx[M:M + nb * B], idx[2 * M:2 * M + nb * B]
+            shell.oc_item, shell.oc_src = idx[3 * M:3 * M + 2 * nb * B], idx[5 * M:5 * M + 2 * nb * B]
+            shell.n_triplets, shell.batch_size = nb * B, B
+            shell.overlap = {"tdef": o["tdef"], "def_q": o["def_q"], "cap": o["cap"], "def_count_host": None,
+                             "def_count_dev": a.meta[head + 4 * cb:head + 5 * cb]}
+            self._graphs[key] = {"stage": stage, "lr": {}, "shell": shell, "ws": ws}
+        h["graph_tabs"] = tabs
+        if lr is not None:
+            for a in h["arenas"]:
+                self._graph_of(self._graphs[(id(a), nb, tabs.U.data_ptr(), tabs.I.data_ptr(), tabs.D)], tabs, nb, lr)
+
+    def _graph_of(self, rec, tabs, nb, lr):
+        g = rec["lr"].get(float(lr))
+        if g is None:
+            # first use of this learning rate (a kernel argument): capture.  torch synchronises the device around a capture.
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                tabs.run_sgd_overlap(rec["shell"], 0, nb, lr, rec["stage"], self.item_stream, self._ovl_events, static=True,
+                                     ws=rec["ws"])
+            tabs.step_id -= nb
+            rec["lr"][float(lr)] = g
+        return g
+
+    def _graph_for(self, h, plan, lr):
+        """the captured stream for this plan, or None (partial plan, lists beyond capacity, hot rows: ordinary stream)"""
+        if plan.overlap is None or plan.n_triplets != plan.arena.max_triplets:
+            return None
+        tabs = h["graph_tabs"]
+        rec = self._graphs.get((id(plan.arena), plan.n_batches, tabs.U.data_ptr(), tabs.I.data_ptr(), tabs.D))
+        if rec is None:
+            return None
+        g = self._graph_of(rec, tabs, plan.n_batches, lr)
+        return g, rec["stage"]
 
     def _prefetch(self, h):
         """enqueue the plan of the next chunk of batches on the side stream (no host wait, no allocation)"""
@@ -919,12 +985,16 @@ class PipelinedSgd:
             if cur is None or pos >= cur[0] + cur[1].n_batches:
                 cur = self._take_next(h, pos, main)
             base, plan = cur
-            c = min(min(end, base + plan.n_batches) - pos, 256)      # at most 256 steps per native call
-            if plan.overlap is not None and c >= 2:
-                sg["tabs"].run_sgd_overlap(plan, pos - base, c, lr, losses[loss_off:loss_off + c], self.item_stream,
-                                           self._ovl_events)
+            c = min(end, base + plan.n_batches) - pos
+            graph = self._graph_for(h, plan, lr) if (h["overlap"] and pos == base and c == plan.n_batches) else None
+            if graph is not None:
+                graph[0].replay()                                    # the whole plan as the overlapped stream, one launch
+                self.stats["graph_replays"] += 1
+                losses[loss_off:loss_off + c].copy_(graph[1])
+                sg["tabs"].step_id += c
             else:
                 sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
+                self.stats["plain_calls"] += 1
             pos += c
             loss_off += c
             if pos >= base + plan.n_batches:
