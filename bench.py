@@ -47,8 +47,9 @@ def parse(argv=None):
     ap.add_argument("--lr", type=float, default=0.05)
     ap.add_argument("--chunk", type=int, default=0, help="batches per plan build (0: min(64, steps))")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent over items (0 = uniform, headline)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="ordinary step stream (item phase of step k strictly before the user phase of step k+1) for A/B")
+    ap.add_argument("--overlap", action="store_true",
+                    help="A/B: overlapped step stream (item phase of step k beside the user phase of step k+1, hipGraph replays); "
+                         "slower than the ordinary stream on this stack, see DESIGN.md section 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-events", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -219,11 +220,11 @@ def single_gpu(args, local_rank):
     # steps — and the timed region builds the plans of the chunks that FOLLOW its own chunks, the last of which is the spare
     # one: K batches' worth of plan builds between the two timestamps, K steps trained.
     u, p, n = synth_triplets((K + W + C) * B, args.users, args.items, dev, 3407, args.zipf)
-    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=not args.no_overlap)
+    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=args.overlap)
     losses_w = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
     losses = torch.empty(K, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    if not args.no_overlap and K + C >= 2 * C:
+    if args.overlap:
         # Untimed priming of the overlapped stream, before the warm-up: its two hipGraphs (one per plan arena) are captured
         # and each is replayed once, on the first 2 C batches of the data.  These are ordinary training steps; they are
         # neither part of the W warm-up steps nor of the K timed ones.
@@ -320,7 +321,7 @@ def single_gpu(args, local_rank):
                       "batch": B, "emb_size": D, "optimizer": "SGD", "l2": 0.0, "lr": args.lr,
                       "plan_chunk_batches": C, "tables": "single GPU", "step_stream": "whisprrec_amd.hip_ops.PipelinedSgd",
                       "overlapped_item_phase": bool(plan.overlap is not None and handle["overlap"]),
-                      "untimed_priming_steps": 0 if args.no_overlap else 2 * C},
+                      "untimed_priming_steps": 2 * C if args.overlap else 0},
            "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
            "roofline": roofline}
     if not args.no_cpu_baseline:

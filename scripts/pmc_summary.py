@@ -25,5 +25,11 @@ for k, d in sorted(res.items()):
     summary[k] = {"launches": f[1] or w[1], "FETCH_SIZE_KiB_raw": f[0], "WRITE_SIZE_KiB": w[0],
                   "read_bytes_corrected_x2": f[0] * 1024 * 2, "write_bytes": w[0] * 1024,
                   "hbm_bytes": f[0] * 1024 * 2 + w[0] * 1024}
-print(json.dumps(summary, indent=1))
-json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+# bench.py quotes a kernel's traffic only when this summary was taken on the kernel sources it runs: record their hash
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+rec = {"csrc_sha": bench.csrc_sha(), "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> (separate passes) -- "
+       "python3 scripts/exp_kernels.py 0   [configs[1]: 1M x 1M, D=64, B=65,536, uniform ids]",
+       "kernels": {k.replace("void wr::", ""): v for k, v in summary.items()}}
+print(json.dumps(rec, indent=1))
+json.dump(rec, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)

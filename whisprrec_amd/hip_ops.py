@@ -815,9 +815,12 @@ class PipelinedSgd:
     PLAN_TRIPLETS = 1 << 22
     OVERLAP_MIN_BATCH = 8192      # below this a step is launch-bound and a third launch per step costs more than it hides
 
-    def __init__(self, chunk=64, min_triplets=None, overlap=True):
+    def __init__(self, chunk=64, min_triplets=None, overlap=False):
         """overlap: run plans that qualify (no hot rows; B >= OVERLAP_MIN_BATCH) as the overlapped stream — item phase of
-        step k beside the user phase of step k+1 (wr_bprmf_run_sgd_overlap); same tables bit for bit"""
+        step k beside the user phase of step k+1 (wr_bprmf_run_sgd_overlap); same tables bit for bit.  OFF by default: on
+        MI355X / ROCm 7.2 the cross-stream event hand-offs it needs cost more than the item phase they hide (measured at
+        1M x 1M, D = 64, B = 65,536: ordinary stream 29.1-30.2 us/step, overlapped 38.3-39.3 eagerly — host-bound on seven
+        runtime calls per step — and 72-77 as a hipGraph replay)."""
         import sys
         self.ops = sys.modules[__name__]
         self.chunk = int(chunk)
