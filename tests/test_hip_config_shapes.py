@@ -147,3 +147,66 @@ def test_c5_sasrec_item_embedding_slice_ml1m_shape():
     assert rel_err(got, ref) < TOL
     assert not got[0].any()                                             # row 0: all three uses drop its gradient
     assert idx.size == B * (T + 2) and (idx == 0).sum() > 1000          # ~45 K rows, thousands of them padding
+
+
+@pytest.mark.parametrize("D,min_density", [(64, 0.12), (64, 0.05), (32, 0.2), (128, 0.12)])
+def test_c3_hybrid_mfma_spmm_matches_oracle_csr_product(D, min_density):
+    """the dense head of the adjacency on the matrix cores + the rest on the CSR kernels = the oracle's CSR product
+    (reference LightGCN.py:139), layer sum included; bitwise reproducible"""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    nU, nI = 6040, 3706
+    uu, ii = ml1m_shaped_pairs()
+    ptr = np.zeros(nU + 1, np.int64)
+    np.cumsum(np.bincount(uu, minlength=nU), out=ptr[1:])
+    rp, col, val = oracle.lightgcn_build_adj(nU, nI, ptr, ii.astype(np.int32))
+    rng = np.random.RandomState(D)
+    X = (rng.standard_normal((nU + nI, D)) * 0.1).astype(np.float32)
+    A0 = (rng.standard_normal((nU + nI, D)) * 0.1).astype(np.float32)
+    ref = oracle.spmm_csr(rp, col, val, X)
+    hy = hip_ops.HybridSpmm(rp, col, val, nU, nI, dev, min_density=min_density)
+    assert hy.enabled and hy.H >= 32 and hy.density > 0.5 * min_density
+    Xd = torch.from_numpy(X).to(dev)
+    acc = torch.from_numpy(A0).to(dev)
+    Y = hy.apply(Xd, acc=acc)
+    assert rel_err(Y.cpu().numpy(), ref) < TOL
+    assert rel_err(acc.cpu().numpy(), A0 + ref) < TOL
+    acc2 = torch.from_numpy(A0).to(dev)
+    Y2 = hy.apply(Xd, acc=acc2)
+    assert torch.equal(Y, Y2) and torch.equal(acc, acc2)
+    # a graph without a dense head: the hybrid declines
+    flat = hip_ops.HybridSpmm(rp, col, val, nU, nI, dev, min_density=0.9)
+    assert not flat.enabled
+
+
+def test_c3_lightgcn_with_the_mfma_product_matches_oracle():
+    """LightGCN.predict + backward with --spmm_mfma 1 on the ml-1m-shaped graph against the oracle (as the CSR-only test)"""
+    from whisprrec_amd.lightgcn import LightGCN
+    dev = torch.device("cuda:0")
+    nU, nI, D, B, L = 6040, 3706, 64, 2048, 2
+    uu, ii = ml1m_shaped_pairs()
+    ptr = np.zeros(nU + 1, np.int64)
+    np.cumsum(np.bincount(uu, minlength=nU), out=ptr[1:])
+    tcs = {u: set(ii[ptr[u]:ptr[u + 1]].tolist()) for u in range(nU)}
+    corpus = host.Corpus(nU, nI, {"train": {"user_id": [], "item_id": []}, "dev": {"user_id": [], "item_id": []},
+                                  "test": {"user_id": [], "item_id": []}}, tcs, {})
+    args = argparse.Namespace(device=dev, model_path="/tmp/wr_lgcn_c3m.pt", buffer=1, num_neg=1, test_all=1, embedding_size=D,
+                              gcn_layers=L, reg_weight=1e-5, spmm_mfma=1)
+    m = LightGCN(args, corpus).to(dev)
+    rng = np.random.RandomState(8)
+    E0 = (rng.standard_normal((nU + nI, D)) * 0.1).astype(np.float32)
+    with torch.no_grad():
+        m.user_embedding.weight.copy_(torch.from_numpy(E0[:nU]))
+        m.item_embedding.weight.copy_(torch.from_numpy(E0[nU:]))
+    rows = rng.randint(0, uu.size, B)
+    u, p, n = uu[rows], ii[rows], rng.randint(1, nI, B)
+    rp, col, val = oracle.lightgcn_build_adj(nU, nI, ptr, ii.astype(np.int32))
+    loss_ref, g_ref = oracle.lightgcn_loss_grads(nU, nI, rp, col, val, E0, L, 1e-5, u, p, n)
+    m.train()
+    loss = m.predict({"user_id": torch.from_numpy(u).to(dev), "pos_item": torch.from_numpy(p).to(dev),
+                      "neg_items": torch.from_numpy(n).to(dev)})
+    assert m._hybrid is not None and m._hybrid.enabled
+    assert abs(float(loss.detach()) - loss_ref) / abs(loss_ref) < TOL
+    loss.backward()
+    assert rel_err(m.user_embedding.weight.grad.cpu().numpy(), g_ref[:nU]) < TOL
+    assert rel_err(m.item_embedding.weight.grad.cpu().numpy(), g_ref[nU:]) < TOL

@@ -228,12 +228,17 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
                                                              const int *__restrict__ chunk_row, const int *__restrict__ col,
                                                              const float *__restrict__ val, const float *__restrict__ X, int D,
                                                              float *__restrict__ Y, float *__restrict__ acc,
-                                                             float *__restrict__ partials) {
+                                                             float *__restrict__ partials,
+                                                             const signed char *__restrict__ row_mode) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int c = blockIdx.x * TEAMS + threadIdx.x / T;
     if (c >= n_chunks) return;
     const int row = chunk_row[c];
+    // row_mode (hybrid product, wr_spmm_mfma.hip): 0 write the row, 1 add to what the dense tiles left in Y[row],
+    // 2 the row belongs to the dense tiles entirely
+    const int mode = row_mode != nullptr ? (int)row_mode[row] : 0;
+    if (mode == 2) return;
     const bool multi = (c > 0 && chunk_row[c - 1] == row) || (c + 1 < n_chunks && chunk_row[c + 1] == row);
     Row<NV> s;
 #pragma unroll
@@ -277,6 +282,13 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
     if (multi) {
         store_row<T, NV, FULL>(partials, c, D, lane, s);
         return;
+    }
+    if (mode == 1) {
+        const Row<NV> y0 = load_row<T, NV, FULL>(Y, row, D, lane);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            s.v[q].x += y0.v[q].x; s.v[q].y += y0.v[q].y; s.v[q].z += y0.v[q].z; s.v[q].w += y0.v[q].w;
+        }
     }
     store_row<T, NV, FULL>(Y, row, D, lane, s);
     if (acc != nullptr) {
@@ -339,7 +351,8 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_groups_kernel(int n_chunk
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, const int *__restrict__ chunk_row,
                                                                const float *__restrict__ partials, int D, float *__restrict__ Y,
-                                                               float *__restrict__ acc) {
+                                                               float *__restrict__ acc,
+                                                               const signed char *__restrict__ row_mode) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int c = blockIdx.x * TEAMS + threadIdx.x / T;
@@ -347,8 +360,17 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, cons
     const int row = chunk_row[c];
     const bool head = (c == 0 || chunk_row[c - 1] != row) && (c + 1 < n_chunks && chunk_row[c + 1] == row);
     if (!head) return;
+    const int mode = row_mode != nullptr ? (int)row_mode[row] : 0;
+    if (mode == 2) return;
     // the head's own partial holds its group's sum; the row's other group leaders sit at the following group boundaries
-    const Row<NV> s = sum_partials<T, NV, FULL>(partials, chunk_row, row, c, (c / kGroup + 1) * kGroup, kGroup, n_chunks, D, lane);
+    Row<NV> s = sum_partials<T, NV, FULL>(partials, chunk_row, row, c, (c / kGroup + 1) * kGroup, kGroup, n_chunks, D, lane);
+    if (mode == 1) {
+        const Row<NV> y0 = load_row<T, NV, FULL>(Y, row, D, lane);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            s.v[q].x += y0.v[q].x; s.v[q].y += y0.v[q].y; s.v[q].z += y0.v[q].z; s.v[q].w += y0.v[q].w;
+        }
+    }
     store_row<T, NV, FULL>(Y, row, D, lane, s);
     if (acc != nullptr) {
         Row<NV> a = load_row<T, NV, FULL>(acc, row, D, lane);
@@ -620,9 +642,9 @@ int32_t wr_spmm_csr(int64_t n_rows, const int64_t *row_ptr, const int32_t *col, 
     return WR_OK;
 }
 
-int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
-                            const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
-                            float *partials, void *stream_) {
+static int32_t spmm_chunked_impl(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                                 const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
+                                 float *partials, const signed char *row_mode, void *stream_) {
     int32_t rc;
     if ((rc = check_table(X, n_rows, D, "X")) != WR_OK) return rc;
     if ((rc = check_table(Y, n_rows, D, "Y")) != WR_OK) return rc;
@@ -636,16 +658,30 @@ int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chu
 #define WR_CALL_MC(T_, NV_, FULL_)                                                                                      \
     do {                                                                                                                \
         hipLaunchKernelGGL((spmm_chunk_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,      \
-                           chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials);                                     \
+                           chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials, row_mode);                           \
         hipLaunchKernelGGL((spmm_combine_groups_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream,            \
                            (int)n_chunks, chunk_row, partials, D);                                                      \
         hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,    \
-                           chunk_row, partials, D, Y, acc);                                                             \
+                           chunk_row, partials, D, Y, acc, row_mode);                                                   \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_MC);
 #undef WR_CALL_MC
     WR_LAUNCH_CHECK("spmm_chunk_kernel");
     return WR_OK;
+}
+
+int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                            const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
+                            float *partials, void *stream_) {
+    return spmm_chunked_impl(n_rows, n_chunks, chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials, nullptr, stream_);
+}
+
+int32_t wr_spmm_csr_chunked_modes(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                                  const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
+                                  float *partials, const int8_t *row_mode, void *stream_) {
+    WR_REQUIRE(row_mode != nullptr, WR_E_NULL, "row_mode is NULL");
+    return spmm_chunked_impl(n_rows, n_chunks, chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials,
+                             reinterpret_cast<const signed char *>(row_mode), stream_);
 }
 
 int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream_) {

@@ -1223,6 +1223,96 @@ def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partia
     return Y
 
 
+class HybridSpmm:
+    """Normalised-adjacency product with the dense head of the item popularity on the matrix cores (wr_spmm_mfma.hip) and
+    the rest on the chunked CSR kernels.  Built once per graph from the symmetric bipartite CSR of LightGCN
+    (reference src/models/general/LightGCN.py:54-121: nodes 0..n_users-1 are users, the others items).  Head = the items
+    rated by at least `min_density` of the users (at most `max_head`, in tiles of 32).  ``enabled`` is False when the graph
+    has no such items — then use spmm_csr_chunked."""
+
+    def __init__(self, row_ptr, col, val, n_users, n_items, device, min_density=0.12, max_head=512, k_split=512):
+        import numpy as np
+        rp, col, val = np.asarray(row_ptr, np.int64), np.asarray(col, np.int64), np.asarray(val, np.float32)
+        nU, nI = int(n_users), int(n_items)
+        N = nU + nI
+        deg = np.diff(rp)
+        order = np.argsort(-deg[nU:], kind="stable")
+        n_head = int((deg[nU:] >= min_density * nU).sum())
+        H = min((n_head + 31) // 32 * 32, int(max_head) // 32 * 32, nI // 32 * 32)
+        self.enabled = H >= 32 and n_head >= 16
+        self.n_nodes, self.device = N, device
+        if not self.enabled:
+            return
+        head_nodes = nU + order[:H]
+        pos_of = np.full(N, -1, np.int64)
+        pos_of[head_nodes] = np.arange(H)
+        rows = np.repeat(np.arange(N), deg)
+        user_head = (rows < nU) & (pos_of[col] >= 0)
+        nU_pad = (nU + 31) // 32 * 32
+        Dn = np.zeros((nU_pad, H), np.float32)
+        Dn[rows[user_head], pos_of[col[user_head]]] = val[user_head]
+        self.head_nnz = int(user_head.sum())
+        self.density = self.head_nnz / float(nU * H)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        # user-side tiles: 32 users x K = H head items (one split)
+        self.u_tiles = nU_pad // 32
+        self.u_A = f32(Dn.reshape(self.u_tiles, 32, H).transpose(0, 2, 1))            # [tile][k][32]
+        self.u_K = H
+        self.u_cols = i32(head_nodes)
+        u_rows = np.arange(nU_pad)
+        u_rows[nU:] = -1
+        self.u_rows = i32(u_rows)
+        # item-side tiles: 32 head items x K = all users, K cut into splits of k_split columns
+        self.k_split = int(k_split)
+        K2 = (nU + self.k_split - 1) // self.k_split * self.k_split
+        Dk = np.zeros((K2, H), np.float32)
+        Dk[:nU] = Dn[:nU]                                                               # A[h, u] = A[u, h]
+        self.i_tiles = H // 32
+        self.i_A = f32(Dk.reshape(K2, self.i_tiles, 32).transpose(1, 0, 2))            # [tile][k = user][32 head items]
+        self.i_K = K2
+        self.i_cols = i32(np.minimum(np.arange(K2), nU - 1))                           # padding columns: zero values
+        self.i_rows = i32(head_nodes)
+        # CSR part: everything but the (user, head item) entries and the head items' rows
+        keep = ~(user_head | (pos_of[rows] >= 0))
+        r_deg = np.bincount(rows[keep], minlength=N)
+        r_rp = np.zeros(N + 1, np.int64)
+        np.cumsum(r_deg, out=r_rp[1:])
+        cptr, crow = spmm_chunks(r_rp)
+        self.chunk_ptr, self.chunk_row = cptr.to(device), crow.to(device)
+        self.col, self.val = i32(col[keep]), f32(val[keep])
+        mode = np.zeros(N, np.int8)
+        mode[:nU] = 1
+        mode[head_nodes] = 2
+        self.row_mode = torch.from_numpy(mode).to(device)
+        self.n_head, self.H = n_head, H
+        self._partials = {}
+
+    def apply(self, X, Y=None, acc=None):
+        """Y = A X (and acc += Y); X [n_nodes, D] fp32"""
+        L = abi.lib()
+        _req(X, torch.float32, "X", 2)
+        N, D = X.shape
+        if Y is None:
+            Y = torch.empty_like(X)
+        pt = self._partials.get(D)
+        if pt is None:
+            nb = abi.check_size(L.wr_spmm_dense_partials_bytes(self.i_tiles, self.i_K, self.k_split, D), "wr_spmm_dense_partials_bytes")
+            pt = (torch.empty(max(nb // 4, 4), dtype=torch.float32, device=X.device),
+                  torch.empty((self.chunk_row.numel(), D), dtype=torch.float32, device=X.device))
+            self._partials[D] = pt
+        # user rows: dense part first (Y = block product), the CSR kernels then add the rest and the layer sum
+        abi.check(L.wr_spmm_dense_tiles(_p(self.u_A), self.u_tiles, self.u_K, self.u_K, _p(self.u_cols), _p(self.u_rows), _p(X), N,
+                                        D, _p(Y), None, None, _stream()), "wr_spmm_dense_tiles")
+        # head item rows: complete on the matrix cores (K = all users, split over workgroups)
+        abi.check(L.wr_spmm_dense_tiles(_p(self.i_A), self.i_tiles, self.i_K, self.k_split, _p(self.i_cols), _p(self.i_rows),
+                                        _p(X), N, D, _p(Y), _p(acc), _p(pt[0]), _stream()), "wr_spmm_dense_tiles")
+        abi.check(L.wr_spmm_csr_chunked_modes(N, self.chunk_row.numel(), _p(self.chunk_ptr), _p(self.chunk_row), _p(self.col),
+                                              _p(self.val), _p(X), D, _p(Y), _p(acc), _p(pt[1]), _p(self.row_mode), _stream()),
+                  "wr_spmm_csr_chunked_modes")
+        return Y
+
+
 def axpy(y, x, alpha, overwrite=False):
     abi.check(abi.lib().wr_axpy(_p(_req(y, torch.float32, "y")), _p(_req(x, torch.float32, "x")), y.numel(), alpha,
                                 1 if overwrite else 0, _stream()), "wr_axpy")

@@ -51,6 +51,9 @@ def build_norm_adj_csr(n_users, n_items, train_clicked_set):
     return row_ptr, cols.astype(np.int32), val
 
 
+SPMM_MFMA_DEFAULT = 0     # decided by measurement: scripts/ab_spmm.py, DESIGN.md section 5
+
+
 class DenseHipOptimizer:
     """zero_grad/step over dense ``.grad`` tensors with the HIP dense optimizers (torch.optim.SGD / Adam semantics,
     reference BaseRunner.py:120-124).  Adam keeps its step number on the DEVICE (a counter bumped by a one-thread kernel,
@@ -134,6 +137,9 @@ def make_lightgcn(general_model_cls):
             parser.add_argument("--embedding_size", type=int, default=64, help="Size of embedding vectors.")
             parser.add_argument("--gcn_layers", type=int, default=2, help="Number of LightGCN layers.")
             parser.add_argument("--reg_weight", type=float, default=1e-05, help="The L2 regularization weight.")
+            parser.add_argument("--spmm_mfma", type=int, default=SPMM_MFMA_DEFAULT,
+                                help="1: the dense head of the adjacency (popular items) runs on the matrix cores "
+                                     "(hip_ops.HybridSpmm), the rest on the CSR kernels; 0: CSR kernels only.")
             return general_model_cls.parse_model_args(parser)
 
         def __init__(self, args, corpus):
@@ -150,6 +156,9 @@ def make_lightgcn(general_model_cls):
             # plain attributes like the reference's norm_adj (not buffers: absent from state_dict, LightGCN.py:49-51)
             cptr, crow = hip_ops.spmm_chunks(rp)   # rows cut into <= 32-non-zero chunks: hubs do not serialise on one team
             self._csr_host = (cptr, crow, torch.from_numpy(col), torch.from_numpy(val))
+            self._csr_full = (rp, col, val)
+            self._use_mfma = bool(getattr(args, "spmm_mfma", SPMM_MFMA_DEFAULT)) and self.emb_size in (32, 64, 96, 128)
+            self._hybrid = None
             self._csr_dev = None
             self._partials = None
             nn.init.xavier_uniform_(self.user_embedding.weight.data)   # LightGCN.py:52, init.py:32-48
@@ -171,6 +180,15 @@ def make_lightgcn(general_model_cls):
             cptr, crow, col, val = self._csr()
             acc = E0.clone()
             cur = E0
+            if self._use_mfma and E0.is_cuda:
+                if self._hybrid is None or self._hybrid.device != E0.device:
+                    self._hybrid = hip_ops.HybridSpmm(*self._csr_full, self.n_users, self.n_items, E0.device)
+                if self._hybrid.enabled:
+                    for _ in range(self.gcn_layers):
+                        cur = self._hybrid.apply(cur, acc=acc)
+                    out = torch.empty_like(acc)
+                    hip_ops.axpy(out, acc, 1.0 / (self.gcn_layers + 1), overwrite=True)
+                    return out
             if self._partials is None or self._partials.device != E0.device:
                 self._partials = torch.empty((crow.numel(), E0.shape[1]), dtype=torch.float32, device=E0.device)
             for _ in range(self.gcn_layers):
