@@ -21,7 +21,37 @@ namespace wr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kDenseWaves = kBlock / 64;   // waves per workgroup = K slices per split
-constexpr int kDenseUnroll = 4;            // k-pairs in flight per wave (loads of 4 pairs issued before their MFMAs)
+constexpr int kDenseUnroll = 4;            // k-pairs per stage: the loads of a stage are issued together
+constexpr int kDenseMaxKw = 256;           // longest K slice of one wave (its column ids are kept in 4 registers)
+
+// One stage = kDenseUnroll k-pairs: per pair one A value and NJ B values per lane.  The column ids of the wave's whole K
+// slice sit in registers (ccache, lane l of register j = column kb + 64 j + l), so a stage's loads depend on nothing
+// loaded inside the loop and the NEXT stage's loads are issued before the current stage's MFMAs (two register stages).
+template <int NJ>
+struct DenseStage {
+    float a[kDenseUnroll];
+    float b[kDenseUnroll][NJ];
+};
+
+template <int NJ>
+__device__ __forceinline__ void dense_load_stage(DenseStage<NJ> &st, const float *__restrict__ At, const float *__restrict__ X,
+                                                 const int (&ccache)[kDenseMaxKw / 64], int k, int kb, int half, int col) {
+    constexpr int D = 32 * NJ;
+#pragma unroll
+    for (int q = 0; q < kDenseUnroll; ++q) {
+        const int kk = k + 2 * q + half;
+        const int rel = kk - kb;
+        int c = __shfl(ccache[0], rel & 63, 64);
+#pragma unroll
+        for (int j = 1; j < kDenseMaxKw / 64; ++j) {
+            const int cj = __shfl(ccache[j], rel & 63, 64);
+            c = (rel >> 6) == j ? cj : c;
+        }
+        st.a[q] = At[(int64_t)kk * 32];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) st.b[q][j] = X[(int64_t)c * D + 32 * j + col];
+    }
+}
 
 template <int NJ>   // D = 32 * NJ
 __global__ __launch_bounds__(kBlock) void spmm_dense_tiles_kernel(const float *__restrict__ A_T, int K_pad, int k_per_split,
@@ -33,32 +63,32 @@ __global__ __launch_bounds__(kBlock) void spmm_dense_tiles_kernel(const float *_
     const int tile = blockIdx.x, split = blockIdx.y, n_splits = gridDim.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
-    const int kw = k_per_split / kDenseWaves;                 // multiple of 2 * kDenseUnroll (checked on the host)
+    const int kw = k_per_split / kDenseWaves;                 // multiple of 2 * kDenseUnroll, <= kDenseMaxKw (host-checked)
     const int kb = split * k_per_split + wave * kw, ke = kb + kw;
     const float *At = A_T + ((int64_t)tile * K_pad) * 32 + col;
+    int ccache[kDenseMaxKw / 64];
+#pragma unroll
+    for (int j = 0; j < kDenseMaxKw / 64; ++j) ccache[j] = (64 * j + lane < kw) ? cols[kb + 64 * j + lane] : 0;
     f32x16 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-    for (int k = kb; k < ke; k += 2 * kDenseUnroll) {
-        float a[kDenseUnroll];
-        int c[kDenseUnroll];
-        float b[kDenseUnroll][NJ];
-#pragma unroll
-        for (int q = 0; q < kDenseUnroll; ++q) {
-            const int kk = k + 2 * q + half;
-            a[q] = At[(int64_t)kk * 32];
-            c[q] = cols[kk];
-        }
+    DenseStage<NJ> s0, s1;
+    dense_load_stage<NJ>(s0, At, X, ccache, kb, kb, half, col);
+    for (int k = kb; k < ke; k += 4 * kDenseUnroll) {
+        const bool more1 = k + 2 * kDenseUnroll < ke;
+        if (more1) dense_load_stage<NJ>(s1, At, X, ccache, k + 2 * kDenseUnroll, kb, half, col);
 #pragma unroll
         for (int q = 0; q < kDenseUnroll; ++q)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[q][j] = X[(int64_t)c[q] * D + 32 * j + col];
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(s0.a[q], s0.b[q][j], acc[j], 0, 0, 0);
+        if (!more1) break;
+        if (k + 4 * kDenseUnroll < ke) dense_load_stage<NJ>(s0, At, X, ccache, k + 4 * kDenseUnroll, kb, half, col);
 #pragma unroll
         for (int q = 0; q < kDenseUnroll; ++q)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1.a[q], s1.b[q][j], acc[j], 0, 0, 0);
     }
     // the four K slices, added in wave order
     float *mine = red + (int64_t)wave * 32 * D;
@@ -124,9 +154,10 @@ int32_t wr_spmm_dense_tiles(const float *A_T, int64_t n_tiles, int64_t K_pad, in
     WR_REQUIRE(A_T && cols && rows, WR_E_NULL, "dense tiles: NULL argument");
     WR_REQUIRE(D == 32 || D == 64 || D == 96 || D == 128, WR_E_SHAPE, "dense tiles: D must be 32, 64, 96 or 128 (got %d)", D);
     WR_REQUIRE(n_tiles > 0 && n_tiles < 65536 && K_pad > 0 && k_per_split > 0 && K_pad % k_per_split == 0 &&
-                   k_per_split % (kDenseWaves * 2 * kDenseUnroll) == 0 && K_pad / k_per_split < 65536,
-               WR_E_SHAPE, "dense tiles: K_pad=%lld must be a multiple of k_per_split=%lld, itself a multiple of %d",
-               (long long)K_pad, (long long)k_per_split, kDenseWaves * 2 * kDenseUnroll);
+                   k_per_split % (kDenseWaves * 2 * kDenseUnroll) == 0 && k_per_split <= kDenseWaves * kDenseMaxKw &&
+                   K_pad / k_per_split < 65536,
+               WR_E_SHAPE, "dense tiles: K_pad=%lld must be a multiple of k_per_split=%lld, itself a multiple of %d and <= %d",
+               (long long)K_pad, (long long)k_per_split, kDenseWaves * 2 * kDenseUnroll, kDenseWaves * kDenseMaxKw);
     WR_REQUIRE(X != Y, WR_E_SHAPE, "spmm: X and Y must not alias");
     const int n_splits = (int)(K_pad / k_per_split);
     WR_REQUIRE(n_splits == 1 || (partials != nullptr && aligned16(partials)), WR_E_NULL, "dense tiles: split K needs partials");
