@@ -389,7 +389,7 @@ int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chu
  * the chunked CSR kernels.  Per 32-row output tile the dense block is stored as A_T[tile][k][32] (value of tile row r and
  * column k at [k][r], zeros included), k = 0..K_pad-1 with cols[k] the node id of column k (padding columns: any valid
  * node, zero values); rows[tile*32 + r] is the node id of tile row r (-1: padding row).  K_pad is cut into splits of
- * k_per_split columns (a multiple of 32), one workgroup each; with one split the tile is written to Y (acc must be NULL:
+ * k_per_split columns (a multiple of 64, at most 1024), one workgroup each; with one split the tile is written to Y (acc must be NULL:
  * such rows also have a CSR part, which adds the layer sum), with several the split tiles go to `partials`
  * (wr_spmm_dense_partials_bytes) and are added in split order, then Y[row] is written and acc[row] += it.  D in
  * {32, 64, 96, 128}.  Summation order differs from CSR order: results agree with wr_spmm_csr to fp32 rounding (1e-6
@@ -397,9 +397,17 @@ int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chu
  * wr_spmm_csr_chunked_modes: the CSR part — row_mode[row] (int8): 0 = write Y[row] (and acc), 1 = ADD to the Y[row] the
  * dense tiles wrote before (then acc), 2 = skip the row (it belongs to the dense tiles). */
 int64_t wr_spmm_dense_partials_bytes(int64_t n_tiles, int64_t K_pad, int64_t k_per_split, int32_t D);
-int32_t wr_spmm_dense_tiles(const float *A_T, int64_t n_tiles, int64_t K_pad, int64_t k_per_split, const int32_t *cols,
-                            const int32_t *rows, const float *X, int64_t n_nodes, int32_t D, float *Y, float *acc,
-                            float *partials, void *stream);
+typedef struct wr_dense_group {
+    const float *A_T;        /* [n_tiles][K_pad][32] */
+    const int32_t *cols;     /* [K_pad] node id of column k */
+    const int32_t *rows;     /* [n_tiles*32] node id of tile row r, -1 = padding */
+    float *partials;         /* >= wr_spmm_dense_partials_bytes(...) when K_pad > k_per_split, else may be NULL */
+    int64_t K_pad, k_per_split, n_tiles;
+} wr_dense_group;
+/* One launch for both tile groups of the hybrid product (either may be NULL): `unsplit` (K_pad == k_per_split: tiles written
+ * straight to Y; acc is NOT touched for them) and `split` (K_pad > k_per_split: split tiles to its partials, then Y and acc). */
+int32_t wr_spmm_dense_tiles(const wr_dense_group *unsplit, const wr_dense_group *split, const float *X, int64_t n_nodes,
+                            int32_t D, float *Y, float *acc, void *stream);
 int32_t wr_spmm_csr_chunked_modes(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
                                   const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
                                   float *partials, const int8_t *row_mode, void *stream);

@@ -83,7 +83,7 @@ SIGNATURES = {
     "wr_spmm_csr": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "wr_spmm_csr_chunked": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "wr_spmm_dense_partials_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i32]),
-    "wr_spmm_dense_tiles": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "wr_spmm_dense_tiles": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "wr_spmm_csr_chunked_modes": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_axpy": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_i32, c_vp]),
     "wr_rank_eval": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -99,6 +99,12 @@ class HotRuns(ctypes.Structure):
                 ("u_piece_q", c_vp), ("u_piece_len", c_vp), ("u_run_q", c_vp), ("u_run_first", c_vp), ("u_run_np", c_vp),
                 ("counts_host", c_vp), ("cap_pieces", c_i64), ("cap_runs", c_i64), ("cap_u_pieces", c_i64),
                 ("cap_u_runs", c_i64)]
+
+
+class DenseGroup(ctypes.Structure):
+    """struct wr_dense_group of include/whisprrec_hip.h"""
+    _fields_ = [("A_T", c_vp), ("cols", c_vp), ("rows", c_vp), ("partials", c_vp), ("K_pad", c_i64), ("k_per_split", c_i64),
+                ("n_tiles", c_i64)]
 
 
 class BucketSide(ctypes.Structure):

@@ -21,7 +21,7 @@ namespace wr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kDenseWaves = kBlock / 64;   // waves per workgroup = K slices per split
-constexpr int kDenseUnroll = 4;            // k-pairs per stage: the loads of a stage are issued together
+constexpr int kDenseUnroll = 8;            // k-pairs per stage: the loads of a stage are issued together
 constexpr int kDenseMaxKw = 256;           // longest K slice of one wave (its column ids are kept in 4 registers)
 
 // One stage = kDenseUnroll k-pairs: per pair one A value and NJ B values per lane.  The column ids of the wave's whole K
@@ -53,14 +53,31 @@ __device__ __forceinline__ void dense_load_stage(DenseStage<NJ> &st, const float
     }
 }
 
+// One launch carries up to two groups of tiles (LightGCN: the user-row tiles, K = head items, one split; and the
+// head-item-row tiles, K = all users, many splits): workgroups [0, g0.n_tiles * g0.n_splits) belong to group 0.
+struct DenseGroup {
+    const float *A_T;
+    const int *cols, *rows;
+    float *partials;
+    int K_pad, k_per_split, n_tiles, n_splits;
+};
+
 template <int NJ>   // D = 32 * NJ
-__global__ __launch_bounds__(kBlock) void spmm_dense_tiles_kernel(const float *__restrict__ A_T, int K_pad, int k_per_split,
-                                                                   const int *__restrict__ cols, const float *__restrict__ X,
-                                                                   const int *__restrict__ rows, float *__restrict__ Y,
-                                                                   float *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void spmm_dense_tiles_kernel(DenseGroup g0, DenseGroup g1, const float *__restrict__ X,
+                                                                   float *__restrict__ Y) {
     constexpr int D = 32 * NJ;
     extern __shared__ float red[];   // [kDenseWaves][32][D]
-    const int tile = blockIdx.x, split = blockIdx.y, n_splits = gridDim.y;
+    const int n0 = g0.n_tiles * g0.n_splits;
+    const bool first = (int)blockIdx.x < n0;
+    const DenseGroup &g = first ? g0 : g1;
+    const int job = first ? (int)blockIdx.x : (int)blockIdx.x - n0;
+    const int n_splits = g.n_splits;
+    const int tile = job / n_splits, split = job - tile * n_splits;
+    const float *__restrict__ A_T = g.A_T;
+    const int *__restrict__ cols = g.cols;
+    const int *__restrict__ rows = g.rows;
+    float *__restrict__ partials = g.partials;
+    const int K_pad = g.K_pad, k_per_split = g.k_per_split;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
     const int kw = k_per_split / kDenseWaves;                 // multiple of 2 * kDenseUnroll, <= kDenseMaxKw (host-checked)
@@ -145,34 +162,51 @@ int64_t wr_spmm_dense_partials_bytes(int64_t n_tiles, int64_t K_pad, int64_t k_p
     return n_splits > 1 ? n_tiles * n_splits * 32 * (int64_t)D * 4 : 0;
 }
 
-int32_t wr_spmm_dense_tiles(const float *A_T, int64_t n_tiles, int64_t K_pad, int64_t k_per_split, const int32_t *cols,
-                            const int32_t *rows, const float *X, int64_t n_nodes, int32_t D, float *Y, float *acc,
-                            float *partials, void *stream_) {
+static int32_t check_group(const wr_dense_group *g, int32_t D, const char *what) {
+    WR_REQUIRE(g->A_T && g->cols && g->rows, WR_E_NULL, "dense tiles (%s): NULL array", what);
+    WR_REQUIRE(g->n_tiles > 0 && g->n_tiles < 65536 && g->K_pad > 0 && g->k_per_split > 0 && g->K_pad % g->k_per_split == 0 &&
+                   g->k_per_split % (kDenseWaves * 2 * kDenseUnroll) == 0 && g->k_per_split <= kDenseWaves * kDenseMaxKw &&
+                   g->K_pad / g->k_per_split < 65536,
+               WR_E_SHAPE, "dense tiles (%s): K_pad=%lld must be a multiple of k_per_split=%lld, itself a multiple of %d and <= %d",
+               what, (long long)g->K_pad, (long long)g->k_per_split, kDenseWaves * 2 * kDenseUnroll, kDenseWaves * kDenseMaxKw);
+    const int64_t n_splits = g->K_pad / g->k_per_split;
+    WR_REQUIRE(n_splits == 1 || (g->partials != nullptr && aligned16(g->partials)), WR_E_NULL,
+               "dense tiles (%s): split K needs partials", what);
+    return WR_OK;
+}
+
+static inline DenseGroup to_dev(const wr_dense_group *g) {
+    if (g == nullptr) return DenseGroup{nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 1};
+    return DenseGroup{g->A_T, g->cols, g->rows, g->partials, (int)g->K_pad, (int)g->k_per_split, (int)g->n_tiles,
+                      (int)(g->K_pad / g->k_per_split)};
+}
+
+int32_t wr_spmm_dense_tiles(const wr_dense_group *unsplit, const wr_dense_group *split, const float *X, int64_t n_nodes,
+                            int32_t D, float *Y, float *acc, void *stream_) {
     int32_t rc;
     if ((rc = check_table(X, n_nodes, D, "X")) != WR_OK) return rc;
     if ((rc = check_table(Y, n_nodes, D, "Y")) != WR_OK) return rc;
-    WR_REQUIRE(A_T && cols && rows, WR_E_NULL, "dense tiles: NULL argument");
+    WR_REQUIRE(unsplit != nullptr || split != nullptr, WR_E_NULL, "dense tiles: no group given");
     WR_REQUIRE(D == 32 || D == 64 || D == 96 || D == 128, WR_E_SHAPE, "dense tiles: D must be 32, 64, 96 or 128 (got %d)", D);
-    WR_REQUIRE(n_tiles > 0 && n_tiles < 65536 && K_pad > 0 && k_per_split > 0 && K_pad % k_per_split == 0 &&
-                   k_per_split % (kDenseWaves * 2 * kDenseUnroll) == 0 && k_per_split <= kDenseWaves * kDenseMaxKw &&
-                   K_pad / k_per_split < 65536,
-               WR_E_SHAPE, "dense tiles: K_pad=%lld must be a multiple of k_per_split=%lld, itself a multiple of %d and <= %d",
-               (long long)K_pad, (long long)k_per_split, kDenseWaves * 2 * kDenseUnroll, kDenseWaves * kDenseMaxKw);
     WR_REQUIRE(X != Y, WR_E_SHAPE, "spmm: X and Y must not alias");
-    const int n_splits = (int)(K_pad / k_per_split);
-    WR_REQUIRE(n_splits == 1 || (partials != nullptr && aligned16(partials)), WR_E_NULL, "dense tiles: split K needs partials");
-    WR_REQUIRE(n_splits > 1 || acc == nullptr, WR_E_SHAPE,
-               "dense tiles: an unsplit launch writes Y only (rows that also have a CSR part get the layer sum there)");
+    if (unsplit != nullptr) {
+        if ((rc = check_group(unsplit, D, "unsplit")) != WR_OK) return rc;
+        WR_REQUIRE(unsplit->K_pad == unsplit->k_per_split, WR_E_SHAPE, "dense tiles: the first group must have one split");
+    }
+    if (split != nullptr) {
+        if ((rc = check_group(split, D, "split")) != WR_OK) return rc;
+        WR_REQUIRE(split->K_pad > split->k_per_split, WR_E_SHAPE, "dense tiles: the second group must have several splits");
+    }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const size_t lds = (size_t)kDenseWaves * 32 * D * 4;
-    const dim3 grid((unsigned)n_tiles, (unsigned)n_splits);
+    const DenseGroup g0 = to_dev(unsplit), g1 = to_dev(split);
+    const dim3 grid((unsigned)(g0.n_tiles * g0.n_splits + g1.n_tiles * g1.n_splits));
 #define WR_DENSE(NJ_)                                                                                                   \
     do {                                                                                                                \
         if (lds > 64 * 1024)                                                                                            \
             WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_dense_tiles_kernel<NJ_>),                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-        hipLaunchKernelGGL((spmm_dense_tiles_kernel<NJ_>), grid, dim3(kBlock), lds, stream, A_T, (int)K_pad,             \
-                           (int)k_per_split, cols, X, rows, Y, partials);                                               \
+        hipLaunchKernelGGL((spmm_dense_tiles_kernel<NJ_>), grid, dim3(kBlock), lds, stream, g0, g1, X, Y);               \
     } while (0)
     if (D == 32) WR_DENSE(1);
     else if (D == 64) WR_DENSE(2);
@@ -180,10 +214,10 @@ int32_t wr_spmm_dense_tiles(const float *A_T, int64_t n_tiles, int64_t K_pad, in
     else WR_DENSE(4);
 #undef WR_DENSE
     WR_LAUNCH_CHECK("spmm_dense_tiles_kernel");
-    if (n_splits > 1) {
-        const int64_t total = n_tiles * 32 * (int64_t)D;
+    if (split != nullptr) {
+        const int64_t total = g1.n_tiles * 32 * (int64_t)D;
         hipLaunchKernelGGL(spmm_dense_combine_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                           partials, (int)n_tiles, n_splits, D, rows, Y, acc);
+                           g1.partials, g1.n_tiles, g1.n_splits, D, g1.rows, Y, acc);
         WR_LAUNCH_CHECK("spmm_dense_combine_kernel");
     }
     return WR_OK;

@@ -1230,7 +1230,7 @@ class HybridSpmm:
     rated by at least `min_density` of the users (at most `max_head`, in tiles of 32).  ``enabled`` is False when the graph
     has no such items — then use spmm_csr_chunked."""
 
-    def __init__(self, row_ptr, col, val, n_users, n_items, device, min_density=0.12, max_head=512, k_split=512):
+    def __init__(self, row_ptr, col, val, n_users, n_items, device, min_density=0.12, max_head=512, k_split=128):
         import numpy as np
         rp, col, val = np.asarray(row_ptr, np.int64), np.asarray(col, np.int64), np.asarray(val, np.float32)
         nU, nI = int(n_users), int(n_items)
@@ -1238,8 +1238,8 @@ class HybridSpmm:
         deg = np.diff(rp)
         order = np.argsort(-deg[nU:], kind="stable")
         n_head = int((deg[nU:] >= min_density * nU).sum())
-        H = min((n_head + 31) // 32 * 32, int(max_head) // 32 * 32, nI // 32 * 32)
-        self.enabled = H >= 32 and n_head >= 16
+        H = min((n_head + 63) // 64 * 64, int(max_head) // 64 * 64, nI // 64 * 64)
+        self.enabled = H >= 64 and n_head >= 16
         self.n_nodes, self.device = N, device
         if not self.enabled:
             return
@@ -1301,12 +1301,12 @@ class HybridSpmm:
             pt = (torch.empty(max(nb // 4, 4), dtype=torch.float32, device=X.device),
                   torch.empty((self.chunk_row.numel(), D), dtype=torch.float32, device=X.device))
             self._partials[D] = pt
-        # user rows: dense part first (Y = block product), the CSR kernels then add the rest and the layer sum
-        abi.check(L.wr_spmm_dense_tiles(_p(self.u_A), self.u_tiles, self.u_K, self.u_K, _p(self.u_cols), _p(self.u_rows), _p(X), N,
-                                        D, _p(Y), None, None, _stream()), "wr_spmm_dense_tiles")
-        # head item rows: complete on the matrix cores (K = all users, split over workgroups)
-        abi.check(L.wr_spmm_dense_tiles(_p(self.i_A), self.i_tiles, self.i_K, self.k_split, _p(self.i_cols), _p(self.i_rows),
-                                        _p(X), N, D, _p(Y), _p(acc), _p(pt[0]), _stream()), "wr_spmm_dense_tiles")
+        # one launch for both tile groups: user rows get their dense part in Y (the CSR kernels then add the rest and the
+        # layer sum); head item rows are complete on the matrix cores (K = all users, split over workgroups)
+        g0 = abi.DenseGroup(_p(self.u_A), _p(self.u_cols), _p(self.u_rows), None, self.u_K, self.u_K, self.u_tiles)
+        g1 = abi.DenseGroup(_p(self.i_A), _p(self.i_cols), _p(self.i_rows), _p(pt[0]), self.i_K, self.k_split, self.i_tiles)
+        abi.check(L.wr_spmm_dense_tiles(ctypes.addressof(g0), ctypes.addressof(g1), _p(X), N, D, _p(Y), _p(acc), _stream()),
+                  "wr_spmm_dense_tiles")
         abi.check(L.wr_spmm_csr_chunked_modes(N, self.chunk_row.numel(), _p(self.chunk_ptr), _p(self.chunk_row), _p(self.col),
                                               _p(self.val), _p(X), D, _p(Y), _p(acc), _p(pt[1]), _p(self.row_mode), _stream()),
                   "wr_spmm_csr_chunked_modes")
