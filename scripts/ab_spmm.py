@@ -44,6 +44,12 @@ def err(y):
 out = {"graph": {"users": nU, "items": nI, "nnz": int(rp[-1]), "D": D}}
 f_csr = lambda: hip_ops.spmm_csr_chunked(cptr, crow, cold, vald, Xd, Y=Y, acc=acc, partials=partials)
 out["csr_chunked"] = {"us": timeit(f_csr), "err": err(Y), "flops": 2.0 * rp[-1] * D}
+for mx in (64, 128):
+    cp2, cr2 = hip_ops.spmm_chunks(rp, max_nnz=mx)
+    cp2, cr2 = cp2.to(dev), cr2.to(dev)
+    pt2 = torch.empty((cr2.numel(), D), device=dev)
+    f2 = lambda: hip_ops.spmm_csr_chunked(cp2, cr2, cold, vald, Xd, Y=Y, acc=acc, partials=pt2)
+    out["csr_chunked_%d" % mx] = {"us": timeit(f2), "err": err(Y), "chunks": int(cr2.numel())}
 for md in [float(x) for x in os.environ.get("WR_DENS", "0.25,0.18,0.12,0.08,0.05").split(",")]:
     hy = hip_ops.HybridSpmm(rp, col, val, nU, nI, dev, min_density=md, max_head=1024)
     if not hy.enabled:

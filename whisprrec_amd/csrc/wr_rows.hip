@@ -223,6 +223,13 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(int64_t n_rows, const 
 // on the host).  One team per chunk, four neighbour rows requested per round.  A row with a single chunk is written
 // directly; the chunks of a longer row go to `partials` and are summed in chunk order by the second kernel, so the
 // result is reproducible and a power-law hub (thousands of neighbours) no longer serialises on one team.
+#ifndef WR_SPMM_FLY
+#define WR_SPMM_FLY 8
+#endif
+// neighbour rows requested per round and team.  The kernel is bound by its chain of dependent L2 round trips (index trip,
+// then one trip per round), not by L2 bandwidth: A/B on the ml-1m-shaped graph (scripts/ab_spmm.py), 4 -> 8 per round.
+constexpr int kSpmmFly = (WR_SPMM_FLY);
+
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const int64_t *__restrict__ chunk_ptr,
                                                              const int *__restrict__ chunk_row, const int *__restrict__ col,
@@ -251,12 +258,12 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
         const int cnt = (int)((k1 - base < 2 * T) ? (k1 - base) : 2 * T);
         const int c_lo = (lane < cnt) ? col[base + lane] : 0, c_hi = (lane + T < cnt) ? col[base + T + lane] : 0;
         const float a_lo = (lane < cnt) ? val[base + lane] : 0.f, a_hi = (lane + T < cnt) ? val[base + T + lane] : 0.f;
-        for (int j = 0; j < cnt; j += 4) {
-            int cj[4];
-            float aj[4];
-            Row<NV> x[4];
+        for (int j = 0; j < cnt; j += kSpmmFly) {
+            int cj[kSpmmFly];
+            float aj[kSpmmFly];
+            Row<NV> x[kSpmmFly];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {   // entries past the chunk get value 0 and row 0: they add +0 in order
+            for (int f = 0; f < kSpmmFly; ++f) {   // entries past the chunk get value 0 and row 0: they add +0 in order
                 const int e = j + f;
                 const int src_lane = e < T ? e : e - T;
                 const int cl = __shfl(c_lo, src_lane, T), ch = __shfl(c_hi, src_lane, T);
@@ -266,10 +273,10 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
                 if (e >= cnt) cj[f] = -1;
             }
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < kSpmmFly; ++f)
                 if (cj[f] >= 0) x[f] = load_row<T, NV, FULL>(X, cj[f], D, lane);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < kSpmmFly; ++f) {
                 if (cj[f] < 0) continue;
 #pragma unroll
                 for (int q = 0; q < NV; ++q) {

@@ -144,8 +144,17 @@ __global__ __launch_bounds__(kBlock) void spmm_dense_combine_kernel(const float 
     const int r = (int)(in / D), d = (int)(in - (int64_t)r * D);
     const int node = rows[tile * 32 + r];
     if (node < 0) return;
-    float s = partials[((int64_t)tile * n_splits) * per_tile + in];
-    for (int sp = 1; sp < n_splits; ++sp) s += partials[((int64_t)tile * n_splits + sp) * per_tile + in];
+    // eight split tiles requested per trip, added in split order
+    const float *p0 = partials + ((int64_t)tile * n_splits) * per_tile + in;
+    float s = 0.f;
+    for (int sp = 0; sp < n_splits; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) v[f] = sp + f < n_splits ? p0[(int64_t)(sp + f) * per_tile] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+            if (sp + f < n_splits) s += v[f];
+    }
     Y[(int64_t)node * D + d] = s;
     if (acc != nullptr) acc[(int64_t)node * D + d] += s;
 }
