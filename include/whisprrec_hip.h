@@ -316,6 +316,25 @@ int32_t wr_bprmf_step_adam(float *user_tab, int64_t n_users, float *item_tab, in
                            const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src, int64_t B,
                            int64_t adam_step, float lr, float l2, float beta1, float beta2, float eps, float *loss_out,
                            const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes, void *stream);
+/* The same step with the catch-up FOLDED into the row loads: rows need NOT be up to date — every team that loads a row
+ * replays the missed zero-gradient steps last[row]+1 .. adam_step-1 on its register copy (consts: the table of
+ * wr_adam_consts, entries 0..adam_step), the finisher applies step adam_step and writes weights and moments once: 3 row
+ * reads + 3 row writes per touched row instead of the 12 transfers of wr_adam_rows_lazy + wr_bprmf_step_adam.  Same bits
+ * as the dense optimizer.  Batches with hot rows are refused (WR_E_RANGE): use the separate catch-up for those. */
+int32_t wr_bprmf_step_adam_folded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
+                                  float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
+                                  const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
+                                  int64_t B, int64_t adam_step, float lr, const float *consts, int64_t n_consts, float l2,
+                                  float beta1, float beta2, float eps, float *loss_out, void *workspace,
+                                  int64_t workspace_bytes, void *stream);
+/* wr_bprmf_run_adam_lazy with wr_bprmf_step_adam_folded for every batch without hot rows (same arguments, same results) */
+int32_t wr_bprmf_run_adam_folded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
+                                 float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
+                                 const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
+                                 int64_t n_triplets, int64_t batch_size, int64_t first_batch, int64_t n_batches,
+                                 int64_t adam_step0, float lr, const float *consts, int64_t n_consts, float l2, float beta1,
+                                 float beta2, float eps, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                                 int64_t workspace_bytes, void *stream);
 /* n_batches consecutive optimizer steps over batches [first_batch, first_batch + n_batches) of a plan, issued from native
  * code (the inner loop of BaseRunner.fit, BaseRunner.py:196-199, with the lazy optimizers): per batch
  *   Adam:  wr_adam_rows_lazy(NULL) on U and I rows -> wr_bprmf_step_adam (gradients + Adam on the rows it finishes);

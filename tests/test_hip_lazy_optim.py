@@ -27,9 +27,12 @@ def _setup(nU, nI, D, B, steps, seed, zipf=False):
     return hip_ops, U, I, plan
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("l2", [0.0, 1e-3])
-@pytest.mark.parametrize("D,zipf", [(64, False), (32, True), (128, False), (20, False)])
-def test_lazy_adam_bit_identical_to_dense(l2, D, zipf):
+@pytest.mark.parametrize("D,zipf", [(64, False), (32, True), (128, False), (20, False), (32, False)])
+def test_lazy_adam_bit_identical_to_dense(l2, D, zipf, fold):
+    """fold=True: the catch-up happens inside the step kernels' row loads (wr_bprmf_step_adam_folded); fold=False: in a pass
+    of its own (wr_adam_rows_lazy) before wr_bprmf_step_adam.  Both must leave the dense optimizer's bits."""
     nU, nI, B, steps, lr = 3000, 2500, 256, 24, 1e-2
     hip_ops, U, I, plan = _setup(nU, nI, D, B, steps, 7 + D, zipf)
     # dense (what FusedOptimizer did before)
@@ -46,7 +49,7 @@ def test_lazy_adam_bit_identical_to_dense(l2, D, zipf):
     # lazy
     Ul, Il = U.clone(), I.clone()
     tl = hip_ops.BprmfTables(Ul, Il)
-    st = hip_ops.LazyOptimizerState(tl, "Adam", lr, l2)
+    st = hip_ops.LazyOptimizerState(tl, "Adam", lr, l2, fold=fold)
     lazy_loss = []
     for k in range(steps):
         lazy_loss.append(st.step(plan, k).clone())
@@ -88,7 +91,7 @@ def test_lazy_adam_consts_table_grows():
     assert st.n_consts == 2 * n0 and torch.isfinite(U).all()
 
 
-@pytest.mark.parametrize("name,l2,zipf", [("Adam", 0.0, False), ("Adam", 1e-3, True), ("SGD", 1e-2, True)])
+@pytest.mark.parametrize("name,l2,zipf", [("Adam", 0.0, False), ("Adam", 1e-3, True), ("Adam", 1e-3, False), ("SGD", 1e-2, True)])
 def test_native_multi_batch_loop_equals_per_batch_calls(name, l2, zipf):
     """wr_bprmf_run_adam_lazy / wr_bprmf_run_sgd_lazy: same bits as calling step() batch by batch (short last batch, hot rows)"""
     nU, nI, D, B, steps, lr = 3000, 2500, 64, 256, 9, 1e-2
@@ -104,9 +107,9 @@ def test_native_multi_batch_loop_equals_per_batch_calls(name, l2, zipf):
     t = lambda a: torch.from_numpy(a).to(dev)
     plan = hip_ops.BatchPlan(t(u), t(p), t(n), B, nU, nI)
     outs = []
-    for native in (False, True):
+    for native in (False, True, "unfolded"):
         Ua, Ia = U.clone(), I.clone()
-        st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ua, Ia), name, lr, l2)
+        st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ua, Ia), name, lr, l2, fold=native != "unfolded")
         if native:
             l1 = st.run(plan, 0, 4); l2_ = st.run(plan, 4, steps - 4)
             losses = torch.cat([l1, l2_])
@@ -114,4 +117,5 @@ def test_native_multi_batch_loop_equals_per_batch_calls(name, l2, zipf):
             losses = torch.stack([st.step(plan, k).clone() for k in range(steps)])
         st.flush()
         outs.append((losses, Ua, Ia))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])

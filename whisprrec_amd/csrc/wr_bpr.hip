@@ -80,7 +80,73 @@ struct AdamArgs {
     int *lastU, *lastI;
     float step_size, inv_bc2_sqrt, b1, b2, eps, l2;
     int t;
+    const float *consts;   // MODE 4: per-step (step_size, 1/sqrt(bias_correction2)) of steps 0..t (wr_adam_consts)
 };
+
+// The moments a team keeps beside a weight row in MODE 4 (empty otherwise: no registers).
+template <int NV, bool ON>
+struct Moments {
+    Row<NV> m, v;
+};
+template <int NV>
+struct Moments<NV, false> {};
+
+// MODE 4 — Adam with the catch-up folded into the row loads.  Rows are stored at the optimizer step last[row]; the team
+// that loads a row replays the missed zero-gradient steps last[row]+1 .. t-1 on its register copy (adam_elem: the bits of the
+// dense optimizer and of wr_adam_rows_lazy) before it uses the weights, and whoever finishes the row applies step t to that
+// copy and writes weights and moments back once: 3 row reads + 3 row writes per touched row and step, where a separate
+// catch-up pass (wr_adam_rows_lazy, then MODE 3) moves twice that.  A row with several occurrences in the batch is replayed
+// by each of its readers (ALU only) and once more by its finisher in the item phase.
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ void adam_load_caught_up(const float *__restrict__ W, const float *__restrict__ M,
+                                                    const float *__restrict__ V, const int *__restrict__ last, int row, int D,
+                                                    int lane, const AdamArgs &a, Row<NV> &w, Row<NV> &m, Row<NV> &v) {
+    const int from = last[row];
+    w = load_row<T, NV, FULL>(W, row, D, lane);
+    m = load_row<T, NV, FULL>(M, row, D, lane);
+    v = load_row<T, NV, FULL>(V, row, D, lane);
+    const float2 *__restrict__ c2 = reinterpret_cast<const float2 *>(a.consts);
+    auto replay = [&](float2 k) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if (a.l2 != 0.f) {
+                adam_elem<true>(w.v[q].x, m.v[q].x, v.v[q].x, 0.f, a.l2, a.b1, a.b2, a.eps, k.x, k.y);
+                adam_elem<true>(w.v[q].y, m.v[q].y, v.v[q].y, 0.f, a.l2, a.b1, a.b2, a.eps, k.x, k.y);
+                adam_elem<true>(w.v[q].z, m.v[q].z, v.v[q].z, 0.f, a.l2, a.b1, a.b2, a.eps, k.x, k.y);
+                adam_elem<true>(w.v[q].w, m.v[q].w, v.v[q].w, 0.f, a.l2, a.b1, a.b2, a.eps, k.x, k.y);
+            } else {
+                adam_elem_zero_grad(w.v[q].x, m.v[q].x, v.v[q].x, a.b1, a.b2, a.eps, k.x, k.y);
+                adam_elem_zero_grad(w.v[q].y, m.v[q].y, v.v[q].y, a.b1, a.b2, a.eps, k.x, k.y);
+                adam_elem_zero_grad(w.v[q].z, m.v[q].z, v.v[q].z, a.b1, a.b2, a.eps, k.x, k.y);
+                adam_elem_zero_grad(w.v[q].w, m.v[q].w, v.v[q].w, a.b1, a.b2, a.eps, k.x, k.y);
+            }
+        }
+    };
+    int s = from + 1;
+    for (; s + 3 < a.t; s += 4) {   // four steps per trip: their constants are fetched together
+        const float2 k0 = c2[s], k1 = c2[s + 1], k2 = c2[s + 2], k3 = c2[s + 3];
+        replay(k0); replay(k1); replay(k2); replay(k3);
+    }
+    for (; s < a.t; ++s) replay(c2[s]);
+}
+
+// step t on a row whose caught-up weights and moments are in registers
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ void adam_finish_row_regs(float *__restrict__ W, float *__restrict__ M, float *__restrict__ V,
+                                                     int *__restrict__ last, int row, int D, int lane, Row<NV> w, Row<NV> m,
+                                                     Row<NV> v, const Row<NV> &g, const AdamArgs &a) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        adam_elem(w.v[k].x, m.v[k].x, v.v[k].x, g.v[k].x, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+        adam_elem(w.v[k].y, m.v[k].y, v.v[k].y, g.v[k].y, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+        adam_elem(w.v[k].z, m.v[k].z, v.v[k].z, g.v[k].z, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+        adam_elem(w.v[k].w, m.v[k].w, v.v[k].w, g.v[k].w, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
+    }
+    store_row<T, NV, FULL>(W, row, D, lane, w);
+    store_row<T, NV, FULL>(M, row, D, lane, m);
+    store_row<T, NV, FULL>(V, row, D, lane, v);
+    if (lane == 0) last[row] = a.t;
+}
 
 template <int T, int NV, bool FULL>
 __device__ __forceinline__ void adam_finish_row(float *__restrict__ W, float *__restrict__ M, float *__restrict__ V,
@@ -110,7 +176,9 @@ template <int T, int NV, bool FULL, int MODE>
 __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &pr, const Row<NV> &nr, int praw, int nraw, int t,
                                              float *I, float *__restrict__ gradI, float *__restrict__ Z,
                                              int *__restrict__ stampI, int step_id, int D, int lane, float lr, float l2,
-                                             float denom, Row<NV> &g, float &terms, const AdamArgs &ad) {
+                                             float denom, Row<NV> &g, float &terms, const AdamArgs &ad,
+                                             const Moments<NV, MODE == 4> &pmv = Moments<NV, MODE == 4>{},
+                                             const Moments<NV, MODE == 4> &nmv = Moments<NV, MODE == 4>{}) {
     const int p = praw & 0x7fffffff, n = nraw & 0x7fffffff;
     const bool p_shared = praw < 0, n_shared = nraw < 0;   // bit 31: the item row has other occurrences in this batch
     const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
@@ -129,6 +197,17 @@ __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &p
     }
     // An item row that occurs once in the batch is read by this team only: finish it here
     // (gradient = +z for the positive, -z for the negative), no stash, no item-phase work.
+    if constexpr (MODE == 4) {
+        if (!p_shared) adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, p, D, lane, pr, pmv.m, pmv.v, z, ad);
+        if (!n_shared) {
+            Row<NV> zn;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) zn.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
+            adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, n, D, lane, nr, nmv.m, nmv.v, zn, ad);
+        }
+        if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
+        return;
+    }
     if (MODE == 3) {
         if (!p_shared) adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, p, D, lane, pr, z, ad);
         if (!n_shared) {
@@ -266,12 +345,21 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
         }
     }
     Row<NV> ur[SLOTS], pr0[SLOTS], nr0[SLOTS];
+    Moments<NV, MODE == 4> umv[SLOTS], pmv0[SLOTS], nmv0[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         if (head[s]) {
-            ur[s] = load_row<T, NV, FULL>(U, uu[s], D, lane);
-            pr0[s] = load_row<T, NV, FULL>(I, praw0[s] & 0x7fffffff, D, lane);
-            nr0[s] = load_row<T, NV, FULL>(I, nraw0[s] & 0x7fffffff, D, lane);
+            if constexpr (MODE == 4) {
+                adam_load_caught_up<T, NV, FULL>(U, ad.mU, ad.vU, ad.lastU, uu[s], D, lane, ad, ur[s], umv[s].m, umv[s].v);
+                adam_load_caught_up<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, praw0[s] & 0x7fffffff, D, lane, ad, pr0[s],
+                                                 pmv0[s].m, pmv0[s].v);
+                adam_load_caught_up<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, nraw0[s] & 0x7fffffff, D, lane, ad, nr0[s],
+                                                 nmv0[s].m, nmv0[s].v);
+            } else {
+                ur[s] = load_row<T, NV, FULL>(U, uu[s], D, lane);
+                pr0[s] = load_row<T, NV, FULL>(I, praw0[s] & 0x7fffffff, D, lane);
+                nr0[s] = load_row<T, NV, FULL>(I, nraw0[s] & 0x7fffffff, D, lane);
+            }
         }
     }
 #pragma unroll
@@ -284,19 +372,28 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
         int t = t0[s];
         int praw = praw0[s], nraw = nraw0[s];
         Row<NV> pr = pr0[s], nr = nr0[s];
+        Moments<NV, MODE == 4> pmv = pmv0[s], nmv = nmv0[s];
         bool more = unext[s] == u;   // known before the first body: the single-triplet user's row store waits on nothing
         for (;;) {
             triplet_body<T, NV, FULL, MODE>(ur[s], pr, nr, praw, nraw, t, I, gradI, Z, stampI, step_id, D, lane, lr, l2, denom, g,
-                                            term_acc, ad);
+                                            term_acc, ad, pmv, nmv);
             if (!more) break;
             ++t;   // next triplet of this user (nothing is kept live across the body: 8 waves per SIMD, no spill)
             praw = tp[t];
             nraw = tn[t];
             more = (t + 1 < B) && (tu[t + 1] == u);
-            pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
-            nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
+            if constexpr (MODE == 4) {
+                adam_load_caught_up<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, praw & 0x7fffffff, D, lane, ad, pr, pmv.m, pmv.v);
+                adam_load_caught_up<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, nraw & 0x7fffffff, D, lane, ad, nr, nmv.m, nmv.v);
+            } else {
+                pr = load_row<T, NV, FULL>(I, praw & 0x7fffffff, D, lane);
+                nr = load_row<T, NV, FULL>(I, nraw & 0x7fffffff, D, lane);
+            }
         }
-        finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur[s], g, ad);
+        if constexpr (MODE == 4)
+            adam_finish_row_regs<T, NV, FULL>(U, ad.mU, ad.vU, ad.lastU, u, D, lane, ur[s], umv[s].m, umv[s].v, g, ad);
+        else
+            finish_user_row<T, NV, FULL, MODE>(U, gradU, stampU, step_id, u, D, lane, lr, l2, ur[s], g, ad);
     }
     if (lane != 0) term_acc = 0.f;  // every lane of a team holds the same terms: count them once
     const float sum = block_sum(term_acc, scratch);
@@ -508,7 +605,10 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
         const int j0 = heads[h];
         const int r = item_tile[j0];
         {
-            const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
+            Row<NV> ir;
+            Moments<NV, MODE == 4> imv;
+            if constexpr (MODE == 4) adam_load_caught_up<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ad, ir, imv.m, imv.v);
+            else ir = load_row<T, NV, FULL>(I, r, D, lane);
             const int s0 = src_tile[j0], s1 = src_tile[j0 + 1];
             const Row<NV> z0 = load_row<T, NV, FULL>(Z, s0 >> 1, D, lane);
             const Row<NV> z1 = load_row<T, NV, FULL>(Z, s1 >> 1, D, lane);
@@ -549,7 +649,10 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                         }
                     }
                 }
-                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
+                if constexpr (MODE == 4)
+                    adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
+                else
+                    finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             } else {
                 // no hot-run list for this batch (none, or a plan built without one): walk the run to its end, whatever
                 // its length — from LDS inside the staged window, from the plan arrays beyond it.  One stashed row at a
@@ -583,7 +686,10 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                     }
                     ++j;
                 }
-                finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
+                if constexpr (MODE == 4)
+                    adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
+                else
+                    finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             }
         }
     }
@@ -722,6 +828,8 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     const dim3 block(kBlock);
     const bool have_hot = hot.item.n_runs > 0 && hot.item.n_pieces > 0;
     const bool have_hot_u = hot.user.n_runs > 0 && hot.user.n_pieces > 0;
+    WR_REQUIRE(MODE != 4 || (!have_hot && !have_hot_u), WR_E_RANGE,
+               "the folded Adam step does not take batches with hot rows (use the catch-up pass + wr_bprmf_step_adam)");
     WR_REQUIRE(hot.item.n_pieces <= hot_cap_pieces(ws_batch, 0) && hot.item.n_runs <= hot_cap_runs(ws_batch, 0) &&
                    hot.user.n_pieces <= hot_cap_pieces(ws_batch, 1) && hot.user.n_runs <= hot_cap_runs(ws_batch, 1),
                WR_E_RANGE, "hot-run counts exceed their capacity");
@@ -1016,10 +1124,35 @@ int32_t wr_bprmf_step_adam(float *user_tab, int64_t n_users, float *item_tab, in
     WR_REQUIRE(adam_step >= 1 && adam_step < INT32_MAX, WR_E_RANGE, "adam_step must be >= 1");
     WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
                "wr_bprmf_step_adam: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
-    AdamArgs ad{m_u, v_u, m_i, v_i, last_u, last_i, 0.f, 0.f, beta1, beta2, eps, l2, (int)adam_step};
+    AdamArgs ad{m_u, v_u, m_i, v_i, last_u, last_i, 0.f, 0.f, beta1, beta2, eps, l2, (int)adam_step, nullptr};
     adam_step_consts(adam_step, lr, beta1, beta2, &ad.step_size, &ad.inv_bc2_sqrt);
     return launch_step<3>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, B, lr, l2, nullptr, nullptr, nullptr, nullptr, 0,
                           loss_out, workspace, reinterpret_cast<hipStream_t>(stream_), nullptr, 0.f, hot_of(hot, 0), 0, ad);
+}
+
+int32_t wr_bprmf_step_adam_folded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
+                                  float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
+                                  const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
+                                  int64_t B, int64_t adam_step, float lr, const float *consts, int64_t n_consts, float l2,
+                                  float beta1, float beta2, float eps, float *loss_out, void *workspace,
+                                  int64_t workspace_bytes, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_table(m_u, n_users, D, "m_u")) != WR_OK) return rc;
+    if ((rc = check_table(v_u, n_users, D, "v_u")) != WR_OK) return rc;
+    if ((rc = check_table(m_i, n_items, D, "m_i")) != WR_OK) return rc;
+    if ((rc = check_table(v_i, n_items, D, "v_i")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, B)) != WR_OK) return rc;
+    WR_REQUIRE(last_u != nullptr && last_i != nullptr && consts != nullptr, WR_E_NULL, "last_u / last_i / consts is NULL");
+    WR_REQUIRE(adam_step >= 1 && adam_step < n_consts && adam_step < INT32_MAX, WR_E_RANGE,
+               "adam_step %lld outside the consts table (%lld entries)", (long long)adam_step, (long long)n_consts);
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
+               "wr_bprmf_step_adam_folded: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
+    AdamArgs ad{m_u, v_u, m_i, v_i, last_u, last_i, 0.f, 0.f, beta1, beta2, eps, l2, (int)adam_step, consts};
+    adam_step_consts(adam_step, lr, beta1, beta2, &ad.step_size, &ad.inv_bc2_sqrt);   // = consts[2t], consts[2t+1]
+    return launch_step<4>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, B, lr, l2, nullptr, nullptr, nullptr, nullptr, 0,
+                          loss_out, workspace, reinterpret_cast<hipStream_t>(stream_), nullptr, 0.f, hot_of(nullptr, 0), 0, ad);
 }
 
 int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,

@@ -315,6 +315,51 @@ int32_t wr_bprmf_run_adam_lazy(float *user_tab, int64_t n_users, float *item_tab
     return WR_OK;
 }
 
+// The same loop with the catch-up FOLDED into the step kernels' row loads (wr_bprmf_step_adam_folded, MODE 4 of wr_bpr.hip):
+// one launch pair per step and 6 instead of 12 row transfers per touched row.  A batch with hot rows (its pieces / combine
+// kernels read rows outside the two step kernels) takes the separate catch-up pass, as above.
+int32_t wr_bprmf_run_adam_folded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, float *m_u,
+                                 float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i, const int32_t *tu,
+                                 const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
+                                 int64_t n_triplets, int64_t batch_size, int64_t first_batch, int64_t n_batches,
+                                 int64_t adam_step0, float lr, const float *consts, int64_t n_consts, float l2, float beta1,
+                                 float beta2, float eps, float *loss_out, const wr_hot_runs *hot, void *workspace,
+                                 int64_t workspace_bytes, void *stream) {
+    WR_REQUIRE(n_triplets > 0 && batch_size > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(adam_step0 >= 1 && adam_step0 + n_batches <= n_consts, WR_E_RANGE,
+               "adam steps [%lld,%lld) outside the consts table (%lld entries)", (long long)adam_step0,
+               (long long)(adam_step0 + n_batches), (long long)n_consts);
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t b = first_batch + k, off = b * batch_size;
+        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
+        const int64_t t = adam_step0 + k;
+        int32_t rc;
+        const bool any_hot = hot != nullptr && hot->counts_host != nullptr &&
+                             (hot->counts_host[4 * b] | hot->counts_host[4 * b + 1] | hot->counts_host[4 * b + 2] |
+                              hot->counts_host[4 * b + 3]) != 0;
+        if (!any_hot) {
+            if ((rc = wr_bprmf_step_adam_folded(user_tab, n_users, item_tab, n_items, D, m_u, v_u, m_i, v_i, last_u, last_i,
+                                                tu + off, tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk, t, lr,
+                                                consts, n_consts, l2, beta1, beta2, eps, loss_out ? loss_out + k : nullptr,
+                                                workspace, workspace_bytes, stream)) != WR_OK) return rc;
+            continue;
+        }
+        wr_hot_runs hb = hot_at_batch(hot, b);
+        if ((rc = wr_adam_rows_lazy(user_tab, m_u, v_u, last_u, n_users, D, tu + off, Bk, nullptr, t, consts, n_consts, l2, beta1,
+                                    beta2, eps, stream)) != WR_OK) return rc;
+        if ((rc = wr_adam_rows_lazy(item_tab, m_i, v_i, last_i, n_items, D, oc_item + 2 * off, 2 * Bk, nullptr, t, consts,
+                                    n_consts, l2, beta1, beta2, eps, stream)) != WR_OK) return rc;
+        if ((rc = wr_bprmf_step_adam(user_tab, n_users, item_tab, n_items, D, m_u, v_u, m_i, v_i, last_u, last_i, tu + off,
+                                     tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk, t, lr, l2, beta1, beta2, eps,
+                                     loss_out ? loss_out + k : nullptr, &hb, workspace, workspace_bytes, stream)) != WR_OK)
+            return rc;
+    }
+    return WR_OK;
+}
+
 int32_t wr_bprmf_run_sgd_lazy(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D, int32_t *last_u,
                               int32_t *last_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0, const int32_t *tu,
                               const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src,
