@@ -1030,13 +1030,19 @@ class LazyOptimizerState:
     needs them and all together in ``flush()`` — call it before anything else reads the tables.  Bit-identical to the
     dense kernels (wr_adam_dense / wr_sgd_dense), without their table passes."""
 
-    def __init__(self, tabs, name, lr, l2, betas=(0.9, 0.999), eps=1e-8, fold=True):
+    FOLD_MAX_GAP = 64      # fold the catch-up into the step kernels while a row misses about this many steps between two uses
+
+    def __init__(self, tabs, name, lr, l2, betas=(0.9, 0.999), eps=1e-8, fold=None):
         """fold (Adam): the catch-up of a batch's rows happens inside the step kernels' row loads (wr_bprmf_step_adam_folded:
-        6 instead of 12 row transfers per touched row) instead of in a pass of its own; same bits either way."""
+        6 instead of 12 row transfers per touched row) instead of in a pass of its own; same bits either way.  The folded
+        replay runs on 16-lane teams whose rows miss different numbers of steps (divergence) and repeats for every reader of a
+        shared row, so it pays while replays are short: None (default) = fold when a row misses about FOLD_MAX_GAP steps or
+        fewer between two batches that contain it (rows / batch size).  MI355X, 1M x 1M x 64: B = 65,536 (gap ~16) 165 ->
+        142 us/step folded; B = 2,048 (gap ~490) 56 us separate against 194 folded (scripts/ab_adam.py)."""
         if name not in ("SGD", "Adam"):
             raise ValueError(name)
         self.tabs, self.name, self.lr, self.l2, self.betas, self.eps = tabs, name, float(lr), float(l2), betas, float(eps)
-        self.fold = bool(fold)
+        self.fold = fold if fold is None else bool(fold)
         dev = tabs.dev
         self.t = 0                                                       # optimizer steps taken
         self.flushed_at = 0
@@ -1047,6 +1053,12 @@ class LazyOptimizerState:
             self.m_u, self.v_u, self.m_i, self.v_i = z(tabs.U), z(tabs.U), z(tabs.I), z(tabs.I)
             self.consts = None
             self._grow_consts(4096)
+
+    def _folds(self, plan):
+        if self.fold is None:
+            gap = max(self.tabs.U.shape[0], self.tabs.I.shape[0]) / float(max(plan.batch_size, 1))
+            return gap <= self.FOLD_MAX_GAP
+        return self.fold
 
     def _grow_consts(self, n):
         host = torch.empty(2 * n, dtype=torch.float32)
@@ -1067,7 +1079,7 @@ class LazyOptimizerState:
         if self.name == "Adam":
             if self.t >= self.n_consts:
                 self._grow_consts(2 * self.n_consts)
-            if self.fold and plan.hot_struct(k) is None:
+            if self._folds(plan) and plan.hot_struct(k) is None:
                 if loss_out is None:
                     loss_out = torch.empty((), dtype=torch.float32, device=tabs.dev)
                 _, tp, tn, _, os_, _ = tabs._plan_ptrs(plan, k)
@@ -1114,7 +1126,7 @@ class LazyOptimizerState:
         if self.name == "Adam":
             while self.t + count >= self.n_consts:
                 self._grow_consts(2 * self.n_consts)
-            fn = L.wr_bprmf_run_adam_folded if self.fold else L.wr_bprmf_run_adam_lazy
+            fn = L.wr_bprmf_run_adam_folded if self._folds(plan) else L.wr_bprmf_run_adam_lazy
             abi.check(fn(
                 _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.m_u), _p(self.v_u), _p(self.m_i),
                 _p(self.v_i), _p(self.last_u), _p(self.last_i),
