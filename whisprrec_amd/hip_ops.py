@@ -1030,7 +1030,7 @@ class LazyOptimizerState:
     needs them and all together in ``flush()`` — call it before anything else reads the tables.  Bit-identical to the
     dense kernels (wr_adam_dense / wr_sgd_dense), without their table passes."""
 
-    FOLD_MAX_GAP = 64      # fold the catch-up into the step kernels while a row misses about this many steps between two uses
+    FOLD_MAX_GAP = 24      # fold the catch-up into the step kernels while a row misses about this many steps between two uses
 
     def __init__(self, tabs, name, lr, l2, betas=(0.9, 0.999), eps=1e-8, fold=None):
         """fold (Adam): the catch-up of a batch's rows happens inside the step kernels' row loads (wr_bprmf_step_adam_folded:
