@@ -37,7 +37,14 @@ def _worker(rank, world, port, payload, out_dir):
         m = RotatingBprmf(nU, nI, D, torch.device("cpu"), parts=parts, local=OracleLocal())
         m.load_full(torch.from_numpy(payload["U"]), torch.from_numpy(payload["I"]))
         T = torch.from_numpy
-        if payload["whole_epoch"]:                                  # all strata in one call: plans pipelined across rotations
+        if payload["whole_epoch"] == "deferred":                    # one call per stratum, last hand-over left to the next call
+            losses = []
+            for r in range(world):
+                u, p, n, per_part = payload["strata"][rank][r]
+                losses.append(m.run_strata([(T(u), T(p), T(n), per_part)], B, lr, defer_last=True))
+                assert m._deferred == parts - 1 and m.held == (rank + r) % world     # the rotation is still open
+            m.complete_rotation()
+        elif payload["whole_epoch"]:                                # all strata in one call: plans pipelined across rotations
             losses = [m.run_strata([(T(u), T(p), T(n), pp) for (u, p, n, pp) in payload["strata"][rank]], B, lr)]
         else:
             losses = []
@@ -59,7 +66,8 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world,nI,parts,whole", [(2, 61, 2, False), (3, 100, 2, True), (2, 40, 1, True), (3, 37, 3, False)])
+@pytest.mark.parametrize("world,nI,parts,whole", [(2, 61, 2, False), (3, 100, 2, True), (2, 40, 1, True), (3, 37, 3, False),
+                                                  (2, 61, 2, "deferred"), (3, 50, 1, "deferred")])
 def test_rotating_epoch_equals_single_process(tmp_path, world, nI, parts, whole):
     from whisprrec_amd.sharded import n_local_rows
     rng = np.random.RandomState(world * 10 + parts)

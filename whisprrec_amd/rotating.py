@@ -82,6 +82,7 @@ class RotatingBprmf:
         self.comm_stream = side_stream(device) if device.type == "cuda" else None
         self._incoming = {}      # part -> event: that part of the NEXT block has landed in I_in
         self._ready = {}         # part -> event still to be waited for before the held block's part is touched
+        self._deferred = None    # part of the held block whose hand-over was left to the next call (run_strata defer_last)
 
     # ------------------------------------------------------------------ layout helpers
     def block_rows(self, block):
@@ -106,6 +107,8 @@ class RotatingBprmf:
 
     def gather_full(self):
         """Re-assemble the reference's checkpoint layout (user table, item table) on every rank."""
+        self.complete_rotation()
+        self._drain()
         G, D = self.world, self.D
         capu = (self.n_users + G - 1) // G
         pu = torch.zeros(capu, D, device=self.device)
@@ -174,12 +177,24 @@ class RotatingBprmf:
         steps_per_part.  Returns the per-step local losses (mean over ranks = loss of the global batch)."""
         return self.run_strata([(u, p, n, steps_per_part)], batch, lr)
 
-    def run_strata(self, strata, batch, lr, part_relative=False):
+    def complete_rotation(self):
+        """hand over the part a previous run_strata(defer_last=True) kept back and finish that rotation"""
+        if self._deferred is not None:
+            k, self._deferred = self._deferred, None
+            self._send_part(k)
+            self._finish_rotation()
+
+    def run_strata(self, strata, batch, lr, part_relative=False, defer_last=False):
         """Consecutive strata [(u, p, n, steps_per_part), ...] (see run_subepoch), one block rotation after each.  All
         their batches go to the local runner as ONE list of segments, so its plan pipeline runs across the rotations: the
         first plan of stratum r+1 is built while stratum r trains (a plan needs the indices only, not the block that is
         still on its way).  With 8 GPUs a stratum is a few dozen steps: an exposed plan build per stratum would cost a
-        third of it.  part_relative=True: p and n already count rows from the start of their part (no offset pass)."""
+        third of it.  part_relative=True: p and n already count rows from the start of their part (no offset pass).
+        defer_last=True: the LAST part of the last stratum is not handed to the ring here but at the start of the next call
+        (or by complete_rotation / gather_full) — in a long run the hand-over of a stratum's last part hides behind the next
+        stratum's first part; a caller that cuts the run into pieces (bench.py: warm-up, timed steps) keeps that overlap
+        across its pieces this way instead of ending each piece on an exposed transfer."""
+        self.complete_rotation()
         B = int(batch)
         # the global batch is the union of the G local batches: its mean loss has 1/(G*B) coefficients.  The local kernels
         # use 1/B, and the local batches touch disjoint rows, so dividing the learning rate by G gives the same update.
@@ -201,16 +216,22 @@ class RotatingBprmf:
         losses = torch.zeros(sum(sum(c) for c in counts), dtype=torch.float32, device=self.device)
         handle = self.local.plan(self.U, segments, B)
         first, seg = 0, 0
-        for per_part in counts:
+        for si, per_part in enumerate(counts):
+            last_stratum = si == len(counts) - 1
             for k, st in enumerate(per_part):
                 if st > 0:
                     self._await_part(k)                 # the held block's part k has landed (it came in during the last stratum)
                     self.local.run(handle, seg, lr, losses[first:first + st])
                     first += st
                 seg += 1
-                self._send_part(k)
-            self._finish_rotation()
-        self._drain()                                   # leave with the held block complete
+                if defer_last and last_stratum and k == len(per_part) - 1 and self.world > 1:
+                    self._deferred = k                  # handed over at the start of the next call
+                else:
+                    self._send_part(k)
+            if self._deferred is None:
+                self._finish_rotation()
+        if self._deferred is None:
+            self._drain()                               # leave with the held block complete
         return losses
 
     def global_losses(self, local_losses):
@@ -290,7 +311,10 @@ def bench_run(args, rank, world, dev):
         return sched, held
 
     def run_schedule(sched):
-        return model.run_strata(sched, B, args.lr, part_relative=True)
+        # the hand-over of the last part is left to the next call: it then runs beside that call's first part, as it would
+        # beside the next stratum's first part in one long run (the timed region takes over the warm-up's pending hand-over
+        # and leaves its own one pending: one rotation's worth of transfers per stratum inside the timed region)
+        return model.run_strata(sched, B, args.lr, part_relative=True, defer_last=True)
 
     warm, held_after = make_schedule(W, model.held)
     timed, _ = make_schedule(K, held_after)
@@ -308,6 +332,8 @@ def bench_run(args, rank, world, dev):
     torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    model.complete_rotation()
+    model._drain()
     losses = model.global_losses(local_losses)
     dt = float(dt.item())
     if rank != 0:
