@@ -6,6 +6,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-$R/gpurun_out/spmm_prof}
 mkdir -p "$OUT"
+OUT=$(cd "$OUT" && pwd)
 cd "$R"
 WR_DENS=0.12 timeout -k 10 200 python3 scripts/ab_spmm.py > "$OUT/ab.txt" 2>&1
 cd /tmp && export TMPDIR=/tmp
