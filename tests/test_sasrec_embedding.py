@@ -63,3 +63,28 @@ def test_full_predict_loss_and_embedding_grad(g5):
     g = m.item_embedding.weight.grad.cpu().numpy()
     assert rel_err(g, g5["gW_full"]) < 1e-4
     assert not g[0].any()
+
+
+@pytest.mark.parametrize("n_rows,n,pad", [(3706, 45056, 0), (16383, 70001, 0), (16384, 30000, 5), (40000, 50000, -1), (7, 5000, 0),
+                                          (3706, 1023, 0), (3706, 1025, 0)])
+def test_scatter_add_both_sort_paths_match_oracle(n_rows, n, pad):
+    """tables of up to 16,383 rows take the counting sort in LDS tiles, larger ones the radix sort: same result (the order
+    inside a destination row is the original position order either way), padding row dropped"""
+    import oracle
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(n_rows + n)
+    idx = rng.randint(0, n_rows, n).astype(np.int64)
+    idx[::7] = min(3, n_rows - 1)                      # a popular row: long run
+    if pad >= 0:
+        idx[::5] = pad
+    src = rng.standard_normal((n, 64)).astype(np.float32)
+    got = hip_ops.scatter_add_rows(torch.zeros(n_rows, 64, device=dev), torch.from_numpy(idx).to(dev), torch.from_numpy(src).to(dev),
+                                   padding_idx=pad)
+    ref = oracle.scatter_add_rows(n_rows, idx, src, padding_idx=pad)
+    assert rel_err(got.cpu().numpy(), ref) < TOL
+    if pad >= 0:
+        assert not got[pad].any()
+    again = hip_ops.scatter_add_rows(torch.zeros(n_rows, 64, device=dev), torch.from_numpy(idx).to(dev),
+                                     torch.from_numpy(src).to(dev), padding_idx=pad)
+    assert torch.equal(got, again)

@@ -54,15 +54,32 @@ __global__ __launch_bounds__(kBlock) void scatter_add_sorted_kernel(float *__res
     Row<NV> acc;
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t q = q0;
-    do {
-        const Row<NV> s = load_row<T, NV, FULL>(src, perm[q], D, lane);
+    // four contributions per trip: their positions, then their rows, are requested together and added in run order
+    // (one contribution per trip made a run of m rows a chain of 2 m dependent round trips)
+    for (int64_t q = q0; q < n && keys[q] == r; q += 4) {
+        bool ok[4];
+        uint32_t sp[4];
+        Row<NV> sr[4];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            acc.v[k].x += s.v[k].x; acc.v[k].y += s.v[k].y; acc.v[k].z += s.v[k].z; acc.v[k].w += s.v[k].w;
+        for (int f = 0; f < 4; ++f) {
+            ok[f] = q + f < n && keys[q + f] == r;
+            sp[f] = ok[f] ? perm[q + f] : 0u;
         }
-        ++q;
-    } while (q < n && keys[q] == r);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (ok[f]) sr[f] = load_row<T, NV, FULL>(src, sp[f], D, lane);
+        bool more = true;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            more = more && ok[f];
+            if (!more) break;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                acc.v[k].x += sr[f].v[k].x; acc.v[k].y += sr[f].v[k].y; acc.v[k].z += sr[f].v[k].z; acc.v[k].w += sr[f].v[k].w;
+            }
+        }
+        if (!more) break;
+    }
     Row<NV> g = load_row<T, NV, FULL>(grad, r, D, lane);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -72,17 +89,139 @@ __global__ __launch_bounds__(kBlock) void scatter_add_sorted_kernel(float *__res
     store_row<T, NV, FULL>(grad, r, D, lane, g);
 }
 
+// ---- destination sort for small tables (SASRec's item table on ml-1m: 3,706 rows, 45 K gathered rows per step) ----------
+// A radix sort of (row, position) pairs per call (rocPRIM: a dozen launches, ~35 us for 45 K pairs) is replaced by a
+// counting sort in three launches whenever the table has at most kSmallRows rows:
+//   S1 one workgroup per tile of kSortTile positions: composites (row << 10 | position in tile) are unique, so a bitonic
+//      sort in LDS orders them by (row, position) whatever the scheduling; per tile the number of positions of every row
+//      (LDS histogram) and the start of every row's run are written out;
+//   S2 one workgroup: per row the exclusive prefix of the tiles' counts, and the rows' bases (exclusive scan of the totals);
+//   S3 one workgroup per tile: every sorted composite goes to base[row] + prefix[tile][row] + (its index in the run):
+//      keys_sorted / perm in ascending (row, original position) order — the order the stable radix sort produced, so the
+//      segmented sum adds the same rows in the same order (same bits as before).
+constexpr int kSortTile = 1024;
+constexpr int kSmallRows = 16383;     // rows + 1 sentinel (padding / out-of-range positions) must fit 14 bits of the composite
+
+__global__ __launch_bounds__(kBlock) void small_sort_tiles_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t n_rows,
+                                                                   int64_t padding_idx, uint32_t *__restrict__ comp_sorted,
+                                                                   int *__restrict__ hist, int *__restrict__ offs) {
+    extern __shared__ int sm[];                 // comp[kSortTile] | cnt[n_rows + 1] | first[n_rows + 1]
+    uint32_t *comp = reinterpret_cast<uint32_t *>(sm);
+    int *cnt = sm + kSortTile;
+    int *first = cnt + (n_rows + 1);
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const int nk = (int)n_rows + 1;
+    for (int j = threadIdx.x; j < nk; j += kBlock) cnt[j] = 0;
+    for (int e = threadIdx.x; e < kSortTile; e += kBlock) {
+        const int64_t i = base + e;
+        uint32_t c = 0xffffffffu;                // beyond the end: sorts last, never counted
+        if (i < n) {
+            const int64_t r = idx[i];
+            const uint32_t key = (r == padding_idx || r < 0 || r >= n_rows) ? (uint32_t)n_rows : (uint32_t)r;
+            c = (key << 10) | (uint32_t)e;
+        }
+        comp[e] = c;
+    }
+    __syncthreads();
+    // bitonic sort of kSortTile unique composites, kBlock threads
+    for (int size = 2; size <= kSortTile; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < kSortTile / 2; t += kBlock) {
+                const int lo = 2 * t - (t & (stride - 1));        // index of the lower element of pair t at this stride
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = comp[lo], b = comp[hi];
+                if ((a > b) == up) { comp[lo] = b; comp[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = threadIdx.x; e < kSortTile; e += kBlock) {
+        const uint32_t c = comp[e];
+        comp_sorted[base + e] = c;
+        if (c == 0xffffffffu) continue;
+        const int key = (int)(c >> 10);
+        atomicAdd(&cnt[key], 1);                                   // integer counts: order irrelevant
+        if (e == 0 || (int)(comp[e - 1] >> 10) != key) first[key] = e;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nk; j += kBlock) {
+        hist[(int64_t)blockIdx.x * nk + j] = cnt[j];
+        offs[(int64_t)blockIdx.x * nk + j] = cnt[j] ? first[j] : 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void small_sort_scan_kernel(int *__restrict__ hist, int n_tiles, int nk, int *__restrict__ base) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < nk; j0 += 1024) {
+        const int j = j0 + threadIdx.x;
+        int total = 0;
+        if (j < nk)
+            for (int t = 0; t < n_tiles; ++t) {                    // exclusive prefix over the tiles, in place
+                const int c = hist[(int64_t)t * nk + j];
+                hist[(int64_t)t * nk + j] = total;
+                total += c;
+            }
+        int incl = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) incl += v;
+        }
+        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int before = carry + incl - total;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wave_tot[w];
+        if (j < nk) base[j] = before;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void small_sort_place_kernel(const uint32_t *__restrict__ comp_sorted, int64_t n, int nk,
+                                                                   const int *__restrict__ hist, const int *__restrict__ offs,
+                                                                   const int *__restrict__ base, uint32_t *__restrict__ keys_out,
+                                                                   uint32_t *__restrict__ perm_out) {
+    const int64_t tb = (int64_t)blockIdx.x * kSortTile;
+    for (int e = threadIdx.x; e < kSortTile; e += kBlock) {
+        const uint32_t c = comp_sorted[tb + e];
+        if (c == 0xffffffffu) continue;
+        const int key = (int)(c >> 10);
+        const int64_t at = (int64_t)blockIdx.x * nk + key;
+        const int dest = base[key] + hist[at] + (e - offs[at]);
+        keys_out[dest] = (uint32_t)key;
+        perm_out[dest] = (uint32_t)(tb + (c & 1023u));
+    }
+}
+
 struct ScatterLayout {
     int64_t arr_bytes;
     size_t temp;
     unsigned end_bit;
     int64_t total;
+    bool small;                 // counting sort in LDS tiles (table of at most kSmallRows rows)
+    int64_t n_tiles, comp_bytes, hist_bytes, base_bytes;
 };
 
 static int32_t scatter_layout(int64_t n, int64_t n_rows, ScatterLayout &L) {
     WR_REQUIRE(n > 0 && n < (int64_t(1) << 31), WR_E_SHAPE, "scatter: n=%lld out of range", (long long)n);
     WR_REQUIRE(n_rows > 0 && n_rows < (int64_t(1) << 31), WR_E_SHAPE, "scatter: n_rows out of range");
     L.arr_bytes = align_up(n * 4, 256);
+    L.n_tiles = (n + kSortTile - 1) / kSortTile;
+    L.small = n_rows <= kSmallRows && L.n_tiles * (n_rows + 1) <= (int64_t(1) << 24);
+    if (L.small) {
+        L.comp_bytes = align_up(L.n_tiles * kSortTile * 4, 256);
+        L.hist_bytes = align_up(L.n_tiles * (n_rows + 1) * 4, 256);
+        L.base_bytes = align_up((n_rows + 1) * 4, 256);
+        L.temp = 0;
+        L.end_bit = 0;
+        L.total = 2 * L.arr_bytes + L.comp_bytes + 2 * L.hist_bytes + L.base_bytes;
+        return WR_OK;
+    }
     L.end_bit = 1;
     while ((int64_t(1) << L.end_bit) < n_rows + 1) ++L.end_bit;
     uint32_t *k = nullptr;
@@ -517,14 +656,39 @@ int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_
                "scatter workspace %lld B < %lld B", (long long)workspace_bytes, (long long)L.total);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char *ws = reinterpret_cast<char *>(workspace);
-    uint32_t *keyA = reinterpret_cast<uint32_t *>(ws), *keyB = reinterpret_cast<uint32_t *>(ws + L.arr_bytes);
-    uint32_t *valA = reinterpret_cast<uint32_t *>(ws + 2 * L.arr_bytes), *valB = reinterpret_cast<uint32_t *>(ws + 3 * L.arr_bytes);
-    void *temp = ws + 4 * L.arr_bytes;
-    size_t temp_bytes = L.temp;
-    const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(scatter_keys_kernel, dim3(g1), dim3(kBlock), 0, stream, idx, n, n_rows, padding_idx, keyA, valA);
-    WR_LAUNCH_CHECK("scatter_keys_kernel");
-    WR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keyA, keyB, valA, valB, (size_t)n, 0u, L.end_bit, stream));
+    uint32_t *keyB, *valB;
+    if (L.small) {
+        keyB = reinterpret_cast<uint32_t *>(ws);
+        valB = reinterpret_cast<uint32_t *>(ws + L.arr_bytes);
+        uint32_t *comp = reinterpret_cast<uint32_t *>(ws + 2 * L.arr_bytes);
+        int *hist = reinterpret_cast<int *>(ws + 2 * L.arr_bytes + L.comp_bytes);
+        int *offs = reinterpret_cast<int *>(ws + 2 * L.arr_bytes + L.comp_bytes + L.hist_bytes);
+        int *base = reinterpret_cast<int *>(ws + 2 * L.arr_bytes + L.comp_bytes + 2 * L.hist_bytes);
+        const int nk = (int)n_rows + 1;
+        const size_t lds = ((size_t)kSortTile + 2 * (size_t)nk) * 4;
+        if (lds > 64 * 1024)
+            WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_sort_tiles_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(small_sort_tiles_kernel, dim3((unsigned)L.n_tiles), dim3(kBlock), lds, stream, idx, n, n_rows,
+                           padding_idx, comp, hist, offs);
+        WR_LAUNCH_CHECK("small_sort_tiles_kernel");
+        hipLaunchKernelGGL(small_sort_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, (int)L.n_tiles, nk, base);
+        WR_LAUNCH_CHECK("small_sort_scan_kernel");
+        hipLaunchKernelGGL(small_sort_place_kernel, dim3((unsigned)L.n_tiles), dim3(kBlock), 0, stream, comp, n, nk, hist, offs,
+                           base, keyB, valB);
+        WR_LAUNCH_CHECK("small_sort_place_kernel");
+    } else {
+        uint32_t *keyA = reinterpret_cast<uint32_t *>(ws);
+        keyB = reinterpret_cast<uint32_t *>(ws + L.arr_bytes);
+        uint32_t *valA = reinterpret_cast<uint32_t *>(ws + 2 * L.arr_bytes);
+        valB = reinterpret_cast<uint32_t *>(ws + 3 * L.arr_bytes);
+        void *temp = ws + 4 * L.arr_bytes;
+        size_t temp_bytes = L.temp;
+        const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(scatter_keys_kernel, dim3(g1), dim3(kBlock), 0, stream, idx, n, n_rows, padding_idx, keyA, valA);
+        WR_LAUNCH_CHECK("scatter_keys_kernel");
+        WR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keyA, keyB, valA, valB, (size_t)n, 0u, L.end_bit, stream));
+    }
     const int tpb = teams_per_block_for(D);
     const unsigned grid = (unsigned)((n + tpb - 1) / tpb);
 #define WR_CALL_S(T_, NV_, FULL_)                                                                                    \
