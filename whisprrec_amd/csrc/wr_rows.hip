@@ -91,14 +91,12 @@ __global__ __launch_bounds__(kBlock) void scatter_add_sorted_kernel(float *__res
 
 // ---- destination sort for small tables (SASRec's item table on ml-1m: 3,706 rows, 45 K gathered rows per step) ----------
 // A radix sort of (row, position) pairs per call (rocPRIM: a dozen launches, ~35 us for 45 K pairs) is replaced by a
-// counting sort in three launches whenever the table has at most kSmallRows rows:
+// sort in LDS tiles and a row-owner sum, two launches, whenever the table has at most kSmallRows rows:
 //   S1 one workgroup per tile of kSortTile positions: composites (row << 10 | position in tile) are unique, so a bitonic
 //      sort in LDS orders them by (row, position) whatever the scheduling; per tile the number of positions of every row
 //      (LDS histogram) and the start of every row's run are written out;
-//   S2 one workgroup: per row the exclusive prefix of the tiles' counts, and the rows' bases (exclusive scan of the totals);
-//   S3 one workgroup per tile: every sorted composite goes to base[row] + prefix[tile][row] + (its index in the run):
-//      keys_sorted / perm in ascending (row, original position) order — the order the stable radix sort produced, so the
-//      segmented sum adds the same rows in the same order (same bits as before).
+//   S2 one team per destination row walks the tiles in order (scatter_add_tiles_kernel): ascending (tile, position) order =
+//      ascending original position — the order the stable radix sort produced, so the same rows are added in the same order.
 constexpr int kSortTile = 1024;
 constexpr int kSmallRows = 16383;     // rows + 1 sentinel (padding / out-of-range positions) must fit 14 bits of the composite
 
@@ -151,51 +149,91 @@ __global__ __launch_bounds__(kBlock) void small_sort_tiles_kernel(const int64_t 
     }
 }
 
-__global__ __launch_bounds__(1024) void small_sort_scan_kernel(int *__restrict__ hist, int n_tiles, int nk, int *__restrict__ base) {
-    __shared__ int wave_tot[16];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int j0 = 0; j0 < nk; j0 += 1024) {
-        const int j = j0 + threadIdx.x;
-        int total = 0;
-        if (j < nk)
-            for (int t = 0; t < n_tiles; ++t) {                    // exclusive prefix over the tiles, in place
-                const int c = hist[(int64_t)t * nk + j];
-                hist[(int64_t)t * nk + j] = total;
-                total += c;
-            }
-        int incl = total;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d, 64);
-            if ((int)(threadIdx.x & 63) >= d) incl += v;
-        }
-        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        int before = carry + incl - total;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wave_tot[w];
-        if (j < nk) base[j] = before;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before + total;
-        __syncthreads();
-    }
-}
+// S2: one team per destination row.  Per group of T tiles the team's lanes fetch (count, start) of the row in their tile, an
+// exclusive scan over the lanes gives every tile's slot range in a per-team LDS list, the lanes copy their tiles' source
+// positions into it (tile-major = ascending original position), and the team then adds the listed rows eight per trip, in
+// list order.  A group holding more than kRowList contributions of one row (a row that fills whole tiles) is walked tile by
+// tile instead.  Same order of addition as the radix-sorted path, no atomics.
+constexpr int kRowListPerLane = 16;     // list slots per team = 16 x (lanes of a team): 256 at D >= 64
 
-__global__ __launch_bounds__(kBlock) void small_sort_place_kernel(const uint32_t *__restrict__ comp_sorted, int64_t n, int nk,
-                                                                   const int *__restrict__ hist, const int *__restrict__ offs,
-                                                                   const int *__restrict__ base, uint32_t *__restrict__ keys_out,
-                                                                   uint32_t *__restrict__ perm_out) {
-    const int64_t tb = (int64_t)blockIdx.x * kSortTile;
-    for (int e = threadIdx.x; e < kSortTile; e += kBlock) {
-        const uint32_t c = comp_sorted[tb + e];
-        if (c == 0xffffffffu) continue;
-        const int key = (int)(c >> 10);
-        const int64_t at = (int64_t)blockIdx.x * nk + key;
-        const int dest = base[key] + hist[at] + (e - offs[at]);
-        keys_out[dest] = (uint32_t)key;
-        perm_out[dest] = (uint32_t)(tb + (c & 1023u));
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void scatter_add_tiles_kernel(float *__restrict__ grad, int D, int n_rows, int nk, int n_tiles,
+                                                                    const uint32_t *__restrict__ comp_sorted,
+                                                                    const int *__restrict__ hist, const int *__restrict__ offs,
+                                                                    const float *__restrict__ src, float alpha) {
+    constexpr int TEAMS = kBlock / T;
+    constexpr int kRowList = kRowListPerLane * T;
+    __shared__ uint32_t lists[TEAMS][kRowList];
+    const int lane = threadIdx.x % T, team = threadIdx.x / T;
+    const int r = blockIdx.x * TEAMS + team;
+    if (r >= n_rows) return;
+    uint32_t *list = lists[team];
+    Row<NV> acc;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
+    auto add_rows = [&](const uint32_t (&sp)[8], int m) {      // m <= 8 listed rows: requested together, added in order
+        Row<NV> sr[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+            if (f < m) sr[f] = load_row<T, NV, FULL>(src, sp[f], D, lane);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            if (f >= m) break;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                acc.v[k].x += sr[f].v[k].x; acc.v[k].y += sr[f].v[k].y; acc.v[k].z += sr[f].v[k].z; acc.v[k].w += sr[f].v[k].w;
+            }
+        }
+    };
+    for (int t0 = 0; t0 < n_tiles; t0 += T) {
+        const int t = t0 + lane;
+        const int c = t < n_tiles ? hist[(int64_t)t * nk + r] : 0;
+        const int o = t < n_tiles ? offs[(int64_t)t * nk + r] : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < T; d <<= 1) {
+            const int v = __shfl_up(incl, d, T);
+            if (lane >= d) incl += v;
+        }
+        const int total = __shfl(incl, T - 1, T);
+        if (total == 0) continue;
+        any = true;
+        if (total <= kRowList) {
+            const int at = incl - c;
+            for (int e = 0; e < c; ++e) list[at + e] = (uint32_t)t * kSortTile + (comp_sorted[(int64_t)t * kSortTile + o + e] & 1023u);
+            // the team's lanes run in lockstep inside one wave: the list is complete for every lane once all have stored
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < total; i += 8) {
+                uint32_t sp[8];
+                const int m = total - i < 8 ? total - i : 8;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) sp[f] = f < m ? list[i + f] : 0u;
+                add_rows(sp, m);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            for (int j = 0; j < T; ++j) {                          // a row that fills tiles: tile by tile, eight per trip
+                const int cj = __shfl(c, j, T), oj = __shfl(o, j, T);
+                const int64_t tb = (int64_t)(t0 + j) * kSortTile;
+                for (int i = 0; i < cj; i += 8) {
+                    uint32_t sp[8];
+                    const int m = cj - i < 8 ? cj - i : 8;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) sp[f] = f < m ? (uint32_t)tb + (comp_sorted[tb + oj + i + f] & 1023u) : 0u;
+                    add_rows(sp, m);
+                }
+            }
+        }
     }
+    if (!any) return;
+    Row<NV> g = load_row<T, NV, FULL>(grad, r, D, lane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        g.v[k].x = fmaf(alpha, acc.v[k].x, g.v[k].x); g.v[k].y = fmaf(alpha, acc.v[k].y, g.v[k].y);
+        g.v[k].z = fmaf(alpha, acc.v[k].z, g.v[k].z); g.v[k].w = fmaf(alpha, acc.v[k].w, g.v[k].w);
+    }
+    store_row<T, NV, FULL>(grad, r, D, lane, g);
 }
 
 struct ScatterLayout {
@@ -216,10 +254,10 @@ static int32_t scatter_layout(int64_t n, int64_t n_rows, ScatterLayout &L) {
     if (L.small) {
         L.comp_bytes = align_up(L.n_tiles * kSortTile * 4, 256);
         L.hist_bytes = align_up(L.n_tiles * (n_rows + 1) * 4, 256);
-        L.base_bytes = align_up((n_rows + 1) * 4, 256);
+        L.base_bytes = 0;
         L.temp = 0;
         L.end_bit = 0;
-        L.total = 2 * L.arr_bytes + L.comp_bytes + 2 * L.hist_bytes + L.base_bytes;
+        L.total = L.comp_bytes + 2 * L.hist_bytes;
         return WR_OK;
     }
     L.end_bit = 1;
@@ -656,14 +694,12 @@ int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_
                "scatter workspace %lld B < %lld B", (long long)workspace_bytes, (long long)L.total);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char *ws = reinterpret_cast<char *>(workspace);
-    uint32_t *keyB, *valB;
+    uint32_t *keyB = nullptr, *valB = nullptr;
+    const int tpb = teams_per_block_for(D);
     if (L.small) {
-        keyB = reinterpret_cast<uint32_t *>(ws);
-        valB = reinterpret_cast<uint32_t *>(ws + L.arr_bytes);
-        uint32_t *comp = reinterpret_cast<uint32_t *>(ws + 2 * L.arr_bytes);
-        int *hist = reinterpret_cast<int *>(ws + 2 * L.arr_bytes + L.comp_bytes);
-        int *offs = reinterpret_cast<int *>(ws + 2 * L.arr_bytes + L.comp_bytes + L.hist_bytes);
-        int *base = reinterpret_cast<int *>(ws + 2 * L.arr_bytes + L.comp_bytes + 2 * L.hist_bytes);
+        uint32_t *comp = reinterpret_cast<uint32_t *>(ws);
+        int *hist = reinterpret_cast<int *>(ws + L.comp_bytes);
+        int *offs = reinterpret_cast<int *>(ws + L.comp_bytes + L.hist_bytes);
         const int nk = (int)n_rows + 1;
         const size_t lds = ((size_t)kSortTile + 2 * (size_t)nk) * 4;
         if (lds > 64 * 1024)
@@ -672,11 +708,14 @@ int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_
         hipLaunchKernelGGL(small_sort_tiles_kernel, dim3((unsigned)L.n_tiles), dim3(kBlock), lds, stream, idx, n, n_rows,
                            padding_idx, comp, hist, offs);
         WR_LAUNCH_CHECK("small_sort_tiles_kernel");
-        hipLaunchKernelGGL(small_sort_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, (int)L.n_tiles, nk, base);
-        WR_LAUNCH_CHECK("small_sort_scan_kernel");
-        hipLaunchKernelGGL(small_sort_place_kernel, dim3((unsigned)L.n_tiles), dim3(kBlock), 0, stream, comp, n, nk, hist, offs,
-                           base, keyB, valB);
-        WR_LAUNCH_CHECK("small_sort_place_kernel");
+        const unsigned grid_rows = (unsigned)((n_rows + tpb - 1) / tpb);
+#define WR_CALL_ST(T_, NV_, FULL_)                                                                                       \
+    hipLaunchKernelGGL((scatter_add_tiles_kernel<T_, NV_, FULL_>), dim3(grid_rows), dim3(kBlock), 0, stream, grad, D,      \
+                       (int)n_rows, nk, (int)L.n_tiles, comp, hist, offs, src, alpha)
+        WR_DISPATCH_D(D, WR_CALL_ST);
+#undef WR_CALL_ST
+        WR_LAUNCH_CHECK("scatter_add_tiles_kernel");
+        return WR_OK;
     } else {
         uint32_t *keyA = reinterpret_cast<uint32_t *>(ws);
         keyB = reinterpret_cast<uint32_t *>(ws + L.arr_bytes);
@@ -689,7 +728,6 @@ int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_
         WR_LAUNCH_CHECK("scatter_keys_kernel");
         WR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keyA, keyB, valA, valB, (size_t)n, 0u, L.end_bit, stream));
     }
-    const int tpb = teams_per_block_for(D);
     const unsigned grid = (unsigned)((n + tpb - 1) / tpb);
 #define WR_CALL_S(T_, NV_, FULL_)                                                                                    \
     hipLaunchKernelGGL((scatter_add_sorted_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, grad, D,     \
