@@ -89,89 +89,125 @@ __global__ __launch_bounds__(kBlock) void scatter_add_sorted_kernel(float *__res
     store_row<T, NV, FULL>(grad, r, D, lane, g);
 }
 
-// ---- destination sort for small tables (SASRec's item table on ml-1m: 3,706 rows, 45 K gathered rows per step) ----------
-// A radix sort of (row, position) pairs per call (rocPRIM: a dozen launches, ~35 us for 45 K pairs) is replaced by a
-// sort in LDS tiles and a row-owner sum, two launches, whenever the table has at most kSmallRows rows:
-//   S1 one workgroup per tile of kSortTile positions: composites (row << 10 | position in tile) are unique, so a bitonic
-//      sort in LDS orders them by (row, position) whatever the scheduling; per tile the number of positions of every row
-//      (LDS histogram) and the start of every row's run are written out;
-//   S2 one team per destination row walks the tiles in order (scatter_add_tiles_kernel): ascending (tile, position) order =
-//      ascending original position — the order the stable radix sort produced, so the same rows are added in the same order.
+// ---- destination lists for small tables (SASRec's item table on ml-1m: 3,706 rows, 45 K gathered rows per step) ---------
+// A radix sort of (row, position) pairs per call (rocPRIM: a dozen launches, ~35 us for 45 K pairs) is replaced by two
+// launches whenever the table has at most kSmallRows rows:
+//   S1 one workgroup per tile of kSortTile positions: counting sort of the tile by destination row in LDS (histogram,
+//      exclusive scan, placement through LDS cursors) — per tile the number of positions of every row, the start of the
+//      row's segment, and the positions grouped by row.  The order INSIDE a segment is whatever the LDS atomics gave;
+//   S2 one team per destination row collects its positions from all tiles into an LDS list, SORTS the list (positions are
+//      unique integers, so the sorted list does not depend on S1's placement order: ascending original position, the order
+//      the stable radix sort produced) and adds the listed rows eight per trip, in list order.  No float atomics, bitwise
+//      reproducible, same bits as the radix-sorted path.
 constexpr int kSortTile = 1024;
-constexpr int kSmallRows = 16383;     // rows + 1 sentinel (padding / out-of-range positions) must fit 14 bits of the composite
+constexpr int kSmallRows = 16383;     // table rows + 1 sentinel (padding / out-of-range positions)
+constexpr int kLongSeg = 16;          // = the shortest per-team list of S2 (kRowListPerLane x 1 lane)
 
 __global__ __launch_bounds__(kBlock) void small_sort_tiles_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t n_rows,
-                                                                   int64_t padding_idx, uint32_t *__restrict__ comp_sorted,
+                                                                   int64_t padding_idx, uint32_t *__restrict__ pos_grouped,
                                                                    int *__restrict__ hist, int *__restrict__ offs) {
-    extern __shared__ int sm[];                 // comp[kSortTile] | cnt[n_rows + 1] | first[n_rows + 1]
-    uint32_t *comp = reinterpret_cast<uint32_t *>(sm);
-    int *cnt = sm + kSortTile;
-    int *first = cnt + (n_rows + 1);
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    extern __shared__ int sm[];                 // cnt[nk] | cur[nk] | out[kSortTile]
+    __shared__ int wave_tot[kBlock / 64];
     const int nk = (int)n_rows + 1;
+    int *cnt = sm, *cur = sm + nk, *out = sm + 2 * nk;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    constexpr int PER = kSortTile / kBlock;
     for (int j = threadIdx.x; j < nk; j += kBlock) cnt[j] = 0;
-    for (int e = threadIdx.x; e < kSortTile; e += kBlock) {
-        const int64_t i = base + e;
-        uint32_t c = 0xffffffffu;                // beyond the end: sorts last, never counted
+    int key[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int64_t i = base + threadIdx.x + k * kBlock;
+        key[k] = -1;
         if (i < n) {
             const int64_t r = idx[i];
-            const uint32_t key = (r == padding_idx || r < 0 || r >= n_rows) ? (uint32_t)n_rows : (uint32_t)r;
-            c = (key << 10) | (uint32_t)e;
-        }
-        comp[e] = c;
-    }
-    __syncthreads();
-    // bitonic sort of kSortTile unique composites, kBlock threads
-    for (int size = 2; size <= kSortTile; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < kSortTile / 2; t += kBlock) {
-                const int lo = 2 * t - (t & (stride - 1));        // index of the lower element of pair t at this stride
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint32_t a = comp[lo], b = comp[hi];
-                if ((a > b) == up) { comp[lo] = b; comp[hi] = a; }
-            }
-            __syncthreads();
+            key[k] = (r == padding_idx || r < 0 || r >= n_rows) ? (int)n_rows : (int)r;
         }
     }
-    for (int e = threadIdx.x; e < kSortTile; e += kBlock) {
-        const uint32_t c = comp[e];
-        comp_sorted[base + e] = c;
-        if (c == 0xffffffffu) continue;
-        const int key = (int)(c >> 10);
-        atomicAdd(&cnt[key], 1);                                   // integer counts: order irrelevant
-        if (e == 0 || (int)(comp[e - 1] >> 10) != key) first[key] = e;
-    }
     __syncthreads();
-    for (int j = threadIdx.x; j < nk; j += kBlock) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (key[k] >= 0) atomicAdd(&cnt[key[k]], 1);            // integer counts: order irrelevant
+    __syncthreads();
+    // exclusive scan of cnt[0..nk) into cur: thread t owns counters [t*per, (t+1)*per)
+    const int per = (nk + kBlock - 1) / kBlock;
+    const int c0 = threadIdx.x * per;
+    int local = 0;
+    for (int j = 0; j < per; ++j)
+        if (c0 + j < nk) local += cnt[c0 + j];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wave_tot[w];
+    for (int j = 0; j < per; ++j)
+        if (c0 + j < nk) {
+            cur[c0 + j] = run;
+            run += cnt[c0 + j];
+        }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nk; j += kBlock) {             // segment starts, before the cursors move
         hist[(int64_t)blockIdx.x * nk + j] = cnt[j];
-        offs[(int64_t)blockIdx.x * nk + j] = cnt[j] ? first[j] : 0;
+        offs[(int64_t)blockIdx.x * nk + j] = cur[j];
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (key[k] >= 0) out[atomicAdd(&cur[key[k]], 1)] = threadIdx.x + k * kBlock;
+    __syncthreads();
+    // Segments longer than kLongSeg are put in ascending position order here (S2 streams them instead of listing them):
+    // one after the other by the whole workgroup, every position counting the smaller ones of its segment.
+    __shared__ int long_keys[kSortTile / kLongSeg];
+    __shared__ int n_long;
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < nk; j += kBlock)
+        if (cnt[j] > kLongSeg) long_keys[atomicAdd(&n_long, 1)] = j;   // at most kSortTile / kLongSeg of them; order irrelevant
+    __syncthreads();
+    const int nl = n_long;
+    for (int q = 0; q < nl; ++q) {
+        const int j = long_keys[q];
+        const int m = cnt[j], s0 = cur[j] - m;                           // the cursor stands at the segment's end
+        int v[PER], rank[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = threadIdx.x + k * kBlock;
+            v[k] = e < m ? out[s0 + e] : 0;
+            rank[k] = 0;
+            if (e < m)
+                for (int x = 0; x < m; ++x) rank[k] += out[s0 + x] < v[k] ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (threadIdx.x + k * kBlock < m) out[s0 + rank[k]] = v[k];
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < kSortTile; e += kBlock)
+        if (base + e < n) pos_grouped[base + e] = (uint32_t)(base + out[e]);
 }
 
-// S2: one team per destination row.  Per group of T tiles the team's lanes fetch (count, start) of the row in their tile, an
-// exclusive scan over the lanes gives every tile's slot range in a per-team LDS list, the lanes copy their tiles' source
-// positions into it (tile-major = ascending original position), and the team then adds the listed rows eight per trip, in
-// list order.  A group holding more than kRowList contributions of one row (a row that fills whole tiles) is walked tile by
-// tile instead.  Same order of addition as the radix-sorted path, no atomics.
 constexpr int kRowListPerLane = 16;     // list slots per team = 16 x (lanes of a team): 256 at D >= 64
 
 template <int T, int NV, bool FULL>
 __global__ __launch_bounds__(kBlock) void scatter_add_tiles_kernel(float *__restrict__ grad, int D, int n_rows, int nk, int n_tiles,
-                                                                    const uint32_t *__restrict__ comp_sorted,
+                                                                    const uint32_t *__restrict__ pos_grouped,
                                                                     const int *__restrict__ hist, const int *__restrict__ offs,
                                                                     const float *__restrict__ src, float alpha) {
     constexpr int TEAMS = kBlock / T;
     constexpr int kRowList = kRowListPerLane * T;
-    __shared__ uint32_t lists[TEAMS][kRowList];
+    __shared__ uint32_t lists[TEAMS][2][kRowList];
     const int lane = threadIdx.x % T, team = threadIdx.x / T;
     const int r = blockIdx.x * TEAMS + team;
     if (r >= n_rows) return;
-    uint32_t *list = lists[team];
+    uint32_t *list = lists[team][0], *sorted = lists[team][1];
     Row<NV> acc;
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool any = false;
     auto add_rows = [&](const uint32_t (&sp)[8], int m) {      // m <= 8 listed rows: requested together, added in order
         Row<NV> sr[8];
 #pragma unroll
@@ -186,6 +222,27 @@ __global__ __launch_bounds__(kBlock) void scatter_add_tiles_kernel(float *__rest
             }
         }
     };
+    // ascending order of m collected positions, by counting the smaller ones (unique values), then the sum in that order
+    auto flush = [&](int m) {
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < m; i += T) {
+            const uint32_t v = list[i];
+            int rank = 0;
+            for (int j = 0; j < m; ++j) rank += list[j] < v ? 1 : 0;
+            sorted[rank] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < m; i += 8) {
+            uint32_t sp[8];
+            const int mm = m - i < 8 ? m - i : 8;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) sp[f] = f < mm ? sorted[i + f] : 0u;
+            add_rows(sp, mm);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    int filled = 0;                                            // team-uniform
+    bool any = false;
     for (int t0 = 0; t0 < n_tiles; t0 += T) {
         const int t = t0 + lane;
         const int c = t < n_tiles ? hist[(int64_t)t * nk + r] : 0;
@@ -199,33 +256,32 @@ __global__ __launch_bounds__(kBlock) void scatter_add_tiles_kernel(float *__rest
         const int total = __shfl(incl, T - 1, T);
         if (total == 0) continue;
         any = true;
-        if (total <= kRowList) {
-            const int at = incl - c;
-            for (int e = 0; e < c; ++e) list[at + e] = (uint32_t)t * kSortTile + (comp_sorted[(int64_t)t * kSortTile + o + e] & 1023u);
-            // the team's lanes run in lockstep inside one wave: the list is complete for every lane once all have stored
-            __builtin_amdgcn_wave_barrier();
-            for (int i = 0; i < total; i += 8) {
-                uint32_t sp[8];
-                const int m = total - i < 8 ? total - i : 8;
-#pragma unroll
-                for (int f = 0; f < 8; ++f) sp[f] = f < m ? list[i + f] : 0u;
-                add_rows(sp, m);
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            for (int j = 0; j < T; ++j) {                          // a row that fills tiles: tile by tile, eight per trip
+        if (total > kRowList) {                                  // a row that fills tiles: one tile's segment at a time
+            if (filled) { flush(filled); filled = 0; }
+            for (int j = 0; j < T; ++j) {
                 const int cj = __shfl(c, j, T), oj = __shfl(o, j, T);
                 const int64_t tb = (int64_t)(t0 + j) * kSortTile;
-                for (int i = 0; i < cj; i += 8) {
+                if (cj <= kLongSeg) {                            // short segment: unordered, through the list
+                    for (int e = lane; e < cj; e += T) list[e] = pos_grouped[tb + oj + e];
+                    if (cj) flush(cj);
+                    continue;
+                }
+                for (int i0 = 0; i0 < cj; i0 += 8) {             // long segment: S1 left it in ascending order
                     uint32_t sp[8];
-                    const int m = cj - i < 8 ? cj - i : 8;
+                    const int m = cj - i0 < 8 ? cj - i0 : 8;
 #pragma unroll
-                    for (int f = 0; f < 8; ++f) sp[f] = f < m ? (uint32_t)tb + (comp_sorted[tb + oj + i + f] & 1023u) : 0u;
+                    for (int f = 0; f < 8; ++f) sp[f] = f < m ? pos_grouped[tb + oj + i0 + f] : 0u;
                     add_rows(sp, m);
                 }
             }
+            continue;
         }
+        if (filled + total > kRowList) { flush(filled); filled = 0; }
+        const int at = filled + incl - c;
+        for (int e = 0; e < c; ++e) list[at + e] = pos_grouped[(int64_t)t * kSortTile + o + e];
+        filled += total;
     }
+    if (filled) flush(filled);
     if (!any) return;
     Row<NV> g = load_row<T, NV, FULL>(grad, r, D, lane);
 #pragma unroll
