@@ -83,6 +83,20 @@ int32_t wr_bprmf_plan_build_i32(const int32_t *u, const int32_t *p, const int32_
                                 int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
                                 void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Small batches (batch_size <= wr_bprmf_plan_small_max_batch() = 4,096; the reference's default is 2,048): the plan of a
+ * batch is built by ONE workgroup in LDS (two bitonic sorts of unique composites), one launch for all batches, no workspace,
+ * nothing to read back but err_flag — the builder of the LightGCN step (a plan per optimizer step, hipGraph-capturable).
+ * Arrays identical to wr_bprmf_plan_build_*'s, bit for bit. */
+int64_t wr_bprmf_plan_small_max_batch(void);
+int32_t wr_bprmf_plan_build_small_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                      int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                      void *stream);
+int32_t wr_bprmf_plan_build_small_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                      int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                      void *stream);
+
 /* Hand-written builder producing bit-identical plan arrays: bucket scatter + per-bucket LDS bitonic sort (one HBM
  * round trip per pair instead of the radix sort's four).  Applies when wr_bprmf_plan_fast_workspace_bytes(...) > 0
  * (batch sizes up to ~1 M, any table size).  flags: int32[2] on device, caller-zeroed; flags[0] = index out of range (as err_flag

@@ -609,3 +609,27 @@ def test_pipelined_sgd_switches_to_the_bucket_map_on_skewed_ids(ops, dev):
     l_ref = ref.run_sgd(plan, 0, nbat, 0.05)
     assert torch.equal(ref.U, Ud) and torch.equal(ref.I, Id) and torch.equal(l_ref, losses)
     ops._FAST_BACKOFF.clear()
+
+
+@pytest.mark.parametrize("B,nbat,nU,nI,short", [(2048, 3, 900, 1500, 100), (4096, 2, 100000, 50, 0), (512, 5, 40, 30, 511), (1, 3, 5, 5, 0),
+                                                (3000, 2, 5000, 7000, 1), (2048, 1, 6040, 3706, 0)])
+def test_small_single_launch_builder_agrees_bitwise(ops, dev, B, nbat, nU, nI, short):
+    """one workgroup per batch, LDS bitonic sorts: the arrays of the radix-sort builder, bit for bit (duplicates, short last
+    batch, non-power-of-two batches, int64 and int32 inputs)"""
+    rng = np.random.RandomState(B + nbat)
+    N = nbat * B - short
+    u, p, n = rng.randint(0, nU, N), rng.randint(0, nI, N), rng.randint(0, nI, N)
+    for cast in (np.int64, np.int32):
+        a = ops.BatchPlan(T(u.astype(cast), dev), T(p.astype(cast), dev), T(n.astype(cast), dev), B, nU, nI, keep_orig=True,
+                          builder="generic", hot=False)
+        b = ops.BatchPlan(T(u.astype(cast), dev), T(p.astype(cast), dev), T(n.astype(cast), dev), B, nU, nI, keep_orig=True,
+                          builder="small", hot=False)
+        assert b.builder == "small"
+        for x, y in ((a.tu, b.tu), (a.tp, b.tp), (a.tn, b.tn), (a.torig, b.torig), (a.oc_item, b.oc_item), (a.oc_src, b.oc_src)):
+            assert torch.equal(x, y)
+    _check_plan(b, u, p, n, B)
+    bad = u.copy(); bad[N // 2] = nU
+    with pytest.raises(IndexError):
+        ops.BatchPlan(T(bad, dev), T(p, dev), T(n, dev), B, nU, nI, builder="small", hot=False)
+    with pytest.raises(Exception):
+        ops.BatchPlan(T(u, dev), T(p, dev), T(n, dev), 5000, nU, nI, builder="small", hot=False)

@@ -24,6 +24,11 @@ SIGNATURES = {
                                         c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_plan_build_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_plan_small_max_batch": (c_i64, []),
+    "wr_bprmf_plan_build_small_i64": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                              c_vp, c_vp]),
+    "wr_bprmf_plan_build_small_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                              c_vp, c_vp]),
     "wr_bprmf_plan_fast_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "wr_bprmf_plan_fast_mapped_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64, c_i32, c_i32]),
     "wr_bprmf_plan_build_fast_mapped_i64": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -92,6 +92,124 @@ __global__ __launch_bounds__(kBlock) void plan_unpack_item(const Key *__restrict
     }
 }
 
+// ----------------------------------------------------------------------------------------------- small batches, one launch
+// For batches of at most kSmallBatch triplets (the reference's default batch is 2,048, BaseRunner.py:32) the whole plan of a
+// batch is built by ONE workgroup in LDS: bitonic sort of the (user << 32 | position) composites, then of the
+// (item << 32 | side << 31 | sorted index) composites — unique keys, so the result is the stable order the other builders
+// produce, bit for bit.  One launch instead of the ~20 of two device radix sorts, and nothing for the host to read back
+// besides the index-range flag: what the LightGCN step (a plan per optimizer step) and hipGraph capture need.
+constexpr int kSmallBatch = 4096;
+constexpr int kSmallThreads = 1024;
+
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long *__restrict__ a, int n_pow2) {
+    for (int size = 2; size <= n_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < n_pow2 / 2; t += kSmallThreads) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(const Idx *__restrict__ u, const Idx *__restrict__ p,
+                                                                    const Idx *__restrict__ nn, int64_t n, int64_t B,
+                                                                    int64_t n_users, int64_t n_items, int *__restrict__ tu,
+                                                                    int *__restrict__ tp, int *__restrict__ tn,
+                                                                    int *__restrict__ torig, int *__restrict__ oc_item,
+                                                                    int *__restrict__ oc_src, int *__restrict__ err) {
+    extern __shared__ unsigned long long keys[];         // 2 * P composites | sp[P] | sn[P] (ints)
+    const int64_t b = blockIdx.x, lo = b * B;
+    const int Bb = (int)((lo + B <= n) ? B : (n - lo));
+    int P = 1;
+    while (P < Bb) P <<= 1;
+    int *sp = reinterpret_cast<int *>(keys + 2 * P), *sn = sp + P;
+    for (int i = threadIdx.x; i < P; i += kSmallThreads) {
+        unsigned long long k = ~0ull;
+        if (i < Bb) {
+            int64_t uu = (int64_t)u[lo + i];
+            if (uu < 0 || uu >= n_users) {
+                if (err) *err = 1;
+                uu = 0;
+            }
+            k = ((unsigned long long)uu << 32) | (unsigned long long)(uint32_t)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    for (int t = threadIdx.x; t < Bb; t += kSmallThreads) {
+        const unsigned long long k = keys[t];
+        const int o = (int)(uint32_t)k;
+        int64_t pi = (int64_t)p[lo + o], ni = (int64_t)nn[lo + o];
+        if (pi < 0 || pi >= n_items || ni < 0 || ni >= n_items) {
+            if (err) *err = 1;
+            pi = (pi < 0 || pi >= n_items) ? 0 : pi;
+            ni = (ni < 0 || ni >= n_items) ? 0 : ni;
+        }
+        tu[lo + t] = (int)(k >> 32);
+        if (torig) torig[lo + t] = (int)(lo + o);
+        sp[t] = (int)pi;
+        sn[t] = (int)ni;
+    }
+    __syncthreads();
+    const int P2 = 2 * P;
+    for (int i = threadIdx.x; i < P2; i += kSmallThreads) {
+        unsigned long long k = ~0ull;
+        if (i < Bb) k = ((unsigned long long)(uint32_t)sp[i] << 32) | (unsigned long long)(uint32_t)i;
+        else if (i >= P && i - P < Bb) k = ((unsigned long long)(uint32_t)sn[i - P] << 32) | (1ull << 31) | (unsigned long long)(uint32_t)(i - P);
+        keys[i] = k;
+    }
+    __syncthreads();
+    bitonic_sort_lds(keys, P2);
+    for (int q = threadIdx.x; q < 2 * Bb; q += kSmallThreads) {
+        const unsigned long long k = keys[q];
+        const int item = (int)(k >> 32);
+        const uint32_t low = (uint32_t)k;
+        const int side = (int)(low >> 31), t = (int)(low & 0x7fffffffu);
+        oc_item[2 * lo + q] = item;
+        oc_src[2 * lo + q] = (t << 1) | side;
+        const bool shared = (q > 0 && (int)(keys[q - 1] >> 32) == item) || (q + 1 < 2 * Bb && (int)(keys[q + 1] >> 32) == item);
+        if (shared) {
+            if (side) sn[t] |= (int)0x80000000; else sp[t] |= (int)0x80000000;   // one writer per (triplet, side)
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Bb; t += kSmallThreads) {
+        tp[lo + t] = sp[t];
+        tn[lo + t] = sn[t];
+    }
+}
+
+template <typename Idx>
+static int32_t plan_build_small(const Idx *u, const Idx *p, const Idx *nn, int64_t n, int64_t B, int64_t n_users,
+                                int64_t n_items, int32_t *tu, int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item,
+                                int32_t *oc_src, int32_t *err_flag, void *stream_) {
+    WR_REQUIRE(u && p && nn, WR_E_NULL, "index arrays must not be NULL");
+    WR_REQUIRE(tu && tp && tn && oc_item && oc_src, WR_E_NULL, "plan output arrays must not be NULL");
+    WR_REQUIRE(n > 0 && n < (int64_t(1) << 31) && B > 0 && B <= kSmallBatch, WR_E_RANGE,
+               "small plan builder: batch size %lld (1..%d)", (long long)B, kSmallBatch);
+    WR_REQUIRE(n_users > 0 && n_users < (int64_t(1) << 31) && n_items > 0 && n_items < (int64_t(1) << 31), WR_E_SHAPE,
+               "small plan builder: table sizes out of range");
+    const int64_t nb = (n + B - 1) / B;
+    int P = 1;
+    while (P < (B < n ? B : n)) P <<= 1;
+    const size_t lds = (size_t)2 * P * 8 + (size_t)2 * P * 4;
+    if (lds > 64 * 1024) {
+        WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<Idx>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL((plan_small_kernel<Idx>), dim3((unsigned)nb), dim3(kSmallThreads), lds, reinterpret_cast<hipStream_t>(stream_),
+                       u, p, nn, n, B, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src, err_flag);
+    WR_LAUNCH_CHECK("plan_small_kernel");
+    return WR_OK;
+}
+
 constexpr int kHotRun = 32;     // must match wr_bpr.hip
 constexpr int kHotPiece = 256;
 
@@ -272,6 +390,24 @@ int32_t wr_bprmf_plan_hot_runs(const int32_t *keys, int32_t kind, int64_t n_trip
                        run_q, run_first, run_np, counts + (kind == 0 ? 0 : 2), 4);
     WR_LAUNCH_CHECK("plan_hot_runs_kernel");
     return WR_OK;
+}
+
+int64_t wr_bprmf_plan_small_max_batch(void) { return kSmallBatch; }
+
+int32_t wr_bprmf_plan_build_small_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                      int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                      void *stream) {
+    return plan_build_small<int64_t>(u, p, n, n_triplets, batch_size, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src,
+                                     err_flag, stream);
+}
+
+int32_t wr_bprmf_plan_build_small_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                      int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *err_flag,
+                                      void *stream) {
+    return plan_build_small<int32_t>(u, p, n, n_triplets, batch_size, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src,
+                                     err_flag, stream);
 }
 
 int64_t wr_bprmf_plan_workspace_bytes(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items) {

@@ -263,7 +263,8 @@ class BatchPlan:
     def __init__(self, u, p, n, batch_size, n_users, n_items, keep_orig=False, validate=True, ws_tag="plan", builder="auto",
                  hot=True, bucket_map=None, arena=None, defer=False, overlap=False):
         """builder: "auto" (default) = hand-written bucket/LDS-sort builder when applicable, generic radix-sort builder
-        otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one.
+        otherwise or when a bucket overflowed (skewed ids) — both emit identical arrays; "fast" / "generic" force one;
+        "small" = one workgroup per batch in LDS (batch_size <= 4,096), one launch, same arrays.
         bucket_map: a BucketMap of the epoch these batches come from — load-balanced buckets for the hand-written builder
         (skewed ids); ``fast_overflowed`` tells afterwards whether the hand-written builder was tried and gave up.
         arena: a PlanArena to build into (no allocation); defer: do not wait for the read-back (see finish());
@@ -330,6 +331,8 @@ class BatchPlan:
             builder = "generic"
             self.fast_overflowed = True
         self._builder_arg = builder
+        if builder == "small":
+            self._build_small()
         if builder in ("auto", "fast") and not self._build_fast():
             if builder == "fast":
                 raise abi.WhisprRecHipError("fast plan builder not applicable to this batch size")
@@ -381,6 +384,24 @@ class BatchPlan:
         if self._want_overlap:
             self._enqueue_overlap_marks()
         return True
+
+    def _build_small(self):
+        """one launch, one workgroup per batch (batch_size <= 4,096): nothing to read back but the index-range flag"""
+        L = abi.lib()
+        u, p, n = self._src
+        if self.batch_size > int(L.wr_bprmf_plan_small_max_batch()):
+            raise abi.WhisprRecHipError("small plan builder: batch size %d > %d" % (self.batch_size,
+                                                                                    L.wr_bprmf_plan_small_max_batch()))
+        fn = L.wr_bprmf_plan_build_small_i64 if u.dtype == torch.int64 else L.wr_bprmf_plan_build_small_i32
+        abi.check(fn(_p(u), _p(p), _p(n), self.n_triplets, self.batch_size, self.n_users, self.n_items, _p(self.tu), _p(self.tp),
+                     _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.err), _stream()),
+                  "wr_bprmf_plan_build_small")
+        self.builder = self._tried = "small"
+        if self._want_hot:
+            self._sides = self._hot_arrays(u.device)
+            self._enqueue_hot_runs()
+        if self._want_overlap:
+            self._enqueue_overlap_marks()
 
     def _build_generic(self):
         L = abi.lib()

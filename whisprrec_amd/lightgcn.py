@@ -224,7 +224,7 @@ def make_lightgcn(general_model_cls):
             # builder and the sequential run path need no host round trip besides the index check.
             tabs = hip_ops.BprmfTables(Ua, Ia)
             # indices already range-checked for the whole epoch (HipRunner): no per-batch read-back, the step never waits on the host
-            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="generic", hot=False,
+            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="small" if B <= 4096 else "generic", hot=False,
                                      validate=not getattr(self, "_trusted_indices", False))
             gOut = torch.zeros(nU + self.n_items, D, device=allE.device)
             tabs.grads(plan, 0, gOut[:nU], gOut[nU:])

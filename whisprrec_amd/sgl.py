@@ -268,7 +268,7 @@ def make_sgl(general_model_cls):
             gE0 += g1.propagate(gE1.contiguous(), L, transpose=True)
             gE0 += g2.propagate(gE2.contiguous(), L, transpose=True)
             # indices already range-checked for the whole epoch (HipRunner): no per-batch read-back, the step never waits on the host
-            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="generic", hot=False,
+            plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="small" if B <= 4096 else "generic", hot=False,
                                      validate=not getattr(self, "_trusted_indices", False))
             hip_ops.embloss_grad(U0, I0, plan, 0, sq, self.reg_weight, gE0[:nU], gE0[nU:])
             return loss, gE0
