@@ -464,6 +464,16 @@ int32_t wr_rank_eval(const float *user_mat, int64_t n_user_rows, const float *it
                      const int64_t *eval_user, const int64_t *eval_target, int64_t n, const int64_t *mask_ptr,
                      const int32_t *mask_idx, int32_t *rank, float *target_score, void *stream);
 
+/* LightGCN.predict's per-batch tail in two launches (src/models/general/LightGCN.py:156-175, src/utils/loss.py:37-39,94-98):
+ *   loss[0] = mean_b( -log(1e-10 + sigmoid(<Ua[u_b], Ia[p_b]> - <Ua[u_b], Ia[n_b]>)) )
+ *             + reg_weight * (||U0[u]||_F + ||I0[p]||_F + ||I0[n]||_F) / B
+ * with Ua / Ia the propagated tables and U0 / I0 the ego tables; sq3[3] receives the three sums of squares (the backward pass
+ * needs them: wr_embloss_grad).  Partials are folded in a fixed order: bitwise reproducible. */
+int64_t wr_lightgcn_loss_workspace_bytes(int64_t B);
+int32_t wr_lightgcn_loss(const float *user_all, const float *item_all, const float *user_ego, const float *item_ego,
+                         int64_t n_users, int64_t n_items, int32_t D, const int64_t *u, const int64_t *p, const int64_t *n,
+                         int64_t B, float reg_weight, float *loss, float *sq3, void *workspace, int64_t workspace_bytes,
+                         void *stream);
 /* Backward of EmbLoss for one planned batch: grad_user[u,:] += m_u * w/(B*sqrt(sq3[0])) * user_tab[u,:] for a user with m_u
  * triplets in the batch; grad_item[r,:] += (m_pos * w/(B*sqrt(sq3[1])) + m_neg * w/(B*sqrt(sq3[2]))) * item_tab[r,:].
  * tu / oc_item / oc_src are the plan arrays of that batch (oc_item must hold plain row ids), sq3 the device output of

@@ -98,6 +98,9 @@ SIGNATURES = {
     "wr_spmm_csr_chunked_modes": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_axpy": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_i32, c_vp]),
     "wr_rank_eval": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "wr_lightgcn_loss_workspace_bytes": (c_i64, [c_i64]),
+    "wr_lightgcn_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp,
+                                 c_i64, c_vp]),
     "wr_embloss_grad": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "wr_embloss_sumsq": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
 }

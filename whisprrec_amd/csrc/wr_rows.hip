@@ -665,6 +665,73 @@ __global__ __launch_bounds__(kBlock) void embloss_finish_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LightGCN loss, fused
+// LightGCN.predict's per-batch tail (reference src/models/general/LightGCN.py:156-175) in one pass over the batch: the BPR
+// terms on the PROPAGATED rows (two dots, -log(1e-10 + sigmoid)) and the squared norms of the three gathered EGO rows
+// (EmbLoss, loss.py:94-98); a one-workgroup second kernel folds the per-block partials in a fixed order into
+// loss = mean(term) + reg_weight * (||U0[u]||_F + ||I0[p]||_F + ||I0[n]||_F) / B   and keeps the three sums of squares for
+// the backward pass.  Two launches where bpr_fwd + finish_loss + embloss_sumsq + embloss_finish + five small tensor
+// operations were nine.
+template <int T, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void lightgcn_tail_fwd_kernel(const float *__restrict__ Ua, const float *__restrict__ Ia,
+                                                                    const float *__restrict__ U0, const float *__restrict__ I0,
+                                                                    int D, const int64_t *__restrict__ u,
+                                                                    const int64_t *__restrict__ p, const int64_t *__restrict__ n,
+                                                                    int B, float *__restrict__ partials, int n_blocks) {
+    __shared__ float scratch[kBlock / 64];
+    constexpr int TEAMS = kBlock / T;
+    const int lane = threadIdx.x % T;
+    const int b = blockIdx.x * TEAMS + threadIdx.x / T;
+    float term = 0.f, su = 0.f, sp = 0.f, sn = 0.f;
+    if (b < B) {
+        const int64_t ub = u[b], pb = p[b], nb = n[b];
+        const Row<NV> ua = load_row<T, NV, FULL>(Ua, ub, D, lane), pa = load_row<T, NV, FULL>(Ia, pb, D, lane),
+                      na = load_row<T, NV, FULL>(Ia, nb, D, lane);
+        const Row<NV> u0 = load_row<T, NV, FULL>(U0, ub, D, lane), p0 = load_row<T, NV, FULL>(I0, pb, D, lane),
+                      n0 = load_row<T, NV, FULL>(I0, nb, D, lane);
+        const float spos = team_sum<T>(dot_partial<NV>(ua, pa));
+        const float sneg = team_sum<T>(dot_partial<NV>(ua, na));
+        float tt, cc;
+        bpr_terms(spos, sneg, (float)B, tt, cc);
+        term = lane == 0 ? tt : 0.f;
+        su = dot_partial<NV>(u0, u0);
+        sp = dot_partial<NV>(p0, p0);
+        sn = dot_partial<NV>(n0, n0);
+    }
+    const float a = block_sum(term, scratch);
+    __syncthreads();
+    const float c = block_sum(su, scratch);
+    __syncthreads();
+    const float e = block_sum(sp, scratch);
+    __syncthreads();
+    const float f = block_sum(sn, scratch);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = a;
+        partials[n_blocks + blockIdx.x] = c;
+        partials[2 * n_blocks + blockIdx.x] = e;
+        partials[3 * n_blocks + blockIdx.x] = f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void lightgcn_tail_finish_kernel(const float *__restrict__ partials, int n_blocks, float B,
+                                                                       float reg_weight, float *__restrict__ loss,
+                                                                       float *__restrict__ sq3) {
+    __shared__ float scratch[kBlock / 64];
+    __shared__ float tot[4];
+    for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < n_blocks; i += kBlock) a += partials[j * n_blocks + i];
+        const float s = block_sum(a, scratch);
+        if (threadIdx.x == 0) tot[j] = s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sq3[0] = tot[1]; sq3[1] = tot[2]; sq3[2] = tot[3];
+        const float reg = (sqrtf(tot[1]) + sqrtf(tot[2]) + sqrtf(tot[3])) / B;
+        loss[0] = tot[0] / B + reg_weight * reg;
+    }
+}
+
 // Gradient of EmbLoss w.r.t. the gathered ego rows, accumulated per table row using a batch plan: every occurrence of row
 // r in block k contributes (reg_weight / (B * ||block_k||_F)) * row, so a run of m occurrences adds m times that.
 // side: 0 = user rows (runs of tu), 1 = item rows (runs of oc_item, positives and negatives have different norms).
@@ -985,6 +1052,37 @@ int32_t wr_embloss_sumsq(const float *user_tab, const float *item_tab, int32_t D
     WR_LAUNCH_CHECK("embloss_sumsq_kernel");
     hipLaunchKernelGGL(embloss_finish_kernel, dim3(1), dim3(kBlock), 0, stream, partials, nblk, sq3);
     WR_LAUNCH_CHECK("embloss_finish_kernel");
+    return WR_OK;
+}
+
+int64_t wr_lightgcn_loss_workspace_bytes(int64_t B) { return align_up(((B + 15) / 16 + 1) * 16, 256); }
+
+int32_t wr_lightgcn_loss(const float *user_all, const float *item_all, const float *user_ego, const float *item_ego,
+                         int64_t n_users, int64_t n_items, int32_t D, const int64_t *u, const int64_t *p, const int64_t *n,
+                         int64_t B, float reg_weight, float *loss, float *sq3, void *workspace, int64_t workspace_bytes,
+                         void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_all, n_users, D, "user_all")) != WR_OK) return rc;
+    if ((rc = check_table(item_all, n_items, D, "item_all")) != WR_OK) return rc;
+    if ((rc = check_table(user_ego, n_users, D, "user_ego")) != WR_OK) return rc;
+    if ((rc = check_table(item_ego, n_items, D, "item_ego")) != WR_OK) return rc;
+    WR_REQUIRE(u && p && n && loss && sq3, WR_E_NULL, "index arrays / outputs must not be NULL");
+    WR_REQUIRE(B > 0 && B <= (int64_t(1) << 29), WR_E_SHAPE, "B out of range");
+    const int tpb = teams_per_block_for(D);
+    const int nblk = (int)((B + tpb - 1) / tpb);
+    WR_REQUIRE(workspace && workspace_bytes >= (int64_t)nblk * 16, WR_E_WORKSPACE, "lightgcn loss workspace %lld B < %lld B",
+               (long long)workspace_bytes, (long long)nblk * 16);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    float *partials = reinterpret_cast<float *>(workspace);
+#define WR_CALL_LT(T_, NV_, FULL_)                                                                                         \
+    hipLaunchKernelGGL((lightgcn_tail_fwd_kernel<T_, NV_, FULL_>), dim3(nblk), dim3(kBlock), 0, stream, user_all, item_all,  \
+                       user_ego, item_ego, D, u, p, n, (int)B, partials, nblk)
+    WR_DISPATCH_D(D, WR_CALL_LT);
+#undef WR_CALL_LT
+    WR_LAUNCH_CHECK("lightgcn_tail_fwd_kernel");
+    hipLaunchKernelGGL(lightgcn_tail_finish_kernel, dim3(1), dim3(kBlock), 0, stream, partials, nblk, (float)B, reg_weight, loss,
+                       sq3);
+    WR_LAUNCH_CHECK("lightgcn_tail_finish_kernel");
     return WR_OK;
 }
 

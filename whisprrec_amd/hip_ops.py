@@ -1377,6 +1377,24 @@ def embloss_grad(user_tab, item_tab, plan, k, sq3, reg_weight, grad_user, grad_i
               "wr_embloss_grad")
 
 
+def lightgcn_loss(user_all, item_all, user_ego, item_ego, u, p, n, reg_weight):
+    """LightGCN.predict's per-batch tail (wr_lightgcn_loss): -> (loss tensor of shape (1,), sq3 tensor of the three EmbLoss
+    sums of squares)"""
+    u, p, n = _idx64(u, "u"), _idx64(p, "p"), _idx64(n, "n")
+    for t, nm in ((user_all, "user_all"), (item_all, "item_all"), (user_ego, "user_ego"), (item_ego, "item_ego")):
+        _req(t, torch.float32, nm, 2)
+    B, D = u.numel(), user_all.shape[1]
+    dev = user_all.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    sq3 = torch.empty(3, dtype=torch.float32, device=dev)
+    L = abi.lib()
+    ws = workspace(dev, "lgcn_loss").get(abi.check_size(L.wr_lightgcn_loss_workspace_bytes(B), "wr_lightgcn_loss_workspace_bytes"))
+    abi.check(L.wr_lightgcn_loss(_p(user_all), _p(item_all), _p(user_ego), _p(item_ego), user_all.shape[0], item_all.shape[0], D,
+                                 _p(u), _p(p), _p(n), B, float(reg_weight), _p(loss), _p(sq3), _p(ws), ws.numel(), _stream()),
+              "wr_lightgcn_loss")
+    return loss, sq3
+
+
 def embloss_sumsq(user_tab, item_tab, u, p, n):
     u, p, n = _idx64(u, "u"), _idx64(p, "p"), _idx64(n, "n")
     B, D = u.numel(), user_tab.shape[1]

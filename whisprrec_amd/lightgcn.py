@@ -208,11 +208,9 @@ def make_lightgcn(general_model_cls):
             E0 = torch.cat([U0, I0], dim=0)
             allE = self._propagate(E0)
             Ua, Ia = allE[:self.n_users], allE[self.n_users:]
-            mf = hip_ops.bpr_fwd(Ua, Ia, u, p, n, scores=False)["loss"]
-            sq = hip_ops.embloss_sumsq(U0, I0, u, p, n)
-            norms = torch.sqrt(sq)                                     # ||U[u]||_F, ||I[p]||_F, ||I[n]||_F
-            reg = norms.sum() / u.numel()
-            loss = (mf + self.reg_weight * reg).reshape(1)             # the reference returns shape (1,) (loss.py:94)
+            # BPR on the propagated rows + EmbLoss on the ego rows, folded to the (1,)-shaped loss of the reference
+            # (loss.py:94) on the device: two launches
+            loss, sq = hip_ops.lightgcn_loss(Ua, Ia, U0, I0, u, p, n, self.reg_weight)
             return loss, (allE, sq)
 
         def _backward(self, idx, saved):
