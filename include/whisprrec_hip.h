@@ -157,6 +157,20 @@ int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users
                                 const int32_t *clicked_idx, uint64_t seed, uint64_t epoch, int32_t *neg_items,
                                 int32_t *err_flag, void *stream);
 
+/* Sampler and shuffle fused, for a RANGE [first, first + count) of the epoch's output rows (batch order): output row i takes
+ * source row j = perm(i) of (users, items) and the negative wr_sample_negatives draws for row j — bit for bit the columns of
+ * wr_sample_negatives followed by wr_epoch_shuffle (same seed, epoch), no intermediate array.  out_* [count] receive rows
+ * first.. (the caller passes pointers to that position); order_out [count] (may be NULL) the source rows.  The step stream
+ * prepares plan chunk c+1's rows this way beside chunk c's steps (hip_ops.PipelinedSgd, `prep`). */
+int32_t wr_epoch_prepare_range_i64(const int64_t *users, const int64_t *items, int64_t n, int64_t n_users, int64_t n_items,
+                                   const int64_t *clicked_ptr, const int32_t *clicked_idx, uint64_t seed, uint64_t epoch,
+                                   int64_t first, int64_t count, int64_t *out_users, int64_t *out_pos, int64_t *out_neg,
+                                   int64_t *order_out, int32_t *err_flag, void *stream);
+int32_t wr_epoch_prepare_range_i32(const int32_t *users, const int32_t *items, int64_t n, int64_t n_users, int64_t n_items,
+                                   const int64_t *clicked_ptr, const int32_t *clicked_idx, uint64_t seed, uint64_t epoch,
+                                   int64_t first, int64_t count, int32_t *out_users, int32_t *out_pos, int32_t *out_neg,
+                                   int64_t *order_out, int32_t *err_flag, void *stream);
+
 /* Epoch shuffle on the device — the row order DataLoader(shuffle=True) gives an epoch (src/helpers/BaseRunner.py:188-193):
  * out_k[i] = col_k[perm(i)] for up to three index columns (NULL pairs are skipped), order_out[i] = perm(i) if not NULL.
  * perm is a keyed bijection of [0, n) evaluated per row (alternating Feistel network on ceil(log2 n) bits, splitmix64

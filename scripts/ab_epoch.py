@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Whole epoch on the device at BASELINE.json configs[1] (1M x 1M, D=64, B=65,536, 100 M interactions): negative sampling
+against the per-user clicked lists + shuffle + plans + steps.  (a) preparation up front (wr_sample_negatives, wr_epoch_shuffle,
+then the step stream), (b) preparation fused and pipelined (wr_epoch_prepare_range per plan chunk, beside the steps)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from whisprrec_amd import hip_ops
+dev = torch.device("cuda:0")
+n_inter = int(os.environ.get("WR_INTER", "100000000")); nU = nI = 1_000_000; D = 64; B = 65536
+g = torch.Generator(device=dev); g.manual_seed(3407)
+users = torch.randint(0, nU, (n_inter,), generator=g, device=dev, dtype=torch.int32)
+items = torch.randint(0, nI, (n_inter,), generator=g, device=dev, dtype=torch.int32)
+ptr, idx = hip_ops.clicked_csr_from_pairs(users, items, nU, nI)
+U = torch.randn(nU, D, generator=g, device=dev) * 0.001; I = torch.randn(nI, D, generator=g, device=dev) * 0.001
+pipe = hip_ops.PipelinedSgd(64)
+nb = (n_inter + B - 1) // B
+for mode in ("upfront", "pipelined"):
+    for epoch in (1, 2, 3):
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if mode == "upfront":
+            neg, err = hip_ops.sample_negatives(users, nU, nI, ptr, idx, 3407, epoch)
+            u, p, n = hip_ops.epoch_shuffle([users, items, neg], 3407, epoch)
+            pipe.run(pipe.plan(U, [(I, u, p, n)], B, lr=0.05), 0, 0.05, losses)
+        else:
+            prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch)
+            pipe.run(pipe.plan(U, [(I, prep.cols[0], prep.cols[1], prep.cols[2])], B, lr=0.05, prep=prep), 0, 0.05, losses)
+            prep.check()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"mode": mode, "epoch_ms": dt * 1e3, "triplets_per_s_epoch": n_inter / dt, "steps": nb,
+                      "loss_mean": float(losses.mean())}))

@@ -133,3 +133,71 @@ def test_epoch_shuffle_rejects_bad_arguments():
         hip_ops.epoch_shuffle([a.float()], 1, 1)
     with pytest.raises(ValueError):
         hip_ops.epoch_shuffle([], 1, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_fused_range_preparation_equals_sampler_then_shuffle(dtype):
+    """wr_epoch_prepare_range (shuffle + negatives fused, any range of output rows) = wr_sample_negatives followed by
+    wr_epoch_shuffle, bit for bit, and — through the oracle restatements of both — the reference's rule
+    (src/models/BaseModel.py:167-177, src/helpers/BaseRunner.py:188-193)"""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(3)
+    nU, nI, n = 300, 97, 20011
+    users = rng.randint(0, nU, n)
+    items = rng.randint(0, nI, n)
+    sets = {}
+    for a, b in zip(users, items):
+        sets.setdefault(int(a), set()).add(int(b))
+    sets[5] = set(range(1, nI - 2))                                  # a user who clicked almost everything: long redraw chains
+    ptr, idx = _csr(sets, nU)
+    tu, ti = torch.from_numpy(users).to(dev).to(dtype), torch.from_numpy(items).to(dev).to(dtype)
+    tptr, tidx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+    for epoch in (0, 3):
+        neg, _ = hip_ops.sample_negatives(tu, nU, nI, tptr, tidx, 3407, epoch)
+        (su, si, sn), order = hip_ops.epoch_shuffle([tu, ti, neg], 3407, epoch, want_order=True)
+        prep = hip_ops.EpochPrep(tu, ti, nU, nI, tptr, tidx, 3407, epoch, want_order=True)
+        for lo, hi in ((7000, 20011), (0, 1), (1, 7000)):           # ranges in any order, any cut
+            prep.fill(lo, hi)
+        torch.cuda.synchronize()
+        assert torch.equal(prep.cols[0], su) and torch.equal(prep.cols[1], si) and torch.equal(prep.cols[2], sn)
+        assert torch.equal(prep.order, order)
+        prep.check()
+        ref_neg = oracle.sample_negatives_counter(users, nI, ptr, idx, 3407, epoch)
+        perm = oracle.epoch_permutation(n, 3407, epoch)
+        assert np.array_equal(prep.cols[2].cpu().numpy().astype(np.int64), ref_neg[perm])
+        assert np.array_equal(prep.cols[0].cpu().numpy().astype(np.int64), users[perm])
+    bad = tu.clone(); bad[17] = nU
+    p2 = hip_ops.EpochPrep(bad, ti, nU, nI, tptr, tidx, 1, 0)
+    p2.fill(0, n)
+    with pytest.raises(IndexError):
+        p2.check()
+
+
+def test_pipelined_preparation_trains_the_same_epoch():
+    """PipelinedSgd with an EpochPrep (rows of plan chunk c+1 produced beside the steps of chunk c) = the same epoch with the
+    columns prepared up front: tables and losses bitwise equal"""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(4)
+    nU, nI, D, B, nb = 5000, 4000, 64, 2048, 13
+    n = nb * B - 77
+    users = rng.randint(0, nU, n).astype(np.int32); items = rng.randint(0, nI, n).astype(np.int32)
+    ptr, idx = hip_ops.clicked_csr_from_pairs(torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev), nU, nI)
+    U = (rng.standard_normal((nU, D)) * 0.1).astype(np.float32); I = (rng.standard_normal((nI, D)) * 0.1).astype(np.float32)
+    tu, ti = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev)
+    outs = []
+    for pipelined in (False, True):
+        Ud, Id = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev)
+        prep = hip_ops.EpochPrep(tu, ti, nU, nI, ptr, idx, 11, 2)
+        if not pipelined:
+            prep.fill(0, n)
+        pipe = hip_ops.PipelinedSgd(chunk=3, min_triplets=1)
+        h = pipe.plan(Ud, [(Id, prep.cols[0], prep.cols[1], prep.cols[2])], B, prep=prep if pipelined else None)
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        pipe.run(h, 0, 0.05, losses)
+        torch.cuda.synchronize()
+        prep.check()
+        assert prep.filled == n
+        outs.append((Ud, Id, losses))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

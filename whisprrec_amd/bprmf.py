@@ -252,9 +252,11 @@ def make_bprmf(general_model_cls):
 
         # ------------------------------------------------------------------ native epoch (used by HipRunner)
         @torch.no_grad()
-        def train_epoch(self, u, p, n, batch_size, lr, l2=0.0, optimizer="SGD", chunk=64):
+        def train_epoch(self, u, p, n, batch_size, lr, l2=0.0, optimizer="SGD", chunk=64, prep=None):
             """Runs one epoch over triplets already in batch order on the device; returns the per-batch losses
-            (device tensor), i.e. the list BaseRunner.fit averages (BaseRunner.py:200-201)."""
+            (device tensor), i.e. the list BaseRunner.fit averages (BaseRunner.py:200-201).  prep: a hip_ops.EpochPrep whose
+            ``cols`` are u, p, n — the columns are then produced chunk by chunk on the device (shuffle + negative sampling)
+            beside the steps instead of before them."""
             tabs = self._tables()
             N = u.numel()
             nb = (N + batch_size - 1) // batch_size
@@ -264,7 +266,7 @@ def make_bprmf(general_model_cls):
                 # stateless update: plans built on a side stream one chunk ahead of the steps, steps issued natively
                 if getattr(self, "_pipe", None) is None:
                     self._pipe = hip_ops.PipelinedSgd(chunk)
-                handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size, lr=lr)
+                handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size, lr=lr, prep=prep)
                 self._pipe.run(handle, 0, lr, losses)
                 return losses
             chunk = hip_ops.PipelinedSgd(chunk).chunk_batches(batch_size)   # small batches: more of them per plan
@@ -273,10 +275,13 @@ def make_bprmf(general_model_cls):
             while done < nb:
                 c = min(chunk, nb - done)
                 lo, hi = done * batch_size, min(N, (done + c) * batch_size)
+                if prep is not None:
+                    prep.fill(lo, hi)
                 plan = hip_ops.BatchPlan(u[lo:hi], p[lo:hi], n[lo:hi], batch_size, self.user_num, self.item_num,
                                          bucket_map=bmap or None)
                 if plan.fast_overflowed:
-                    bmap = hip_ops.BucketMap(u, p, self.user_num, self.item_num, batch_size) if bmap is None else False
+                    src = (prep.users, prep.items) if prep is not None else (u, p)
+                    bmap = hip_ops.BucketMap(src[0], src[1], self.user_num, self.item_num, batch_size) if bmap is None else False
                 if optimizer in ("SGD", "Adam"):
                     if opt is None or opt.name != optimizer or opt.lr != float(lr) or opt.l2 != float(l2):
                         if opt is not None and opt.adam_step > 0 and opt.name == optimizer:

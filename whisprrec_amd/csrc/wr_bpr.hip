@@ -24,6 +24,13 @@
 #include "wr_common.h"
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: stop events attached to a dispatch (timing hooks of launch_step)
 
+#ifndef WR_USER_TWO
+#define WR_USER_TWO 0
+#endif
+#ifndef WR_USER_WAVES
+#define WR_USER_WAVES 8      // waves per SIMD the headline instantiation of the user phase is held to (64 VGPRs)
+#endif
+
 namespace wr {
 
 constexpr int kHotRun = 32;     // an item row with more occurrences than this in one batch is "hot" (must match wr_plan.hip)
@@ -287,7 +294,7 @@ __device__ __forceinline__ void finish_user_row(float *__restrict__ U, float *__
 //      rewriting, so this launch may run beside that item phase;
 //   2  the heads listed in `dlist` (the deferred runs: positions in ascending order), one team each.
 template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT, int DEF = 0>
-__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? 8 : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
+__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? WR_USER_WAVES : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
                                                             const int *__restrict__ tn, int B, float lr, float l2,
                                                             float *__restrict__ Z, float *__restrict__ partials,
@@ -309,6 +316,11 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
     // trips in a row before the first row load is issued, and a workgroup's lifetime is what bounds the bytes in flight.
     int t0[SLOTS], uu[SLOTS], unext[SLOTS], praw0[SLOTS], nraw0[SLOTS];
     bool head[SLOTS];
+#if WR_USER_TWO
+    // second triplet of the run (97 % of the multi-triplet runs have exactly two): its indices come with the first batch of
+    // index loads and its rows with the first batch of row loads, instead of two more dependent round trips behind the first body
+    int praw1[SLOTS], nraw1[SLOTS], unext2[SLOTS];
+#endif
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         t0[s] = team + s * seg;
@@ -323,6 +335,12 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
                 const int t = dlist[team];
                 t0[s] = t;
                 const int u = tu[t], un = tu[min(t + 1, B - 1)];
+#if WR_USER_TWO
+                const int un2 = tu[min(t + 2, B - 1)];
+                praw1[s] = tp[min(t + 1, B - 1)];
+                nraw1[s] = tn[min(t + 1, B - 1)];
+                unext2[s] = (t + 2 < B) ? un2 : ~u;
+#endif
                 praw0[s] = tp[t];
                 nraw0[s] = tn[t];
                 uu[s] = u;
@@ -334,6 +352,12 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
             const int u = tu[t], uprev = tu[max(t - 1, 0)], un = tu[min(t + 1, B - 1)];
             const int uhot = SKIP_HOT ? tu[min(t + kHotRun, B - 1)] : 0;
             const int dm = DEF == 1 ? dmask[t >> 5] : 0;
+#if WR_USER_TWO
+            const int un2 = tu[min(t + 2, B - 1)];
+            praw1[s] = tp[min(t + 1, B - 1)];
+            nraw1[s] = tn[min(t + 1, B - 1)];
+            unext2[s] = (t + 2 < B) ? un2 : ~u;
+#endif
             praw0[s] = tp[t];
             nraw0[s] = tn[t];
             uu[s] = u;
@@ -345,6 +369,9 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
         }
     }
     Row<NV> ur[SLOTS], pr0[SLOTS], nr0[SLOTS];
+#if WR_USER_TWO
+    Row<NV> pr1[SLOTS], nr1[SLOTS];
+#endif
     Moments<NV, MODE == 4> umv[SLOTS], pmv0[SLOTS], nmv0[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -359,6 +386,12 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
                 ur[s] = load_row<T, NV, FULL>(U, uu[s], D, lane);
                 pr0[s] = load_row<T, NV, FULL>(I, praw0[s] & 0x7fffffff, D, lane);
                 nr0[s] = load_row<T, NV, FULL>(I, nraw0[s] & 0x7fffffff, D, lane);
+#if WR_USER_TWO
+                if (unext[s] == uu[s]) {
+                    pr1[s] = load_row<T, NV, FULL>(I, praw1[s] & 0x7fffffff, D, lane);
+                    nr1[s] = load_row<T, NV, FULL>(I, nraw1[s] & 0x7fffffff, D, lane);
+                }
+#endif
             }
         }
     }
@@ -379,6 +412,16 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
                                             term_acc, ad, pmv, nmv);
             if (!more) break;
             ++t;   // next triplet of this user (nothing is kept live across the body: 8 waves per SIMD, no spill)
+#if WR_USER_TWO
+            if (MODE != 4 && t == t0[s] + 1) {   // the run's second triplet: indices and rows are already here
+                praw = praw1[s];
+                nraw = nraw1[s];
+                more = unext2[s] == u;
+                pr = pr1[s];
+                nr = nr1[s];
+                continue;
+            }
+#endif
             praw = tp[t];
             nraw = tn[t];
             more = (t + 1 < B) && (tu[t + 1] == u);

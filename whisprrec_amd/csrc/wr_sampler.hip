@@ -132,6 +132,67 @@ static int32_t epoch_shuffle(const Idx *c0, const Idx *c1, const Idx *c2, int64_
     return WR_OK;
 }
 
+// ----------------------------------------------------------------------------------------------- fused, by range
+// Sampler and shuffle in one pass over a RANGE of the epoch's output rows: output row i takes source row j = perm(i) and the
+// negative wr_sample_negatives would have drawn for row j (the generator is keyed by the source row) — bit for bit the
+// columns of wr_sample_negatives followed by wr_epoch_shuffle, without the intermediate negatives array, and chunk by
+// chunk: the step stream prepares the rows of plan chunk c+1 on the plan stream while chunk c trains.
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void epoch_prepare_range_kernel(const Idx *__restrict__ users, const Idx *__restrict__ items,
+                                                                      int64_t n, int64_t n_users, uint32_t n_items,
+                                                                      const int64_t *__restrict__ ptr, const int *__restrict__ idx,
+                                                                      uint64_t seed, uint64_t epoch, unsigned bits, uint64_t key,
+                                                                      int64_t first, int64_t count, Idx *__restrict__ out_u,
+                                                                      Idx *__restrict__ out_p, Idx *__restrict__ out_n,
+                                                                      int64_t *__restrict__ order, int *__restrict__ err) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const int64_t j = (int64_t)shuffle_index((uint64_t)(first + k), (uint64_t)n, bits, key);
+    const Idx uj = users[j];
+    int64_t u = (int64_t)uj;
+    if (u < 0 || u >= n_users) {
+        if (err) *err = 1;
+        u = 0;
+    }
+    const int64_t lo = ptr[u], hi = ptr[u + 1];
+    uint32_t attempt = 0;
+    uint32_t cand = draw_item(seed, epoch, (uint64_t)j, attempt, n_items);
+    while (clicked(idx, lo, hi, (int)cand)) {
+        if (++attempt < kMaxAttempts) {
+            cand = draw_item(seed, epoch, (uint64_t)j, attempt, n_items);
+        } else {
+            cand = (cand + 1u >= n_items) ? 1u : cand + 1u;
+            if (attempt >= kMaxAttempts + n_items) {
+                if (err) *err = 2;
+                break;
+            }
+        }
+    }
+    out_u[k] = uj;
+    out_p[k] = items[j];
+    out_n[k] = (Idx)cand;
+    if (order) order[k] = j;
+}
+
+template <typename Idx>
+static int32_t epoch_prepare_range(const Idx *users, const Idx *items, int64_t n, int64_t n_users, int64_t n_items,
+                                   const int64_t *clicked_ptr, const int32_t *clicked_idx, uint64_t seed, uint64_t epoch,
+                                   int64_t first, int64_t count, Idx *out_u, Idx *out_p, Idx *out_n, int64_t *order,
+                                   int32_t *err_flag, void *stream) {
+    WR_REQUIRE(users && items && clicked_ptr && clicked_idx && out_u && out_p && out_n, WR_E_NULL, "epoch prepare: NULL argument");
+    WR_REQUIRE(n > 0 && n < (int64_t(1) << 62) && n_users > 0 && n_items >= 2 && n_items < (int64_t(1) << 31), WR_E_SHAPE,
+               "epoch prepare: bad sizes");
+    WR_REQUIRE(first >= 0 && count >= 0 && first + count <= n, WR_E_RANGE, "epoch prepare: rows [%lld,%lld) outside the epoch's %lld",
+               (long long)first, (long long)(first + count), (long long)n);
+    if (count == 0) return WR_OK;
+    const uint64_t key = mix64(mix64(seed ^ (epoch * 0x9E3779B97F4A7C15ull)) ^ 0x5DEECE66Dull);
+    hipLaunchKernelGGL((epoch_prepare_range_kernel<Idx>), dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), users, items, n, n_users, (uint32_t)n_items, clicked_ptr, clicked_idx,
+                       seed, epoch, shuffle_bits(n), key, first, count, out_u, out_p, out_n, order, err_flag);
+    WR_LAUNCH_CHECK("epoch_prepare_range_kernel");
+    return WR_OK;
+}
+
 }  // namespace wr
 
 using namespace wr;
@@ -162,6 +223,22 @@ int32_t wr_sample_negatives_i32(const int32_t *users, int64_t n, int64_t n_users
                        seed, epoch, neg_items, err_flag);
     WR_LAUNCH_CHECK("sample_negatives_kernel");
     return WR_OK;
+}
+
+int32_t wr_epoch_prepare_range_i64(const int64_t *users, const int64_t *items, int64_t n, int64_t n_users, int64_t n_items,
+                                   const int64_t *clicked_ptr, const int32_t *clicked_idx, uint64_t seed, uint64_t epoch,
+                                   int64_t first, int64_t count, int64_t *out_users, int64_t *out_pos, int64_t *out_neg,
+                                   int64_t *order_out, int32_t *err_flag, void *stream) {
+    return epoch_prepare_range<int64_t>(users, items, n, n_users, n_items, clicked_ptr, clicked_idx, seed, epoch, first, count,
+                                        out_users, out_pos, out_neg, order_out, err_flag, stream);
+}
+
+int32_t wr_epoch_prepare_range_i32(const int32_t *users, const int32_t *items, int64_t n, int64_t n_users, int64_t n_items,
+                                   const int64_t *clicked_ptr, const int32_t *clicked_idx, uint64_t seed, uint64_t epoch,
+                                   int64_t first, int64_t count, int32_t *out_users, int32_t *out_pos, int32_t *out_neg,
+                                   int64_t *order_out, int32_t *err_flag, void *stream) {
+    return epoch_prepare_range<int32_t>(users, items, n, n_users, n_items, clicked_ptr, clicked_idx, seed, epoch, first, count,
+                                        out_users, out_pos, out_neg, order_out, err_flag, stream);
 }
 
 int32_t wr_epoch_shuffle_i64(const int64_t *col0, const int64_t *col1, const int64_t *col2, int64_t n, uint64_t seed,

@@ -734,6 +734,48 @@ def epoch_shuffle(cols, seed, epoch, want_order=False):
     return (outs, order) if want_order else outs
 
 
+class EpochPrep:
+    """The epoch's (user, positive, negative) columns in batch order, produced RANGE BY RANGE on the device
+    (wr_epoch_prepare_range: keyed shuffle + negative sampling fused; same columns as sample_negatives + epoch_shuffle).
+    ``cols`` are the epoch-sized output arrays; ``fill(lo, hi)`` enqueues rows [lo, hi) on the current stream.  PipelinedSgd
+    calls it for each plan chunk right before that chunk's plan build, on the plan stream: the preparation of chunk c+1 runs
+    beside the steps of chunk c."""
+
+    def __init__(self, users, items, n_users, n_items, clicked_ptr, clicked_idx, seed, epoch, want_order=False):
+        if users.dtype not in (torch.int64, torch.int32) or items.dtype != users.dtype:
+            raise TypeError("users / items must both be int64 or int32")
+        self.users = _req(users.contiguous(), users.dtype, "users", 1)
+        self.items = _req(items.contiguous(), users.dtype, "items", 1)
+        if self.items.numel() != self.users.numel():
+            raise ValueError("users / items must have the same length")
+        _req(clicked_ptr, torch.int64, "clicked_ptr", 1)
+        _req(clicked_idx, torch.int32, "clicked_idx", 1)
+        self.ptr, self.idx = clicked_ptr, clicked_idx
+        self.n, self.n_users, self.n_items = users.numel(), int(n_users), int(n_items)
+        self.seed, self.epoch = int(seed), int(epoch)
+        self.cols = [torch.empty_like(self.users) for _ in range(3)]
+        self.order = torch.empty(self.n, dtype=torch.int64, device=users.device) if want_order else None
+        self.err = torch.zeros(1, dtype=torch.int32, device=users.device)
+        self.filled = 0
+
+    def fill(self, lo, hi):
+        lo, hi = int(lo), min(int(hi), self.n)
+        if hi <= lo:
+            return
+        es = self.users.element_size()
+        fn = abi.lib().wr_epoch_prepare_range_i64 if self.users.dtype == torch.int64 else abi.lib().wr_epoch_prepare_range_i32
+        abi.check(fn(_p(self.users), _p(self.items), self.n, self.n_users, self.n_items, _p(self.ptr), _p(self.idx), self.seed,
+                     self.epoch, lo, hi - lo, self.cols[0].data_ptr() + es * lo, self.cols[1].data_ptr() + es * lo,
+                     self.cols[2].data_ptr() + es * lo, None if self.order is None else self.order.data_ptr() + 8 * lo,
+                     _p(self.err), _stream()), "wr_epoch_prepare_range")
+        self.filled = max(self.filled, hi)
+
+    def check(self):
+        """after the epoch (one read-back): nn.Embedding would have raised IndexError for an out-of-range user id"""
+        if int(self.err.item()) == 1:
+            raise IndexError("user id out of range in the training frame")
+
+
 def clicked_csr_from_pairs(users, items, n_users, n_items):
     """device (user, item) interaction pairs -> device CSR of each user's distinct items, ascending (the layout
     wr_sample_negatives and wr_rank_eval take).  One-off setup: torch sort/unique glue."""
@@ -869,7 +911,7 @@ class PipelinedSgd:
             self._arenas[key] = pair
         return pair
 
-    def plan(self, U, segments, batch, first_chunk=None, lr=None):
+    def plan(self, U, segments, batch, first_chunk=None, lr=None, prep=None):
         """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order.
         Only the last segment may end with a short batch.  first_chunk: batches in the first plan, or a list with the sizes
         of the first few plans (default: full chunks) — lets a caller that consumes the stream piecewise (bench.py: warm-up,
@@ -903,7 +945,7 @@ class PipelinedSgd:
             a.release_after(main)
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
-             "overlap": use_overlap,
+             "overlap": use_overlap, "prep": prep,
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
         if use_overlap:
             self._capture_graphs(h, segs[0]["tabs"], lr)
@@ -974,6 +1016,8 @@ class PipelinedSgd:
         lo, hi = first * B, min(h["u"].numel(), (first + c) * B)
         with torch.cuda.stream(self.plan_stream):
             bmap = h["map"] if h["map"] else None
+            if h["prep"] is not None:
+                h["prep"].fill(lo, hi)       # this chunk's rows: shuffle + negatives, on the plan stream, before its plan
             plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
                                       validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap, arena=h["arenas"][h["tag"]],
                                       defer=True, overlap=h["overlap"])
@@ -997,7 +1041,10 @@ class PipelinedSgd:
                 h["map"] = False
             elif h["map"] is None:
                 with torch.cuda.stream(self.plan_stream):
-                    h["map"] = self.ops.BucketMap(h["u"], h["p"], h["n_users"], h["n_items"], h["B"])
+                    # row shares from the whole epoch: with a pipelined preparation the batch-order columns are not
+                    # complete yet, the source columns have the same rows in another order
+                    src = (h["prep"].users, h["prep"].items) if h["prep"] is not None else (h["u"], h["p"])
+                    h["map"] = self.ops.BucketMap(src[0], src[1], h["n_users"], h["n_items"], h["B"])
         h["cur"], h["next"] = cur, None
         return cur
 

@@ -279,7 +279,7 @@ def make_hip_runner(base_runner_cls):
             self.seed = int(getattr(args, "random_seed", 3407))
             self._epoch_cache = None
 
-        def _device_epoch(self, dataset, dev, epoch):
+        def _device_epoch(self, dataset, dev, epoch, pipelined=False):
             """negatives (wr_sample_negatives) + shuffle, all on the device: no Python loop over rows"""
             from . import hip_ops
             model, corpus = dataset.model, dataset.corpus
@@ -289,16 +289,20 @@ def make_hip_runner(base_runner_cls):
                 ptr, idx = hip_ops.clicked_csr(corpus.train_clicked_set, model.user_num, dev)
                 self._epoch_cache = (dataset, users, items, ptr, idx)
             _, users, items, ptr, idx = self._epoch_cache
-            neg, err = hip_ops.sample_negatives(users, model.user_num, model.item_num, ptr, idx, self.seed, max(epoch, 0))
-            # the epoch's row order: a keyed bijection evaluated per row (wr_epoch_shuffle) — no 100 M-key sort as in
-            # torch.randperm, no order array unless the per-row histories of a sequential dataset have to follow it
+            # the epoch's rows in batch order: a keyed bijection of the rows (no 100 M-key sort as in torch.randperm) and the
+            # negative of every row, fused and produced range by range (wr_epoch_prepare_range) — a model with a native epoch
+            # loop gets the EpochPrep itself and fills each plan chunk's rows beside the previous chunk's steps
             sequential = "position" in dataset.data
-            cols = hip_ops.epoch_shuffle([users, items, neg], self.seed, max(epoch, 0), want_order=sequential)
+            prep = hip_ops.EpochPrep(users, items, model.user_num, model.item_num, ptr, idx, self.seed, max(epoch, 0),
+                                     want_order=sequential)
+            self._epoch_prep = prep
+            if pipelined:
+                return prep
+            prep.fill(0, prep.n)
             if sequential:
-                cols, self._last_order = cols
-            if int(err.item()) == 1:
-                raise IndexError("user id out of range in the training frame")
-            return cols
+                self._last_order = prep.order
+            prep.check()
+            return prep.cols
 
         def evaluate(self, dataset, topks, metrics):
             """Full-ranking evaluation on the device when the model exposes its factor matrices (``eval_factors``): ranks
@@ -425,6 +429,13 @@ def make_hip_runner(base_runner_cls):
             dev = next(model.parameters()).device
             model.train()
             if hasattr(model, "train_epoch") and self.optimizer_name in ("SGD", "Adam"):
+                if self.device_epoch_prep and not sequential:
+                    prep = self._device_epoch(dataset, dev, epoch, pipelined=True)
+                    losses = model.train_epoch(prep.cols[0], prep.cols[1], prep.cols[2], self.batch_size, self.learning_rate,
+                                               float(self.l2), self.optimizer_name, prep=prep)
+                    out = float(np.mean(losses.cpu().numpy()))
+                    prep.check()
+                    return out
                 cols = self._epoch_columns(dataset, dev, epoch)
                 losses = model.train_epoch(cols[0], cols[1], cols[2], self.batch_size, self.learning_rate, float(self.l2),
                                            self.optimizer_name)
