@@ -194,13 +194,20 @@ class RotatingBprmf:
         (or by complete_rotation / gather_full) — in a long run the hand-over of a stratum's last part hides behind the next
         stratum's first part; a caller that cuts the run into pieces (bench.py: warm-up, timed steps) keeps that overlap
         across its pieces this way instead of ending each piece on an exposed transfer."""
-        self.complete_rotation()
+        return self.run_prepared(self.prepare(strata, batch, part_relative), lr, defer_last=defer_last)
+
+    def prepare(self, strata, batch, part_relative=False):
+        """Index-side preparation of run_strata — segments, and the local runner's plan handle with the plan of the first
+        chunk already queued (a plan depends on the indices only).  Does not touch the ring: a hand-over left pending by
+        the previous call (defer_last) is accounted for (the strata start on the block that hand-over brings in) and is
+        carried out by run_prepared.  Lets a caller build the first plan of a piece of work outside that piece's timed
+        region, the way every later plan is built beside steps."""
         B = int(batch)
-        # the global batch is the union of the G local batches: its mean loss has 1/(G*B) coefficients.  The local kernels
-        # use 1/B, and the local batches touch disjoint rows, so dividing the learning rate by G gives the same update.
-        lr = lr / self.world
-        bufs = (self.I, self.I_in)                      # stratum r trains on bufs[r % 2] (the rotation swaps them)
-        segments, counts, held = [], [], self.held
+        pending = self._deferred is not None and self.world > 1
+        # stratum r trains on bufs[r % 2] (every rotation swaps I and I_in; a pending one swaps them before stratum 0)
+        bufs = (self.I_in, self.I) if pending else (self.I, self.I_in)
+        held = (self.held + 1) % self.world if pending else self.held
+        segments, counts = [], []
         for r, (u, p, n, steps_per_part) in enumerate(strata):
             per_part = [int(steps_per_part[k]) if k < len(steps_per_part) else 0 for k in range(self.parts)]
             table = bufs[r % 2] if self.world > 1 else self.I
@@ -213,8 +220,20 @@ class RotatingBprmf:
                 first += st
             counts.append(per_part)
             held = (held + 1) % self.world
-        losses = torch.zeros(sum(sum(c) for c in counts), dtype=torch.float32, device=self.device)
         handle = self.local.plan(self.U, segments, B)
+        return {"handle": handle, "counts": counts, "B": B, "pending": pending}
+
+    def run_prepared(self, prep, lr, n_strata=None, defer_last=False):
+        """the steps of the first n_strata strata (default: all) of a prepare()d schedule; see run_strata"""
+        if prep["pending"] != (self._deferred is not None and self.world > 1):
+            raise RuntimeError("the ring's state changed between prepare() and run_prepared()")
+        self.complete_rotation()
+        # the global batch is the union of the G local batches: its mean loss has 1/(G*B) coefficients.  The local kernels
+        # use 1/B, and the local batches touch disjoint rows, so dividing the learning rate by G gives the same update.
+        lr = lr / self.world
+        counts = prep["counts"] if n_strata is None else prep["counts"][:n_strata]
+        handle = prep["handle"]
+        losses = torch.zeros(sum(sum(c) for c in counts), dtype=torch.float32, device=self.device)
         first, seg = 0, 0
         for si, per_part in enumerate(counts):
             last_stratum = si == len(counts) - 1
@@ -274,7 +293,7 @@ def bench_run(args, rank, world, dev):
     S = stratum_steps(args.interactions, world, B)
     from .hip_ops import PipelinedSgd
     chunk = args.chunk if args.chunk > 0 else max(1, min(64, K))
-    model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts, local=PipelinedSgd(chunk))
+    model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts, local=PipelinedSgd(chunk, min_triplets=1))
     model.init_xavier(3407)
     g = torch.Generator(device=dev)
     g.manual_seed(3407 * 7919 + rank)
@@ -310,23 +329,25 @@ def bench_run(args, rank, world, dev):
             sched.append((u_all[first:at], p_all[first:at], n_all[first:at], per_part))
         return sched, held
 
-    def run_schedule(sched):
-        # the hand-over of the last part is left to the next call: it then runs beside that call's first part, as it would
-        # beside the next stratum's first part in one long run (the timed region takes over the warm-up's pending hand-over
-        # and leaves its own one pending: one rotation's worth of transfers per stratum inside the timed region)
-        return model.run_strata(sched, B, args.lr, part_relative=True, defer_last=True)
-
+    # Same shape as the N=1 bench.  The hand-over of a piece's last part is left to the next piece (defer_last): it then runs
+    # beside that piece's first part, as it would beside the next stratum's first part in one long run — the timed region
+    # takes over the warm-up's pending hand-over and leaves its own pending.  The timed piece's index work is prepare()d
+    # before the clock starts (its first plan is built outside the region, like every plan but a run's first is built beside
+    # steps), with one spare stratum of `chunk` steps behind it that is planned — inside the region, beside the last timed
+    # steps — but never trained: K steps' worth of plan builds between the two timestamps, K steps trained.
     warm, held_after = make_schedule(W, model.held)
-    timed, _ = make_schedule(K, held_after)
+    timed, held_after = make_schedule(K, held_after)
+    spare, _ = make_schedule(min(chunk, S), held_after)
     torch.cuda.synchronize()
 
     if W > 0:
-        run_schedule(warm)
+        model.run_strata(warm, B, args.lr, part_relative=True, defer_last=True)
+    prepared = model.prepare(timed + spare, B, part_relative=True)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    local_losses = run_schedule(timed)
+    local_losses = model.run_prepared(prepared, args.lr, n_strata=len(timed), defer_last=True)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
