@@ -28,6 +28,8 @@ import time
 
 # dmabuf IPC only on this pool's hosts: RCCL / cross-process tensor sharing fails without it (set before HIP initialises)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION: keep stdout to the one JSON line unless the caller asks for more
+os.environ.setdefault("NCCL_DEBUG", "WARN")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
