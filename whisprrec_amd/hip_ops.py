@@ -205,6 +205,7 @@ class PlanArena:
         n_meta = BatchPlan.meta_len(self.max_batches)
         self.meta = torch.zeros(n_meta, **i32)
         self.meta_host = torch.zeros(n_meta, dtype=torch.int32, pin_memory=True)
+        self.meta_np = self.meta_host.numpy()      # the same pinned words as a NumPy view: cheap scalar reads on the step path
         self.hot_sides = None
         if hot:
             self.hot_sides = []
@@ -486,7 +487,8 @@ class BatchPlan:
         mh = None
         while self._tried in ("fast", "fast+map") or self._want_hot:
             mh = self._read_meta()
-            if self._tried in ("fast", "fast+map") and int(mh[1]) != 0:
+            overflow = int(self.arena.meta_np[1]) if self._pinned is not None else int(mh[1])
+            if self._tried in ("fast", "fast+map") and overflow != 0:
                 if self._builder_arg == "fast":
                     raise abi.WhisprRecHipError("fast plan builder: bucket overflow (skewed ids)")
                 self.fast_overflowed = True
@@ -504,7 +506,11 @@ class BatchPlan:
             self.builder = self._tried
         if self._want_hot:
             counts_host = mh[self.META_HEAD:self.META_HEAD + 4 * self.n_batches]
-            if int(counts_host.sum().item()) > 0:
+            if self._pinned is not None:
+                any_hot = bool(self.arena.meta_np[self.META_HEAD:self.META_HEAD + 4 * self.n_batches].any())
+            else:
+                any_hot = int(counts_host.sum().item()) > 0
+            if any_hot:
                 self.hot = {"sides": self._sides, "counts_host": counts_host}
         if self._want_overlap and self.hot is None:
             o, nb, cb = self.arena.overlap, self.n_batches, self._cap_batches
@@ -533,7 +539,8 @@ class BatchPlan:
         self.finish()
         if self.meta_host is None:
             self.meta_host = self._read_meta()
-        if int(self.meta_host[0].item()) != 0:
+        bad = int(self.arena.meta_np[0]) if self._pinned is not None else int(self.meta_host[0].item())
+        if bad != 0:
             raise IndexError("index out of range in batch (user_id >= n_users or item id >= n_items)")
 
     def batch_len(self, k):

@@ -335,13 +335,18 @@ def bench_run(args, rank, world, dev):
     # before the clock starts (its first plan is built outside the region, like every plan but a run's first is built beside
     # steps), with one spare stratum of `chunk` steps behind it that is planned — inside the region, beside the last timed
     # steps — but never trained: K steps' worth of plan builds between the two timestamps, K steps trained.
-    warm, held_after = make_schedule(W, model.held)
+    warm, held_after = make_schedule(W - W // 2, model.held)
+    warm2 = None
+    if W >= 2:
+        warm2, held_after = make_schedule(W // 2, held_after)
     timed, held_after = make_schedule(K, held_after)
     spare, _ = make_schedule(min(chunk, S), held_after)
     torch.cuda.synchronize()
 
     if W > 0:
         model.run_strata(warm, B, args.lr, part_relative=True, defer_last=True)
+        if W >= 2:      # in two pieces when it can be: every host path of a piece has then run twice before the clock starts
+            model.run_strata(warm2, B, args.lr, part_relative=True, defer_last=True)
     prepared = model.prepare(timed + spare, B, part_relative=True)
     torch.cuda.synchronize()
     dist.barrier()
