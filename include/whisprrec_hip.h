@@ -344,6 +344,20 @@ int32_t wr_bprmf_step_adam(float *user_tab, int64_t n_users, float *item_tab, in
                            const int32_t *tp, const int32_t *tn, const int32_t *oc_item, const int32_t *oc_src, int64_t B,
                            int64_t adam_step, float lr, float l2, float beta1, float beta2, float eps, float *loss_out,
                            const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes, void *stream);
+/* torch.optim.Adagrad (kind = 1) / torch.optim.Adadelta (kind = 2) with weight_decay = 0 fused into the step kernels, for
+ * n_batches consecutive batches of a plan (the reference eval's --optimizer into torch.optim.<name>(params, lr,
+ * weight_decay=l2), src/helpers/BaseRunner.py:34-37,120-124).  With a zero gradient neither optimizer moves a weight, so the
+ * tables are always current: no catch-up before the gradients, no flush before evaluation.
+ *   Adagrad : s1_* = state_sum tables (s2_*, last_* unused, may be NULL); exactly sparse.  eps = 1e-10 in torch.
+ *   Adadelta: s1_* = square_avg, s2_* = acc_delta, last_* [n_rows] int32 = step of the row's last update (0 initially): a
+ *             missed step multiplies both state rows by rho, replayed by the finisher before step t.  rho 0.9, eps 1e-6.
+ * step0 = optimizer step number of the first batch (1-based).  Hot rows are handled (pieces + combine) like in the SGD step. */
+int32_t wr_bprmf_run_stateful(int32_t kind, float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                              float *s1_u, float *s2_u, float *s1_i, float *s2_i, int32_t *last_u, int32_t *last_i,
+                              const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                              const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                              int64_t n_batches, int64_t step0, float lr, float rho, float eps, float *loss_out,
+                              const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes, void *stream);
 /* The same step with the catch-up FOLDED into the row loads: rows need NOT be up to date — every team that loads a row
  * replays the missed zero-gradient steps last[row]+1 .. adam_step-1 on its register copy (consts: the table of
  * wr_adam_consts, entries 0..adam_step), the finisher applies step adam_step and writes weights and moments once: 3 row

@@ -55,3 +55,8 @@ def g5():
 @pytest.fixture(scope="session")
 def g6():
     return load_golden("g6_eval")
+
+
+@pytest.fixture(scope="session")
+def g10():
+    return load_golden("g10_optimizers")

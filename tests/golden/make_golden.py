@@ -152,6 +152,15 @@ def g1_bprmf_step():
     run("Adam", 1e-2, 0.0, 3, "adam")
     run("Adam", 1e-2, 1e-3, 3, "adaml2")
     save("g1_bprmf_step", **out)
+    # G10: the other two optimizers of the reference's flag surface (BaseRunner.py:34-37: --optimizer SGD / Adam / Adagrad /
+    # Adadelta, eval'ed into torch.optim.<name>(params, lr=lr, weight_decay=l2) at :120-124), same tables and batches; kept
+    # in a file of its own so that g1 stays byte-identical
+    out10 = {}
+    keep, out = out, out10
+    run("Adagrad", 5e-2, 0.0, 5, "adagrad")
+    run("Adadelta", 2.0, 0.0, 5, "adadelta")
+    out = keep
+    save("g10_optimizers", **out10)
 
 
 # --------------------------------------------------------------------------------------------- G2

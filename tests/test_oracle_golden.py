@@ -201,3 +201,21 @@ def test_epoch_permutation_is_a_keyed_bijection(n):
         assert (p == q).mean() < 0.01 and (p == np.arange(n)).mean() < 0.01
         assert abs(np.corrcoef(np.arange(n), p)[0, 1]) < 0.1
         assert abs(np.abs(np.diff(p)).mean() / n - 1 / 3) < 0.03      # consecutive rows land far apart
+
+
+@pytest.mark.parametrize("name", ["adagrad", "adadelta"])
+def test_adagrad_adadelta_restatements_match_reference_trajectories(g1, g10, name):
+    """oracle.adagrad_dense / adadelta_dense on the oracle's dense gradients vs torch.optim.Adagrad / Adadelta driven by the
+    reference's BPRMF.predict + backward (tests/golden/make_golden.py g1 -> g10_optimizers.npz)"""
+    lr = float(g10[name + "_hp"][0])
+    U, I = g1["U0"].copy(), g1["I0"].copy()
+    z = np.zeros_like
+    su, si, au, ai = z(U), z(I), z(U), z(I)
+    for k in range(5):
+        gU, gI, loss = oracle.bpr_dense_grads(U, I, g1[f"u{k}"], g1[f"p{k}"], g1[f"n{k}"])
+        assert abs(loss - g10[name + "_loss"][k]) / g10[name + "_loss"][k] < 1e-5
+        if name == "adagrad":
+            oracle.adagrad_dense(U, gU, su, lr); oracle.adagrad_dense(I, gI, si, lr)
+        else:
+            oracle.adadelta_dense(U, gU, su, au, lr); oracle.adadelta_dense(I, gI, si, ai, lr)
+        assert rel_err(U, g10[f"{name}_U{k + 1}"]) < 1e-5 and rel_err(I, g10[f"{name}_I{k + 1}"]) < 1e-5

@@ -78,6 +78,9 @@ SIGNATURES = {
     "wr_sgd_catchup_all": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_f32, c_vp]),
     "wr_bprmf_step_adam": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                    c_i64, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_run_stateful": (c_i32, [c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_i64,
+                                      c_vp]),
     "wr_bprmf_step_adam_folded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_vp, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_i64,
                                           c_vp]),

@@ -32,9 +32,15 @@ class FusedOptimizer:
     batch needs it, all rows in ``flush()``; same bits, no table passes), -1 = lazy when the tables hold at least 8 rows
     per batch row and 65536 rows in all."""
 
+    SPARSE_STATEFUL = ("Adagrad", "Adadelta")     # fused when l2 == 0 (hip_ops.StatefulSparseState)
+
+    @staticmethod
+    def supports(name, l2):
+        return name in ("SGD", "Adam") or (name in FusedOptimizer.SPARSE_STATEFUL and float(l2) == 0.0)
+
     def __init__(self, model, name, lr, l2, lazy=-1):
-        if name not in ("SGD", "Adam"):
-            raise ValueError("FusedOptimizer supports SGD and Adam, got %r" % name)
+        if not self.supports(name, l2):
+            raise ValueError("FusedOptimizer supports SGD, Adam and (with l2 = 0) Adagrad / Adadelta, got %r l2=%r" % (name, l2))
         self.model, self.name, self.lr, self.l2 = model, name, float(lr), float(l2)
         self.betas, self.eps = (0.9, 0.999), 1e-8
         self.adam_step = 0
@@ -55,6 +61,13 @@ class FusedOptimizer:
                           "mI": z(m.item_embeddings.weight), "vI": z(m.item_embeddings.weight)}
         return self.state
 
+    def _sparse_state(self, tabs):
+        if self.lazy_state is None:
+            self.lazy_state = hip_ops.StatefulSparseState(tabs, self.name, self.lr)
+        elif self.lazy_state.tabs.U.data_ptr() != tabs.U.data_ptr() or self.lazy_state.tabs.I.data_ptr() != tabs.I.data_ptr():
+            raise RuntimeError("the embedding tables were re-allocated after optimizer steps had been taken")
+        return self.lazy_state
+
     def _use_lazy(self, tabs, batch):
         """decided at the first step and kept: the two representations of the optimizer state are not mixed"""
         if self._lazy_decided is None:
@@ -66,6 +79,9 @@ class FusedOptimizer:
     @torch.no_grad()
     def step_batch(self, tabs, plan, k, loss_out=None):
         """zero_grad / predict / backward / optimizer.step of BaseRunner.py:196-199 on batch k of the plan"""
+        if self.name in self.SPARSE_STATEFUL:
+            self.adam_step += 1
+            return self._sparse_state(tabs).step(plan, k, loss_out=loss_out)
         if self._use_lazy(tabs, plan.batch_size):
             if self.lazy_state is None:
                 self.lazy_state = hip_ops.LazyOptimizerState(tabs, self.name, self.lr, self.l2, self.betas, self.eps)
@@ -87,6 +103,9 @@ class FusedOptimizer:
     @torch.no_grad()
     def run_batches(self, tabs, plan, first, count, losses):
         """`count` consecutive step_batch calls; the lazy optimizers issue them from native code"""
+        if self.name in self.SPARSE_STATEFUL:
+            self.adam_step += count
+            return self._sparse_state(tabs).run(plan, first, count, losses)
         if self._use_lazy(tabs, plan.batch_size):
             if self.lazy_state is None:
                 self.lazy_state = hip_ops.LazyOptimizerState(tabs, self.name, self.lr, self.l2, self.betas, self.eps)
@@ -187,7 +206,7 @@ def make_bprmf(general_model_cls):
             self._backward_seen = False
             self._tabs = None
             name = getattr(args, "optimizer", None)
-            if name in ("SGD", "Adam") and hasattr(args, "lr"):
+            if name is not None and hasattr(args, "lr") and FusedOptimizer.supports(name, getattr(args, "l2", 0.0)):
                 self.optimizer = FusedOptimizer(self, name, args.lr, getattr(args, "l2", 0.0),
                                                 getattr(args, "lazy_optimizer", -1))
 
@@ -282,7 +301,7 @@ def make_bprmf(general_model_cls):
                 if plan.fast_overflowed:
                     src = (prep.users, prep.items) if prep is not None else (u, p)
                     bmap = hip_ops.BucketMap(src[0], src[1], self.user_num, self.item_num, batch_size) if bmap is None else False
-                if optimizer in ("SGD", "Adam"):
+                if FusedOptimizer.supports(optimizer, l2):
                     if opt is None or opt.name != optimizer or opt.lr != float(lr) or opt.l2 != float(l2):
                         if opt is not None and opt.adam_step > 0 and opt.name == optimizer:
                             raise ValueError("lr / l2 changed after optimizer steps had been taken")

@@ -173,6 +173,68 @@ __device__ __forceinline__ void adam_finish_row(float *__restrict__ W, float *__
     if (lane == 0) last[row] = a.t;
 }
 
+// MODE 5 / 6 — torch.optim.Adagrad / Adadelta where MODE 3 applies Adam (reference src/helpers/BaseRunner.py:34-37,120-124:
+// the --optimizer flag is eval'ed into torch.optim.<name>(params, lr, weight_decay=l2); this path is for l2 = 0).  With a
+// zero gradient neither optimizer moves a weight, so the TABLES are always current (no catch-up before gradients, no flush):
+//   Adagrad   (MODE 5): state_sum += g*g; w -= lr * g / (sqrt(state_sum) + 1e-10) — a zero gradient changes nothing at all:
+//             exactly sparse.  AdamArgs: mU / mI = state_sum tables, eps, step_size = lr.
+//   Adadelta  (MODE 6): square_avg = rho*square_avg + (1-rho) g*g; std = sqrt(square_avg + eps);
+//             delta = sqrt(acc_delta + eps) / std * g; acc_delta = rho*acc_delta + (1-rho) delta*delta; w -= lr*delta.
+//             A zero gradient only multiplies both state rows by rho: the finisher replays the missed decays (t-1-last[row]
+//             multiplications per element, the dense optimizer's bits) before it applies step t.  AdamArgs: mU / mI =
+//             square_avg, vU / vI = acc_delta, lastU / lastI, b1 = rho, eps, step_size = lr, t.
+// sqrt and the quotient on v_sqrt_f32 / v_rcp_f32 (1 ulp), like adam_elem.
+template <int T, int NV, bool FULL, int MODE>
+__device__ __forceinline__ void opt_finish_row(float *__restrict__ W, float *__restrict__ S1, float *__restrict__ S2,
+                                               int *__restrict__ last, int row, int D, int lane, const Row<NV> &w0,
+                                               const Row<NV> &g, const AdamArgs &a) {
+    if constexpr (MODE == 3) {
+        adam_finish_row<T, NV, FULL>(W, S1, S2, last, row, D, lane, w0, g, a);
+    } else if constexpr (MODE == 5) {
+        Row<NV> s = load_row<T, NV, FULL>(S1, row, D, lane), w = w0;
+        auto elem = [&](float &ww, float &ss, float gg) {
+            ss = fmaf(gg, gg, ss);
+            ww = fmaf(-a.step_size, gg * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(ss) + a.eps), ww);
+        };
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            elem(w.v[k].x, s.v[k].x, g.v[k].x); elem(w.v[k].y, s.v[k].y, g.v[k].y);
+            elem(w.v[k].z, s.v[k].z, g.v[k].z); elem(w.v[k].w, s.v[k].w, g.v[k].w);
+        }
+        store_row<T, NV, FULL>(W, row, D, lane, w);
+        store_row<T, NV, FULL>(S1, row, D, lane, s);
+    } else {
+        Row<NV> sq = load_row<T, NV, FULL>(S1, row, D, lane), ac = load_row<T, NV, FULL>(S2, row, D, lane), w = w0;
+        const int missed = a.t - 1 - last[row];
+        const float rho = a.b1;
+        for (int j = 0; j < missed; ++j) {          // the decays of the steps this row had no gradient in
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                sq.v[k].x *= rho; sq.v[k].y *= rho; sq.v[k].z *= rho; sq.v[k].w *= rho;
+                ac.v[k].x *= rho; ac.v[k].y *= rho; ac.v[k].z *= rho; ac.v[k].w *= rho;
+            }
+        }
+        auto elem = [&](float &ww, float &s2, float &a2, float gg) {
+            s2 = fmaf(1.0f - rho, gg * gg, rho * s2);
+            const float std = __builtin_amdgcn_sqrtf(s2 + a.eps);
+            const float delta = __builtin_amdgcn_sqrtf(a2 + a.eps) * __builtin_amdgcn_rcpf(std) * gg;
+            a2 = fmaf(1.0f - rho, delta * delta, rho * a2);
+            ww = fmaf(-a.step_size, delta, ww);
+        };
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            elem(w.v[k].x, sq.v[k].x, ac.v[k].x, g.v[k].x); elem(w.v[k].y, sq.v[k].y, ac.v[k].y, g.v[k].y);
+            elem(w.v[k].z, sq.v[k].z, ac.v[k].z, g.v[k].z); elem(w.v[k].w, sq.v[k].w, ac.v[k].w, g.v[k].w);
+        }
+        store_row<T, NV, FULL>(W, row, D, lane, w);
+        store_row<T, NV, FULL>(S1, row, D, lane, sq);
+        store_row<T, NV, FULL>(S2, row, D, lane, ac);
+        if (lane == 0) last[row] = a.t;
+    }
+}
+
+constexpr bool mode_has_state(int mode) { return mode == 3 || mode == 5 || mode == 6; }
+
 // ----------------------------------------------------------------------------------------------- user phase
 // MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.  MODE 3: Adam apply in place.
 // MODE 2 (row-sharded step): user rows applied in place, item gradients emitted (the item "table" is the buffer of
@@ -215,13 +277,13 @@ __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &p
         if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
         return;
     }
-    if (MODE == 3) {
-        if (!p_shared) adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, p, D, lane, pr, z, ad);
+    if constexpr (mode_has_state(MODE)) {
+        if (!p_shared) opt_finish_row<T, NV, FULL, MODE>(I, ad.mI, ad.vI, ad.lastI, p, D, lane, pr, z, ad);
         if (!n_shared) {
             Row<NV> zn;
 #pragma unroll
             for (int k = 0; k < NV; ++k) zn.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
-            adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, n, D, lane, nr, zn, ad);
+            opt_finish_row<T, NV, FULL, MODE>(I, ad.mI, ad.vI, ad.lastI, n, D, lane, nr, zn, ad);
         }
         if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
         return;
@@ -266,8 +328,8 @@ template <int T, int NV, bool FULL, int MODE>
 __device__ __forceinline__ void finish_user_row(float *__restrict__ U, float *__restrict__ gradU, int *__restrict__ stampU,
                                                 int step_id, int u, int D, int lane, float lr, float l2, const Row<NV> &ur,
                                                 const Row<NV> &g, const AdamArgs &ad) {
-    if (MODE == 3) {
-        adam_finish_row<T, NV, FULL>(U, ad.mU, ad.vU, ad.lastU, u, D, lane, ur, g, ad);
+    if constexpr (mode_has_state(MODE)) {
+        opt_finish_row<T, NV, FULL, MODE>(U, ad.mU, ad.vU, ad.lastU, u, D, lane, ur, g, ad);
         return;
     }
     if (MODE != 1) {
@@ -574,8 +636,8 @@ template <int T, int NV, bool FULL, int MODE>
 __device__ __forceinline__ void finish_item_row(float *__restrict__ I, float *__restrict__ gradI, int *__restrict__ stampI,
                                                 int step_id, int r, int D, int lane, float lr, float l2, const Row<NV> &ir,
                                                 const Row<NV> &g, const AdamArgs &ad) {
-    if (MODE == 3) {
-        adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
+    if constexpr (mode_has_state(MODE)) {
+        opt_finish_row<T, NV, FULL, MODE>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
         return;
     }
     if (MODE == 0) {
@@ -768,9 +830,9 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_hot_combine(float *__restri
             g.v[c].x += x.v[c].x; g.v[c].y += x.v[c].y; g.v[c].z += x.v[c].z; g.v[c].w += x.v[c].w;
         }
     }
-    if (MODE == 3) {
+    if constexpr (mode_has_state(MODE)) {
         const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
-        adam_finish_row<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
+        opt_finish_row<T, NV, FULL, MODE>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
         return;
     }
     if (MODE == 0) {
@@ -1196,6 +1258,52 @@ int32_t wr_bprmf_step_adam_folded(float *user_tab, int64_t n_users, float *item_
     adam_step_consts(adam_step, lr, beta1, beta2, &ad.step_size, &ad.inv_bc2_sqrt);   // = consts[2t], consts[2t+1]
     return launch_step<4>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, B, lr, l2, nullptr, nullptr, nullptr, nullptr, 0,
                           loss_out, workspace, reinterpret_cast<hipStream_t>(stream_), nullptr, 0.f, hot_of(nullptr, 0), 0, ad);
+}
+
+int32_t wr_bprmf_run_stateful(int32_t kind, float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                              float *s1_u, float *s2_u, float *s1_i, float *s2_i, int32_t *last_u, int32_t *last_i,
+                              const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                              const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                              int64_t n_batches, int64_t step0, float lr, float rho, float eps, float *loss_out,
+                              const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes, void *stream_) {
+    int32_t rc;
+    WR_REQUIRE(kind == 1 || kind == 2, WR_E_RANGE, "kind must be 1 (Adagrad) or 2 (Adadelta)");
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_table(s1_u, n_users, D, "s1_u")) != WR_OK) return rc;
+    if ((rc = check_table(s1_i, n_items, D, "s1_i")) != WR_OK) return rc;
+    if (kind == 2) {
+        if ((rc = check_table(s2_u, n_users, D, "s2_u")) != WR_OK) return rc;
+        if ((rc = check_table(s2_i, n_items, D, "s2_i")) != WR_OK) return rc;
+        WR_REQUIRE(last_u != nullptr && last_i != nullptr, WR_E_NULL, "Adadelta needs last_u / last_i");
+    }
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, batch_size)) != WR_OK) return rc;
+    WR_REQUIRE(n_triplets > 0 && first_batch >= 0 && n_batches >= 0 && step0 >= 1 && step0 + n_batches < INT32_MAX, WR_E_SHAPE,
+               "bad batch / step range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(batch_size, D), WR_E_WORKSPACE,
+               "wr_bprmf_run_stateful: workspace %lld B < %lld B", (long long)workspace_bytes,
+               (long long)step_ws_bytes(batch_size, D));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t b = first_batch + k;
+        const int64_t off = b * batch_size;
+        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
+        AdamArgs ad{s1_u, s2_u, s1_i, s2_i, last_u, last_i, lr, 0.f, rho, 0.f, eps, 0.f, (int)(step0 + k), nullptr};
+        float *lo = loss_out ? loss_out + k : nullptr;
+        if (kind == 1)
+            rc = launch_step<5>(user_tab, item_tab, D, tu + off, tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk, lr,
+                                0.f, nullptr, nullptr, nullptr, nullptr, 0, lo, workspace, stream, nullptr, 0.f, hot_of(hot, b),
+                                batch_size, ad);
+        else
+            rc = launch_step<6>(user_tab, item_tab, D, tu + off, tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk, lr,
+                                0.f, nullptr, nullptr, nullptr, nullptr, 0, lo, workspace, stream, nullptr, 0.f, hot_of(hot, b),
+                                batch_size, ad);
+        if (rc != WR_OK) return rc;
+    }
+    return WR_OK;
 }
 
 int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,

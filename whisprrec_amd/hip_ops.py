@@ -1235,6 +1235,51 @@ class LazyOptimizerState:
         self.flushed_at = self.t
 
 
+class StatefulSparseState:
+    """torch.optim.Adagrad / Adadelta (weight_decay = 0) fused into the step kernels (wr_bprmf_run_stateful): with a zero
+    gradient neither moves a weight, so only the rows of a batch are touched and the tables are always current (nothing to
+    flush).  Adagrad's state (state_sum) is exactly sparse; Adadelta's two state rows decay by rho at every step — the
+    missed decays of a row are replayed when it is next updated (``last`` = step of its last update)."""
+
+    KIND = {"Adagrad": 1, "Adadelta": 2}
+
+    def __init__(self, tabs, name, lr, rho=0.9, eps=None):
+        if name not in self.KIND:
+            raise ValueError(name)
+        self.tabs, self.name, self.lr, self.rho = tabs, name, float(lr), float(rho)
+        self.eps = float(eps) if eps is not None else (1e-10 if name == "Adagrad" else 1e-6)   # torch.optim defaults
+        z = torch.zeros_like
+        self.s1_u, self.s1_i = z(tabs.U), z(tabs.I)
+        self.s2_u = self.s2_i = self.last_u = self.last_i = None
+        if name == "Adadelta":
+            self.s2_u, self.s2_i = z(tabs.U), z(tabs.I)
+            self.last_u = torch.zeros(tabs.U.shape[0], dtype=torch.int32, device=tabs.dev)
+            self.last_i = torch.zeros(tabs.I.shape[0], dtype=torch.int32, device=tabs.dev)
+        self.t = 0
+
+    def run(self, plan, first, count, losses=None):
+        tabs = self.tabs
+        if losses is None:
+            losses = torch.empty(count, dtype=torch.float32, device=tabs.dev)
+        ws = tabs._ws(plan.batch_size)
+        hot = plan.hot_struct()
+        abi.check(abi.lib().wr_bprmf_run_stateful(
+            self.KIND[self.name], _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.s1_u), _p(self.s2_u),
+            _p(self.s1_i), _p(self.s2_i), _p(self.last_u), _p(self.last_i), _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item),
+            _p(plan.oc_src), plan.n_triplets, plan.batch_size, first, count, self.t + 1, self.lr, self.rho, self.eps, _p(losses),
+            ctypes.addressof(hot) if hot is not None else None, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_stateful")
+        self.t += count
+        tabs.step_id += count
+        return losses
+
+    def step(self, plan, k, loss_out=None):
+        out = self.run(plan, k, 1, losses=None if loss_out is None else loss_out.reshape(1))
+        return out.reshape(()) if loss_out is None else loss_out
+
+    def flush(self):
+        """nothing to do: the weights never lag (kept so that callers treat every optimizer state alike)"""
+
+
 def adam_consts(n, lr, beta1=0.9, beta2=0.999, device=None):
     """device table of the per-step Adam constants for steps 0..n-1 (wr_adam_consts: the host expressions of wr_adam_dense)"""
     host = torch.empty(2 * n, dtype=torch.float32)

@@ -428,7 +428,8 @@ def make_hip_runner(base_runner_cls):
                 return base_runner_cls.fit(self, dataset, epoch)
             dev = next(model.parameters()).device
             model.train()
-            if hasattr(model, "train_epoch") and self.optimizer_name in ("SGD", "Adam"):
+            if hasattr(model, "train_epoch") and (self.optimizer_name in ("SGD", "Adam") or (
+                    self.optimizer_name in ("Adagrad", "Adadelta") and float(self.l2) == 0.0)):
                 if self.device_epoch_prep and not sequential:
                     prep = self._device_epoch(dataset, dev, epoch, pipelined=True)
                     losses = model.train_epoch(prep.cols[0], prep.cols[1], prep.cols[2], self.batch_size, self.learning_rate,
