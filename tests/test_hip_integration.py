@@ -117,11 +117,12 @@ def test_lazy_and_dense_runs_are_bit_identical(g2):
 
 
 def test_torch_optimizer_on_dense_grads(g1):
-    """--optimizer Adagrad (BaseRunner.py:36 lists it): torch.optim on the dense gradients our backward emits must equal
-    torch.optim on autograd's dense gradients, which we hold as golden gU/gI."""
+    """--optimizer Adagrad with --l2 (BaseRunner.py:36 lists it; weight decay moves every row, so it is not fused): torch.optim
+    on the dense gradients our backward emits must equal torch.optim on autograd's dense gradients, which we hold as golden
+    gU/gI.  (Without --l2 Adagrad / Adadelta are fused: tests/test_hip_optimizers.py.)"""
     from whisprrec_amd.bprmf import BPRMF
     from whisprrec_amd import host
-    args = _args(optimizer="Adagrad", lr=0.05)
+    args = _args(optimizer="Adagrad", lr=0.05, l2=1e-4)
     corpus = host.Corpus(97, 131, {"train": {"user_id": g1["u0"], "item_id": g1["p0"]},
                                    "dev": {"user_id": [], "item_id": []}, "test": {"user_id": [], "item_id": []}})
     model = BPRMF(args, corpus).to(args.device)
