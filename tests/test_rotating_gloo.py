@@ -42,7 +42,27 @@ def _worker(rank, world, port, payload, out_dir):
             for r in range(world):
                 u, p, n, per_part = payload["strata"][rank][r]
                 losses.append(m.run_strata([(T(u), T(p), T(n), per_part)], B, lr, defer_last=True))
-                assert m._deferred == parts - 1 and m.held == (rank + r) % world     # the rotation is still open
+                assert m._deferred == (parts - 1, True) and m.held == (rank + r) % world     # the rotation is still open
+            m.complete_rotation()
+        elif payload["whole_epoch"] == "pieces":                    # ONE continuous run cut at arbitrary steps (bench.py N > 1)
+            S = sum(payload["strata"][rank][0][3])
+            spp = payload["strata"][rank][0][3]
+            part_end = np.cumsum(spp)
+            losses, g0 = [], 0
+            for length in payload["cuts"]:
+                pieces, gs, g1 = [], g0, g0 + length
+                while gs < g1:
+                    r, o0 = gs // S, gs % S
+                    o1 = min(S, o0 + (g1 - gs))
+                    u, p, n, _ = payload["strata"][rank][r]
+                    per_part = [max(0, min(o1, int(part_end[k])) - max(o0, int(part_end[k] - spp[k]))) for k in range(parts)]
+                    ends = [bool(o0 < part_end[k] <= o1) for k in range(parts)]
+                    sl = slice(o0 * B, o1 * B)
+                    pieces.append((T(u[sl]), T(p[sl]), T(n[sl]), per_part, ends))
+                    gs += o1 - o0
+                losses.append(m.run_strata(pieces, B, lr, defer_last=True))
+                g0 += length
+            assert g0 == world * S
             m.complete_rotation()
         elif payload["whole_epoch"]:                                # all strata in one call: plans pipelined across rotations
             losses = [m.run_strata([(T(u), T(p), T(n), pp) for (u, p, n, pp) in payload["strata"][rank]], B, lr)]
@@ -67,7 +87,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,nI,parts,whole", [(2, 61, 2, False), (3, 100, 2, True), (2, 40, 1, True), (3, 37, 3, False),
-                                                  (2, 61, 2, "deferred"), (3, 50, 1, "deferred")])
+                                                  (2, 61, 2, "deferred"), (3, 50, 1, "deferred"), (2, 61, 2, "pieces"),
+                                                  (3, 70, 2, "pieces")])
 def test_rotating_epoch_equals_single_process(tmp_path, world, nI, parts, whole):
     from whisprrec_amd.sharded import n_local_rows
     rng = np.random.RandomState(world * 10 + parts)
@@ -94,7 +115,9 @@ def test_rotating_epoch_equals_single_process(tmp_path, world, nI, parts, whole)
             u, p, n = np.concatenate(us), np.concatenate(ps), np.concatenate(ns)
             strata[rank][r] = (u.astype(np.int64), p.astype(np.int64), n.astype(np.int64), steps_per_part)
             glob[r].append((u * world + rank, p * world + held, n * world + held))   # back to global ids
-    payload = dict(shape=(nU, nI, D, B, lr, parts), U=U, I=I, strata=strata, whole_epoch=whole)
+    total = world * sum(steps_per_part)
+    cuts = [3, 1, 2] + [total - 6] if total > 6 else [total]       # pieces that end inside parts, on part ends, on stratum ends
+    payload = dict(shape=(nU, nI, D, B, lr, parts), U=U, I=I, strata=strata, whole_epoch=whole, cuts=cuts)
     mp.spawn(_worker, args=(world, _free_port(), payload, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     Uo, Io = U.copy(), I.copy()

@@ -178,11 +178,16 @@ class RotatingBprmf:
         return self.run_strata([(u, p, n, steps_per_part)], batch, lr)
 
     def complete_rotation(self):
-        """hand over the part a previous run_strata(defer_last=True) kept back and finish that rotation"""
+        """hand over the part a previous run_strata(defer_last=True) kept back — and finish the rotation if it was the
+        stratum's last part"""
         if self._deferred is not None:
-            k, self._deferred = self._deferred, None
+            (k, stratum_done), self._deferred = self._deferred, None
             self._send_part(k)
-            self._finish_rotation()
+            if stratum_done:
+                self._finish_rotation()
+
+    def _rotation_pending(self):
+        return self._deferred is not None and self._deferred[1] and self.world > 1
 
     def run_strata(self, strata, batch, lr, part_relative=False, defer_last=False):
         """Consecutive strata [(u, p, n, steps_per_part), ...] (see run_subepoch), one block rotation after each.  All
@@ -203,12 +208,18 @@ class RotatingBprmf:
         carried out by run_prepared.  Lets a caller build the first plan of a piece of work outside that piece's timed
         region, the way every later plan is built beside steps."""
         B = int(batch)
-        pending = self._deferred is not None and self.world > 1
+        pending = self._rotation_pending()
         # stratum r trains on bufs[r % 2] (every rotation swaps I and I_in; a pending one swaps them before stratum 0)
         bufs = (self.I_in, self.I) if pending else (self.I, self.I_in)
         held = (self.held + 1) % self.world if pending else self.held
-        segments, counts = [], []
-        for r, (u, p, n, steps_per_part) in enumerate(strata):
+        segments, counts, ends = [], [], []
+        for r, stratum in enumerate(strata):
+            u, p, n, steps_per_part = stratum[:4]
+            # optional 5th element: per part, whether its steps END in this call (default: every part does).  A part that
+            # goes on in a later call is not handed over yet; only the last stratum of a call may be left open.
+            part_ends = [bool(e) for e in stratum[4]] if len(stratum) > 4 else [True] * self.parts
+            if len(part_ends) != self.parts or (not part_ends[-1] and r != len(strata) - 1):
+                raise ValueError("only the last stratum of a call may be left open")
             per_part = [int(steps_per_part[k]) if k < len(steps_per_part) else 0 for k in range(self.parts)]
             table = bufs[r % 2] if self.world > 1 else self.I
             first = 0
@@ -219,23 +230,32 @@ class RotatingBprmf:
                                  n[sl] if part_relative else n[sl] - lo))
                 first += st
             counts.append(per_part)
+            ends.append(part_ends)
             held = (held + 1) % self.world
         handle = self.local.plan(self.U, segments, B)
-        return {"handle": handle, "counts": counts, "B": B, "pending": pending}
+        return {"handle": handle, "counts": counts, "ends": ends, "B": B, "pending": pending}
 
     def run_prepared(self, prep, lr, n_strata=None, defer_last=False):
         """the steps of the first n_strata strata (default: all) of a prepare()d schedule; see run_strata"""
-        if prep["pending"] != (self._deferred is not None and self.world > 1):
+        if prep["pending"] != self._rotation_pending():
             raise RuntimeError("the ring's state changed between prepare() and run_prepared()")
         self.complete_rotation()
         # the global batch is the union of the G local batches: its mean loss has 1/(G*B) coefficients.  The local kernels
         # use 1/B, and the local batches touch disjoint rows, so dividing the learning rate by G gives the same update.
         lr = lr / self.world
         counts = prep["counts"] if n_strata is None else prep["counts"][:n_strata]
+        ends = prep["ends"][:len(counts)]
         handle = prep["handle"]
         losses = torch.zeros(sum(sum(c) for c in counts), dtype=torch.float32, device=self.device)
         first, seg = 0, 0
-        for si, per_part in enumerate(counts):
+        open_stratum = False
+        # defer_last: the LAST hand-over of the call — a part whose steps end the call — is left to the next call
+        tail = None
+        if defer_last and self.world > 1 and counts:
+            done = [k for k in range(self.parts) if ends[-1][k]]
+            if done and all(counts[-1][k2] == 0 for k2 in range(done[-1] + 1, self.parts)):
+                tail = done[-1]
+        for si, (per_part, part_ends) in enumerate(zip(counts, ends)):
             last_stratum = si == len(counts) - 1
             for k, st in enumerate(per_part):
                 if st > 0:
@@ -243,13 +263,17 @@ class RotatingBprmf:
                     self.local.run(handle, seg, lr, losses[first:first + st])
                     first += st
                 seg += 1
-                if defer_last and last_stratum and k == len(per_part) - 1 and self.world > 1:
-                    self._deferred = k                  # handed over at the start of the next call
+                if not part_ends[k]:
+                    continue                            # the part goes on in the next call: not handed over yet
+                if last_stratum and k == tail:
+                    self._deferred = (k, bool(part_ends[-1]) and k == self.parts - 1)   # handed over at the start of the next call
                 else:
                     self._send_part(k)
-            if self._deferred is None:
+            if not part_ends[-1]:
+                open_stratum = True                     # the stratum goes on in the next call: no rotation yet
+            elif self._deferred is None:
                 self._finish_rotation()
-        if self._deferred is None:
+        if self._deferred is None and not open_stratum:
             self._drain()                               # leave with the held block complete
         return losses
 
@@ -263,8 +287,9 @@ def stratum_steps(n_interactions, world, batch):
 
 
 # ---------------------------------------------------------------------------------------------------- bench (N > 1)
-SAMPLING_NOTE = ("stratified: a triplet's negative is drawn uniformly from the item block of its positive (a fixed "
-                 "pseudo-random 1/G of the items, i % G) and batches are drawn per (user shard, item block) stratum; the "
+SAMPLING_NOTE = ("stratified: a triplet's negative is drawn uniformly from the PART of the item block its positive lies in (a "
+                 "block = a fixed pseudo-random 1/G of the items, i % G; a part = one of `parts` contiguous row ranges of it) "
+                 "and batches are drawn per (user shard, item part) stratum; the "
                  "reference draws negatives from ALL items (src/models/BaseModel.py:168) — waived in this mode, kept in "
                  "mode 'alltoall'; the arithmetic of a step (batch-synchronous SGD on the global batch) is unchanged")
 
@@ -298,54 +323,60 @@ def bench_run(args, rank, world, dev):
     g = torch.Generator(device=dev)
     g.manual_seed(3407 * 7919 + rank)
 
-    def make_schedule(count, held0):
-        """strata of `count` steps in all, generated BEFORE the timed region like the N=1 bench: uniform users of this rank,
-        positives and negatives uniform inside each part of the held block (item 0, which the reference never draws as a
-        negative, is local row 0 of block 0), batches of part 0 first, then part 1, ...; indices count rows from the start
-        of their part.  One flat array per column for the whole schedule: the strata and parts are views of it."""
-        layout, done, held = [], 0, held0
-        while done < count:
-            st = min(S, count - done)
-            per_part = [st // model.parts + (1 if k < st % model.parts else 0) for k in range(model.parts)]
-            layout.append((held, per_part))
-            held = (held + 1) % world
-            done += st
-        total = count * B
-        u_all = torch.randint(0, model.U.shape[0], (total,), generator=g, device=dev, dtype=torch.int32)
-        p_all = torch.empty(total, dtype=torch.int32, device=dev)
-        n_all = torch.empty(total, dtype=torch.int32, device=dev)
-        sched, at = [], 0
-        for blk, per_part in layout:
-            first = at
-            for k, stp in enumerate(per_part):
-                lo, hi = model.part_range(blk, k)
-                cnt = stp * B
-                if cnt:
+    part_len = [S // model.parts + (1 if k < S % model.parts else 0) for k in range(model.parts)]   # steps of a part
+    part_end = np.cumsum(part_len)                                                               # offsets inside a stratum
+
+    def make_pieces(g0, count):
+        """The strata pieces of global steps [g0, g0 + count) of ONE continuous run: stratum s = steps [s S, (s+1) S) trains
+        on block (rank + s) % G, part k of it on steps [part_end[k] - part_len[k], part_end[k]) of the stratum.  A part is
+        handed to the ring in the piece that contains its last step, the block rotates in the piece that contains the
+        stratum's last step — so a window shorter than a part (the driver's 20 steps at G = 2: a part lasts 190) carries no
+        hand-over, as in the long run it is cut from, instead of a whole block per window.  Indices are generated BEFORE
+        the timed region like the N=1 bench: uniform users of this rank, positives and negatives uniform inside the part
+        (item 0, which the reference never draws as a negative, is local row 0 of block 0); they count rows from the
+        start of their part."""
+        pieces, gs, g1 = [], g0, g0 + count
+        while gs < g1:
+            s_idx, o0 = gs // S, gs % S
+            o1 = min(S, o0 + (g1 - gs))
+            held = (rank + s_idx) % world
+            per_part, ends, cols = [], [], []
+            for k in range(model.parts):
+                a, b = int(part_end[k] - part_len[k]), int(part_end[k])
+                st = max(0, min(o1, b) - max(o0, a))
+                per_part.append(st)
+                ends.append(bool(o0 < b <= o1) if part_len[k] > 0 else bool(o1 == S))
+                if st:
+                    lo, hi = model.part_range(held, k)
                     width = max(hi - lo, 1)
-                    p_all[at:at + cnt] = torch.randint(0, width, (cnt,), generator=g, device=dev, dtype=torch.int32)
-                    n0 = 1 if (blk == 0 and lo == 0 and width > 1) else 0
-                    n_all[at:at + cnt] = torch.randint(n0, width, (cnt,), generator=g, device=dev, dtype=torch.int32)
-                at += cnt
-            sched.append((u_all[first:at], p_all[first:at], n_all[first:at], per_part))
-        return sched, held
+                    cnt = st * B
+                    uu = torch.randint(0, model.U.shape[0], (cnt,), generator=g_idx, device=dev, dtype=torch.int32)
+                    pp = torch.randint(0, width, (cnt,), generator=g_idx, device=dev, dtype=torch.int32)
+                    n0 = 1 if (held == 0 and lo == 0 and width > 1) else 0
+                    nn_ = torch.randint(n0, width, (cnt,), generator=g_idx, device=dev, dtype=torch.int32)
+                    cols.append((uu, pp, nn_))
+            if cols:
+                u_c, p_c, n_c = (torch.cat([c[j] for c in cols]) for j in range(3))
+                pieces.append((u_c, p_c, n_c, per_part, ends))
+            gs += o1 - o0
+        return pieces
 
-    # Same shape as the N=1 bench.  The hand-over of a piece's last part is left to the next piece (defer_last): it then runs
-    # beside that piece's first part, as it would beside the next stratum's first part in one long run — the timed region
-    # takes over the warm-up's pending hand-over and leaves its own pending.  The timed piece's index work is prepare()d
-    # before the clock starts (its first plan is built outside the region, like every plan but a run's first is built beside
-    # steps), with one spare stratum of `chunk` steps behind it that is planned — inside the region, beside the last timed
-    # steps — but never trained: K steps' worth of plan builds between the two timestamps, K steps trained.
-    warm, held_after = make_schedule(W - W // 2, model.held)
-    warm2 = None
-    if W >= 2:
-        warm2, held_after = make_schedule(W // 2, held_after)
-    timed, held_after = make_schedule(K, held_after)
-    spare, _ = make_schedule(min(chunk, S), held_after)
+    g_idx = g
+    w1 = W - W // 2
+    warm = make_pieces(0, w1) if W > 0 else []
+    warm2 = make_pieces(w1, W - w1) if W >= 2 else None
+    timed = make_pieces(W, K)
+    spare = make_pieces(W + K, min(chunk, S))
+    # Same shape as the N=1 bench.  The hand-over of a piece's last part (when the piece ends on a part's last step) is left
+    # to the next piece (defer_last): it then runs beside that piece's first part, as it would beside the next part in one
+    # long run.  The timed piece's index work is prepare()d before the clock starts (its first plan is built outside the
+    # region, like every plan but a run's first is built beside steps), with a spare piece of `chunk` steps behind it that is
+    # planned — inside the region, beside the last timed steps — but never trained: K steps' worth of plan builds between the
+    # two timestamps, K steps trained.
     torch.cuda.synchronize()
-
     if W > 0:
         model.run_strata(warm, B, args.lr, part_relative=True, defer_last=True)
-        if W >= 2:      # in two pieces when it can be: every host path of a piece has then run twice before the clock starts
+        if warm2:       # in two pieces when it can be: every host path of a piece has then run twice before the clock starts
             model.run_strata(warm2, B, args.lr, part_relative=True, defer_last=True)
     prepared = model.prepare(timed + spare, B, part_relative=True)
     torch.cuda.synchronize()
