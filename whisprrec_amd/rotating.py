@@ -213,13 +213,15 @@ class RotatingBprmf:
         bufs = (self.I_in, self.I) if pending else (self.I, self.I_in)
         held = (self.held + 1) % self.world if pending else self.held
         segments, counts, ends = [], [], []
-        for r, stratum in enumerate(strata):
+        r = 0                                            # strata completed so far in this call (buffer parity)
+        for stratum in strata:
             u, p, n, steps_per_part = stratum[:4]
-            # optional 5th element: per part, whether its steps END in this call (default: every part does).  A part that
-            # goes on in a later call is not handed over yet; only the last stratum of a call may be left open.
+            # optional 5th element: per part, whether its steps END in this entry (default: every part does).  A part that
+            # goes on is not handed over yet; an entry that leaves its stratum open (last part not ended) is followed, if at
+            # all, by the entry that continues the SAME stratum (a run cut into pieces: bench.py's timed piece + spare piece)
             part_ends = [bool(e) for e in stratum[4]] if len(stratum) > 4 else [True] * self.parts
-            if len(part_ends) != self.parts or (not part_ends[-1] and r != len(strata) - 1):
-                raise ValueError("only the last stratum of a call may be left open")
+            if len(part_ends) != self.parts:
+                raise ValueError("one end flag per part")
             per_part = [int(steps_per_part[k]) if k < len(steps_per_part) else 0 for k in range(self.parts)]
             table = bufs[r % 2] if self.world > 1 else self.I
             first = 0
@@ -231,7 +233,9 @@ class RotatingBprmf:
                 first += st
             counts.append(per_part)
             ends.append(part_ends)
-            held = (held + 1) % self.world
+            if part_ends[-1]:                            # the stratum is complete: the next entry trains on the next block
+                held = (held + 1) % self.world
+                r += 1
         handle = self.local.plan(self.U, segments, B)
         return {"handle": handle, "counts": counts, "ends": ends, "B": B, "pending": pending}
 
