@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--overlap", action="store_true",
                     help="A/B: overlapped step stream (item phase of step k beside the user phase of step k+1, hipGraph replays); "
                          "slower than the ordinary stream on this stack, see DESIGN.md section 4")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="N=1: two launches per step (user phase, item phase) instead of the chained step launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-events", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -222,7 +224,7 @@ def single_gpu(args, local_rank):
     # steps — and the timed region builds the plans of the chunks that FOLLOW its own chunks, the last of which is the spare
     # one: K batches' worth of plan builds between the two timestamps, K steps trained.
     u, p, n = synth_triplets((K + W + C) * B, args.users, args.items, dev, 3407, args.zipf)
-    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=args.overlap)
+    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=args.overlap, chain=not args.no_chain)
     losses_w = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
     losses = torch.empty(K, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -249,15 +251,29 @@ def single_gpu(args, local_rank):
     # per-kernel timing: HIP events that the library attaches to the dispatches of the two kernels of each step (the
     # kernels' own start / end timestamps), on a second pass over already planned batches — outside the throughput
     # measurement, so nothing extra sits in the timed region.
-    events, KP = None, 0
+    events, KP, chain_ev, chained = None, 0, None, []
     if not args.no_phase_events:
         KP = min(K, 64, plan.n_batches)
-        events = [torch.cuda.Event(enable_timing=True) for _ in range(4 * KP)]
-        for e in events:
-            e.record()
-        torch.cuda.synchronize()
+
+        def fresh_events():
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4 * KP)]
+            for e in evs:
+                e.record()
+            torch.cuda.synchronize()
+            return evs
+        if handle["chain"] and plan.overlap is not None and KP >= 2:
+            # the chained form first (what the timed region ran): per step ONE launch that carries the user phase of the
+            # step and the item phase of the step before (the first step of a call and steps with too many deferred runs go
+            # out as two launches)
+            chain_ev = fresh_events()
+            tabs.run_sgd_chain(plan, 0, KP, args.lr, phase_events=chain_ev)
+            torch.cuda.synchronize()
+            dc = plan.overlap["def_count_np"]
+            chained = [k for k in range(1, KP) if 0 <= int(dc[k]) <= plan.overlap["cap"]]
+        events = fresh_events()
         tabs.run_sgd(plan, 0, KP, args.lr, phase_events=events)
         torch.cuda.synchronize()
+        tabs.check_chain()
 
     lv = losses.cpu().numpy()
     assert np.all(np.isfinite(lv)), "non-finite loss"
@@ -287,10 +303,18 @@ def single_gpu(args, local_rank):
             name, tk, bk = "bprmf_item_phase", t_item, bytes_item
         else:
             name, tk, bk = "bprmf_user_phase", t_user, bytes_user
+        t_chain = None
+        if chained:
+            # the launch of step k: user phase of batch k + item phase of batch k-1 = one step's algorithmic bytes
+            t_chain = np.mean([chain_ev[4 * k].elapsed_time(chain_ev[4 * k + 1]) for k in chained]) * 1e-3
+            name, tk, bk = "bprmf_chain_step", t_chain, bytes_step
         ach = bk / tk / 1e9
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": None, "kernel": name, "kernel_us": tk * 1e6, "algorithmic_bytes_per_launch": bk,
                     "kernel_us_method": "start/stop events attached to the dispatch (hipExtLaunchKernelGGL)",
+                    "chain_step_us": None if t_chain is None else t_chain * 1e6,
+                    "chained_steps_of_timing_pass": "%d of %d" % (len(chained), KP),
+                    # the two-launch form of the same steps (a second pass; what --no-chain runs)
                     "user_phase_us": t_user * 1e6, "item_phase_us": t_item * 1e6,
                     "user_phase_GBs": bytes_user / t_user / 1e9, "item_phase_GBs": bytes_item / t_item / 1e9,
                     "step_algorithmic_bytes": bytes_step, "step_achieved_GBs": bytes_step * K / dt / 1e9,
@@ -323,6 +347,8 @@ def single_gpu(args, local_rank):
                       "batch": B, "emb_size": D, "optimizer": "SGD", "l2": 0.0, "lr": args.lr,
                       "plan_chunk_batches": C, "tables": "single GPU", "step_stream": "whisprrec_amd.hip_ops.PipelinedSgd",
                       "overlapped_item_phase": bool(plan.overlap is not None and handle["overlap"]),
+                      "chained_step_launch": bool(plan.overlap is not None and handle["chain"]),
+                      "step_stream_calls": dict(pipe.stats),
                       "untimed_priming_steps": 2 * C if args.overlap else 0},
            "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
            "roofline": roofline}

@@ -260,6 +260,33 @@ int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_t
                                  int64_t workspace_bytes, void *stream_main, void *stream_side, void *const *events,
                                  int32_t n_events);
 
+/* Chained step stream — the same consecutive steps as wr_bprmf_run_sgd (BaseRunner.py:194-200, l2 = 0, no hot rows) with
+ * ONE launch per step on ONE stream: the item phase of step k-1 rides, as extra workgroups, in the launch that carries the
+ * user phase of step k.  The runs of batch k that read an item row that item phase rewrites (the plan's deferred runs,
+ * wr_bprmf_plan_overlap_marks) are taken by a few workgroups that first wait, inside the launch, for a counter the item
+ * workgroups add to after their (write-through) row stores; every other run needs no ordering.  Every table row keeps one
+ * writer per step and its summation order: tables bit-identical to wr_bprmf_run_sgd's; the loss of a step differs by the
+ * association of its partial sums only (fixed by the plan, bitwise reproducible).
+ *   tdef, def_q, def_count_host, def_cap as for wr_bprmf_run_sgd_overlap.  A step whose batch has more than
+ *         min(def_cap, def_limit) deferred runs (small item tables: almost every run) is issued as the two ordinary
+ *         launches; the first step of a call always is, and the call ends with an ordinary item-phase launch — on return
+ *         the stream holds complete steps only.
+ *   phase_events (may be NULL): 4 handles per step as for wr_bprmf_run_sgd; [4k], [4k+1] are attached to the launch that
+ *         carries the user phase of step k, [4k+2], [4k+3] to a separate item-phase launch of step k where there is one.
+ *   workspace >= 2 * wr_bprmf_step_workspace_bytes(batch_size, D).
+ *   sync: wr_bprmf_chain_sync_words(n_batches) int32 words of device memory, 16-byte aligned, owned by the caller: one
+ *         (sharded) counter per step from word 0 (zeroed by the call) and, at word sync_words - 4, a sticky word the kernels set when a
+ *         bounded wait expired (zero it once when allocating; non-zero afterwards = the run is invalid).
+ * Rows must be whole 128-byte lines: D % 32 == 0 and both tables 128-byte aligned (wr_bprmf_chain_supported; WR_E_ALIGN). */
+int32_t wr_bprmf_chain_supported(const float *user_tab, const float *item_tab, int32_t D);
+int64_t wr_bprmf_chain_sync_words(int64_t n_batches);
+int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                               const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                               const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                               int64_t n_batches, float lr, float *loss_out, const int32_t *tdef, const int32_t *def_q,
+                               const int32_t *def_count_host, int64_t def_cap, int64_t def_limit, void *const *phase_events,
+                               void *workspace, int64_t workspace_bytes, int32_t *sync, int64_t sync_words, void *stream);
+
 /* Plan-time marks for wr_bprmf_run_sgd_overlap (index work only; call after the plan build, on the same stream).
  *   bitmap [n_batches * ceil(n_items/32)] (out): per batch, bit r = item row r has several occurrences in the batch;
  *   prev_bitmap: that bitmap of the batch BEFORE this plan's first batch, or NULL (then the first batch defers nothing);

@@ -21,14 +21,15 @@ def wrap(obj, name):
     def w(*a, **k):
         t = time.perf_counter(); r = f(*a, **k); log.append((name, (t - T0[0]) * 1e6, (time.perf_counter() - t) * 1e6)); return r
     setattr(obj, name, w)
-for rep in range(3):
-    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1)
+for rep in range(6):
+    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, chain=(rep % 2 == 0))
     for nm in ("_prefetch", "_take_next"):
         wrap(pipe, nm)
     lw = torch.empty(W, device=dev); l = torch.empty(K, device=dev)
     torch.cuda.synchronize()
-    h = pipe.plan(U, [(I, u, p, n)], B, first_chunk=W)
+    h = pipe.plan(U, [(I, u, p, n)], B, first_chunk=[W - W // 2, W // 2])
     wrap(h["segs"][0]["tabs"], "run_sgd")
+    wrap(h["segs"][0]["tabs"], "run_sgd_chain")
     pipe.run_steps(h, W, args.lr, lw)
     torch.cuda.synchronize()
     log.clear()

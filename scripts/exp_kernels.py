@@ -42,3 +42,12 @@ for rep in range(2):
         tabs.run_sgd(plan, 0, 4, 0.05)
         t = timeit(lambda k: tabs.run_sgd(plan, 0, NB, 0.05), 1) / NB
         print("variant %d: step (user+item phase): %.2f us" % (v, t))
+
+# the chained step launch (one launch per step: user phase of step k + item phase of step k-1)
+arena = hip_ops.PlanArena(dev, NB * B, B, overlap_items=nI)
+plan_c = hip_ops.BatchPlan(u.to(torch.int32), p.to(torch.int32), n.to(torch.int32), B, nU, nI, arena=arena, overlap=True)
+tabs.run_sgd_chain(plan_c, 0, 4, 0.05)
+for rep in range(2):
+    t = timeit(lambda k: tabs.run_sgd_chain(plan_c, 0, NB, 0.05), 1) / NB
+    print("chained step launch: %.2f us/step" % t)
+tabs.check_chain()

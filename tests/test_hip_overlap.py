@@ -73,9 +73,10 @@ def test_marks_match_their_definition(ops, nI, B):
         assert np.array_equal(def_q[b, :min(want.size, cap)], want[:cap])
         prev_multi = multi
     if nI == 3000:
-        assert plan.overlap is None and counts.max() > cap                             # lists beyond capacity: ordinary stream
+        # lists beyond capacity: not for the two-stream form (the chained launch decides per step)
+        assert plan.overlap is not None and not plan.overlap["fits"] and counts.max() > cap
     else:
-        assert plan.overlap is not None and counts[0] == 0 and counts[1:].min() > 0
+        assert plan.overlap is not None and plan.overlap["fits"] and counts[0] == 0 and counts[1:].min() > 0
 
 
 @pytest.mark.parametrize("nI,D", [(200_000, 64), (60_000, 64), (60_000, 128), (90_000, 32)])
@@ -129,7 +130,7 @@ def test_pipeline_picks_the_stream_per_plan_and_results_do_not_depend_on_it(ops,
     I = (rng.standard_normal((nI, D)) * 0.2).astype(np.float32)
     res, used = [], []
     for overlap in (True, False):
-        pipe = ops.PipelinedSgd(chunk=4, min_triplets=1, overlap=overlap)
+        pipe = ops.PipelinedSgd(chunk=4, min_triplets=1, overlap=overlap, chain=False)
         Ud, Id = T(U, dev), T(I, dev)
         h = pipe.plan(Ud, [(Id, T(u, dev), T(p, dev), T(n, dev))], B, lr=lr if case != "hot_rows" else None)
         losses = torch.empty(nb, dtype=torch.float32, device=dev)

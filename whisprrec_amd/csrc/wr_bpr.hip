@@ -355,21 +355,20 @@ __device__ __forceinline__ void finish_user_row(float *__restrict__ U, float *__
 //   1  every head whose bit in `dmask` is clear — the runs that read no item row the PREVIOUS batch's item phase is still
 //      rewriting, so this launch may run beside that item phase;
 //   2  the heads listed in `dlist` (the deferred runs: positions in ascending order), one team each.
-template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT, int DEF = 0>
-__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? WR_USER_WAVES : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
-                                                            const int *__restrict__ tu, const int *__restrict__ tp,
-                                                            const int *__restrict__ tn, int B, float lr, float l2,
-                                                            float *__restrict__ Z, float *__restrict__ partials,
-                                                            float *__restrict__ gradU, int *__restrict__ stampU,
-                                                            float *__restrict__ gradI, int *__restrict__ stampI,
-                                                            int step_id, float denom, AdamArgs ad,
-                                                            const int *__restrict__ dmask,
-                                                            const int *__restrict__ dlist, int n_list,
-                                                            const int *__restrict__ n_list_dev) {
-    __shared__ float scratch[kBlock / 64];
+// `vblock` is the workgroup's index within the phase (blockIdx.x for the plain launches; the chained step launch carries
+// several kinds of workgroups and numbers each kind itself); the workgroup's loss partial goes to *partial_out.
+template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT, int DEF>
+__device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I, int D, const int *__restrict__ tu,
+                                                 const int *__restrict__ tp, const int *__restrict__ tn, int B, float lr,
+                                                 float l2, float *__restrict__ Z, float *__restrict__ partial_out,
+                                                 float *__restrict__ gradU, int *__restrict__ stampU,
+                                                 float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
+                                                 float denom, const AdamArgs &ad, const int *__restrict__ dmask,
+                                                 const int *__restrict__ dlist, int n_list,
+                                                 const int *__restrict__ n_list_dev, int vblock, float *scratch) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
-    const int team = blockIdx.x * TEAMS + threadIdx.x / T;
+    const int team = vblock * TEAMS + threadIdx.x / T;
     const int seg = (B + SLOTS - 1) / SLOTS;
     float term_acc = 0.f;
 
@@ -502,7 +501,24 @@ __global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKI
     }
     if (lane != 0) term_acc = 0.f;  // every lane of a team holds the same terms: count them once
     const float sum = block_sum(term_acc, scratch);
-    if (threadIdx.x == 0) partials[blockIdx.x] = sum;
+    if (threadIdx.x == 0) *partial_out = sum;
+}
+
+template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT, int DEF = 0>
+__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? WR_USER_WAVES : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
+                                                            const int *__restrict__ tu, const int *__restrict__ tp,
+                                                            const int *__restrict__ tn, int B, float lr, float l2,
+                                                            float *__restrict__ Z, float *__restrict__ partials,
+                                                            float *__restrict__ gradU, int *__restrict__ stampU,
+                                                            float *__restrict__ gradI, int *__restrict__ stampI,
+                                                            int step_id, float denom, AdamArgs ad,
+                                                            const int *__restrict__ dmask,
+                                                            const int *__restrict__ dlist, int n_list,
+                                                            const int *__restrict__ n_list_dev) {
+    __shared__ float scratch[kBlock / 64];
+    user_phase_block<T, NV, FULL, MODE, SLOTS, SKIP_HOT, DEF>(U, I, D, tu, tp, tn, B, lr, l2, Z, partials + blockIdx.x, gradU,
+                                                              stampU, gradI, stampI, step_id, denom, ad, dmask, dlist, n_list,
+                                                              n_list_dev, (int)blockIdx.x, scratch);
 }
 
 // Hot users: a piece = up to kHotPiece consecutive triplets of ONE user.  One workgroup per piece: every team holds the
@@ -632,7 +648,9 @@ __device__ __forceinline__ void item_hot_piece(int piece, int D, const int *__re
 }
 
 // torch.optim.SGD on a finished item row (g' = g + l2 w ; w -= lr g'), or the gradient row itself for MODE != 0
-template <int T, int NV, bool FULL, int MODE>
+// WT: the row is stored write-through (store_row_wt) — the chained step launch hands these rows to other workgroups of
+// the same launch (bprmf_chain_step).
+template <int T, int NV, bool FULL, int MODE, bool WT = false>
 __device__ __forceinline__ void finish_item_row(float *__restrict__ I, float *__restrict__ gradI, int *__restrict__ stampI,
                                                 int step_id, int r, int D, int lane, float lr, float l2, const Row<NV> &ir,
                                                 const Row<NV> &g, const AdamArgs &ad) {
@@ -649,53 +667,47 @@ __device__ __forceinline__ void finish_item_row(float *__restrict__ I, float *__
             w.v[k].z = ir.v[k].z - lr * fmaf(l2, ir.v[k].z, g.v[k].z);
             w.v[k].w = ir.v[k].w - lr * fmaf(l2, ir.v[k].w, g.v[k].w);
         }
-        store_row<T, NV, FULL>(I, r, D, lane, w);
+        if constexpr (WT) store_row_wt<T, NV, FULL>(I, r, D, lane, w);
+        else store_row<T, NV, FULL>(I, r, D, lane, w);
     } else {
         store_row<T, NV, FULL>(gradI, r, D, lane, g);
     }
     if (stampI != nullptr && lane == 0) stampI[r] = step_id;
 }
 
-template <int T, int NV, bool FULL, int MODE, bool PIECES>
-__global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I, int D, const int *__restrict__ oc_item,
-                                                            const int *__restrict__ oc_src, int B2,
-                                                            const float *__restrict__ Z, float lr, float l2,
-                                                            float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
-                                                            const float *__restrict__ partials, int n_partials,
-                                                            float loss_denom, float *__restrict__ loss_out, int skip_hot,
-                                                            const unsigned long long *__restrict__ hot_loss, int n_tiles,
-                                                            const int *__restrict__ piece_q, const int *__restrict__ piece_len,
-                                                            float *__restrict__ hotP, AdamArgs ad) {
-    if constexpr (PIECES) {                 // this instantiation carries hot pieces as extra workgroups (one each; they are
-        extern __shared__ float piece_rows[];   // independent of the tiles' rows); the lean one keeps its 32 VGPRs
-        if ((int)blockIdx.x >= n_tiles) {
-            item_hot_piece<T, NV, FULL>((int)blockIdx.x - n_tiles, D, oc_src, Z, piece_q, piece_len, hotP, piece_rows);
-            return;
-        }
-    }
+// One tile of the item phase (TILE sorted occurrences); `vblock` = the tile's index.
+template <int T, int NV, bool FULL, int MODE, bool PIECES, bool WT, int TILE = kItemTile>
+__device__ __forceinline__ void item_tile_block(float *__restrict__ I, int D, const int *__restrict__ oc_item,
+                                                const int *__restrict__ oc_src, int B2, const float *__restrict__ Z, float lr,
+                                                float l2, float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
+                                                const float *__restrict__ partials, int n_partials, float loss_denom,
+                                                float *__restrict__ loss_out, const unsigned long long *__restrict__ hot_loss,
+                                                const AdamArgs &ad, int vblock) {
+    static_assert(TILE <= kBlock && TILE >= 32, "item tile");
+    static_assert(!WT || MODE == 0, "write-through rows: plain SGD only");
     __shared__ float scratch[kBlock / 64];
-    __shared__ int heads[kItemTile];
+    __shared__ int heads[TILE];
     // entries staged beyond the tile: with a hot-run list every run that starts in the tile is in LDS up to the entry that
     // proves it hot; without one, eight (longer runs go on from the plan arrays)
     constexpr int kAhead = PIECES ? kHotRun + 1 : 8;
-    __shared__ int item_tile[kItemTile + kAhead];
-    __shared__ int src_tile[kItemTile + kAhead];
+    __shared__ int item_tile[TILE + kAhead];
+    __shared__ int src_tile[TILE + kAhead];
     __shared__ int n_heads;
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
-    const int tile0 = blockIdx.x * kItemTile;
+    const int tile0 = vblock * TILE;
     // 1) one THREAD per sorted occurrence: stage the tile's (item, source) pairs in LDS, find the heads of runs
     //    of >= 2 equal item rows and compact them (single-occurrence rows were finished by the user phase; the
     //    order of the list is irrelevant: every run is an independent row).  One global round trip.
     if (threadIdx.x == 0) n_heads = 0;
-    for (int i = threadIdx.x; i < kItemTile + kAhead; i += kBlock) {   // the tile plus kAhead entries beyond it
+    for (int i = threadIdx.x; i < TILE + kAhead; i += kBlock) {   // the tile plus kAhead entries beyond it
         const int q = tile0 + i;
         item_tile[i] = (q < B2) ? oc_item[q] : -1;
         src_tile[i] = (q < B2) ? oc_src[q] : 0;
     }
     const int prev_item = (threadIdx.x == 0) ? ((tile0 > 0 && tile0 < B2) ? oc_item[tile0 - 1] : -1) : 0;
     __syncthreads();
-    if (threadIdx.x < kItemTile) {
+    if (threadIdx.x < TILE) {
         const int r = item_tile[threadIdx.x];
         if (r >= 0) {
             const int before = (threadIdx.x == 0) ? prev_item : item_tile[threadIdx.x - 1];
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                 if constexpr (MODE == 4)
                     adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
                 else
-                    finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
+                    finish_item_row<T, NV, FULL, MODE, WT>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             } else {
                 // no hot-run list for this batch (none, or a plan built without one): walk the run to its end, whatever
                 // its length — from LDS inside the staged window, from the plan arrays beyond it.  One stashed row at a
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                 for (;;) {
                     const int q = tile0 + j;
                     if (q >= B2) break;
-                    const bool in_lds = j < kItemTile + kAhead;
+                    const bool in_lds = j < TILE + kAhead;
                     const int it = in_lds ? item_tile[j] : oc_item[q];
                     if (it != r) break;
                     const int src = in_lds ? src_tile[j] : oc_src[q];
@@ -794,11 +806,11 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
                 if constexpr (MODE == 4)
                     adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
                 else
-                    finish_item_row<T, NV, FULL, MODE>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
+                    finish_item_row<T, NV, FULL, MODE, WT>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             }
         }
     }
-    if (blockIdx.x == 0 && loss_out != nullptr) {  // uniform per block: fold the user phase's partials
+    if (vblock == 0 && loss_out != nullptr) {  // uniform per block: fold the user phase's partials
         const float a = strided_partial_sum(partials, n_partials);
         float s = block_sum(a, scratch);
         if (threadIdx.x == 0) {
@@ -806,6 +818,27 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I
             loss_out[0] = s / loss_denom;
         }
     }
+}
+
+template <int T, int NV, bool FULL, int MODE, bool PIECES>
+__global__ __launch_bounds__(kBlock) void bprmf_item_phase(float *__restrict__ I, int D, const int *__restrict__ oc_item,
+                                                            const int *__restrict__ oc_src, int B2,
+                                                            const float *__restrict__ Z, float lr, float l2,
+                                                            float *__restrict__ gradI, int *__restrict__ stampI, int step_id,
+                                                            const float *__restrict__ partials, int n_partials,
+                                                            float loss_denom, float *__restrict__ loss_out, int skip_hot,
+                                                            const unsigned long long *__restrict__ hot_loss, int n_tiles,
+                                                            const int *__restrict__ piece_q, const int *__restrict__ piece_len,
+                                                            float *__restrict__ hotP, AdamArgs ad) {
+    if constexpr (PIECES) {                 // this instantiation carries hot pieces as extra workgroups (one each; they are
+        extern __shared__ float piece_rows[];   // independent of the tiles' rows); the lean one keeps its 32 VGPRs
+        if ((int)blockIdx.x >= n_tiles) {
+            item_hot_piece<T, NV, FULL>((int)blockIdx.x - n_tiles, D, oc_src, Z, piece_q, piece_len, hotP, piece_rows);
+            return;
+        }
+    }
+    item_tile_block<T, NV, FULL, MODE, PIECES, false>(I, D, oc_item, oc_src, B2, Z, lr, l2, gradI, stampI, step_id, partials,
+                                                     n_partials, loss_denom, loss_out, hot_loss, ad, (int)blockIdx.x);
 }
 
 // One team per hot row: adds its pieces in piece order and finishes the row like the item phase does.
@@ -1097,6 +1130,218 @@ static int32_t launch_overlap_steps(float *U, float *I, int32_t D, const int32_t
     return WR_OK;
 }
 
+// ----------------------------------------------------------------------------------------------- chained step launch
+// ONE launch per step: the item phase of step k-1 rides in the launch that carries the user phase of step k, so its ~5 us
+// of latency (two dependent round trips over ~8 K rows) and the kernel boundary in front of it are hidden behind 20 us of
+// user-phase traffic.  The launch has three kinds of workgroups, numbered by segments of blockIdx.x:
+//     item tiles of batch k-1   rows with several occurrences in batch k-1 are summed and rewritten — WRITE-THROUGH
+//                               (store_row_wt) — then every wave waits for its stores, the workgroup meets at a barrier and
+//                               one lane adds 1 to the step's counter (agent scope);
+//     user runs of batch k      all heads whose bit in the plan's deferred mask is clear (DEF = 1): they read and write no
+//                               row an item tile of this launch touches (wr_overlap.hip: the plan marks every run of batch k
+//                               that reads a row with several occurrences in batch k-1) — no ordering needed;
+//     deferred runs of batch k  (~1.6 % of the runs at 1M x 1M, B = 65,536) at most kChainDefBlocks workgroups walk the
+//                               plan's list of deferred heads (DEF = 2): one lane polls the counter (relaxed, agent scope)
+//                               until every item tile has signalled, then ONE agent-scope acquire, s_waitcnt vmcnt(0), a
+//                               workgroup barrier, and plain loads.
+// Forward progress does not rest on dispatch order: only the deferred workgroups ever wait, there are at most
+// kChainDefBlocks (128) of them — fewer than the 256 CUs each hold at least one workgroup — and nothing they wait for
+// waits itself, so a free slot always goes to a workgroup that runs to completion.  The poll is bounded all the same (an
+// exit every wave reaches): on expiry the sticky word `timeout` is set and the workgroup goes on; the host treats a
+// non-zero word as a failed run (never observed).
+// Rows are handed over in whole 128-B lines (the host takes this path only when D * 4 is a multiple of 128 and the tables
+// are 128-B aligned), so no line holds bytes of a row an undeferred run touches beside bytes an item tile rewrites.
+// Every table row still has exactly one writer per step and the same summation order: tables bit-identical to the
+// two-launch step (tests/test_hip_chain.py).  The loss of a step is summed over more partials (one per deferred chunk): same
+// terms, another grouping — equal to ~1 ulp, and a deterministic function of the plan.
+// WR_CHAIN_DBG (timing experiments only, never in the shipped build; all variants stay inside the arrays — indices come
+// from the plan, not from table values): 1 = no acquire fence, 2 = plain row stores, 4 = no wait for the item tiles,
+// 8 = item tiles only signal, 16 = no deferred workgroups.
+#ifndef WR_CHAIN_DBG
+#define WR_CHAIN_DBG 0
+#endif
+constexpr int kChainDefBlocks = 128;
+constexpr int kChainShards = 64;        // shards of a step's counter
+constexpr int kChainShardStride = 16;   // words between shards (64 B)
+constexpr int kChainStepWords = kChainShards * kChainShardStride;
+constexpr unsigned kChainSpinLimit = 1u << 22;   // polls of ~0.25 us (s_sleep 8): about a second
+
+template <int T, int NV, bool FULL, int TILE>
+__global__ __launch_bounds__(kBlock, NV == 1 ? WR_USER_WAVES : 1) void bprmf_chain_step(
+    float *__restrict__ U, float *I, int D,
+    // item tiles: batch k-1
+    const int *__restrict__ oc_item, const int *__restrict__ oc_src, int B2_prev, const float *__restrict__ Z_prev,
+    const float *__restrict__ partials_prev, int n_partials_prev, float denom_prev, float *__restrict__ loss_prev,
+    int n_item_blocks, int item_at,
+    // user runs: batch k
+    const int *__restrict__ tu, const int *__restrict__ tp, const int *__restrict__ tn, int B, float lr,
+    float *__restrict__ Z, float *__restrict__ partials, float denom, const int *__restrict__ dmask,
+    const int *__restrict__ dlist, int n_def, int n_user_blocks, int def_at, int n_def_blocks,
+    unsigned *__restrict__ done, unsigned *__restrict__ timeout) {
+    __shared__ float scratch[kBlock / 64];
+    constexpr int TEAMS = kBlock / T;
+    const AdamArgs ad{};
+    // blockIdx.x -> kind: [user 0 .. item_at) [item tiles] [user item_at .. def_at) [deferred] [user def_at .. n_user_blocks)
+    int b = (int)blockIdx.x;
+    if (b >= item_at && b < item_at + n_item_blocks) {
+        if (!(WR_CHAIN_DBG & 8))
+        item_tile_block<T, NV, FULL, 0, false, !(WR_CHAIN_DBG & 2), TILE>(I, D, oc_item, oc_src, B2_prev, Z_prev, lr, 0.f, nullptr, nullptr, 0,
+                                                           partials_prev, n_partials_prev, denom_prev, loss_prev, nullptr, ad,
+                                                           b - item_at);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its write-through stores have left
+        __syncthreads();
+        // the counter is kept in kChainShards shards on lines of their own: atomic adds execute at the memory side, one
+        // address takes one every 10-20 ns (2,048 tiles adding to ONE word held the launch for 22 us)
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_add(done + ((b - item_at) % kChainShards) * kChainShardStride, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (b >= item_at) b -= n_item_blocks;
+    if (b >= def_at && b < def_at + n_def_blocks) {
+        if (threadIdx.x < 64) {   // wave 0: lane j polls shard j until it holds the adds of all tiles j, j + 64, ...
+            const int j = (int)threadIdx.x;
+            const unsigned want = j < kChainShards ? (unsigned)((n_item_blocks - j + kChainShards - 1) / kChainShards) : 0u;
+            const unsigned *shard = done + (j < kChainShards ? j : 0) * kChainShardStride;
+            unsigned spins = 0;
+            while (!(WR_CHAIN_DBG & 4)) {
+                const bool ok = __hip_atomic_load(shard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > kChainSpinLimit) {
+                    if (j == 0) __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+#if !(WR_CHAIN_DBG & 1)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        }
+        __syncthreads();
+        const int n_chunks = (n_def + TEAMS - 1) / TEAMS;
+        for (int c = b - def_at; c < n_chunks; c += n_def_blocks) {
+            user_phase_block<T, NV, FULL, 0, 1, false, 2>(U, I, D, tu, tp, tn, B, lr, 0.f, Z, partials + n_user_blocks + c, nullptr,
+                                                          nullptr, nullptr, nullptr, 0, denom, ad, nullptr, dlist, n_def, nullptr,
+                                                          c, scratch);
+            __syncthreads();   // the next chunk reuses the loss scratch
+        }
+        return;
+    }
+    if (b >= def_at) b -= n_def_blocks;
+    user_phase_block<T, NV, FULL, 0, 1, false, 1>(U, I, D, tu, tp, tn, B, lr, 0.f, Z, partials + b, nullptr, nullptr, nullptr,
+                                                  nullptr, 0, denom, ad, dmask, nullptr, 0, nullptr, b, scratch);
+}
+
+// Where the item tiles and the deferred workgroups sit among the user workgroups (fractions of the user grid, in 1/16):
+// WR_CHAIN_ITEM_AT = 0: the tiles are dispatched first, WR_CHAIN_DEF_AT = 8: the deferred workgroups after half the others.
+#ifndef WR_CHAIN_ITEM_AT
+#define WR_CHAIN_ITEM_AT 0
+#endif
+#ifndef WR_CHAIN_DEF_AT
+#define WR_CHAIN_DEF_AT 8
+#endif
+#ifndef WR_CHAIN_TILE
+#define WR_CHAIN_TILE 64
+#endif
+
+static inline bool chain_shape_ok(const float *U, const float *I, int32_t D) {
+    return (D * 4) % 128 == 0 && (reinterpret_cast<uintptr_t>(U) & 127u) == 0 && (reinterpret_cast<uintptr_t>(I) & 127u) == 0;
+}
+
+template <int T, int NV, bool FULL>
+static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
+                                  const int32_t *oc_item, const int32_t *oc_src, int64_t n_triplets, int64_t batch_size,
+                                  int64_t first_batch, int64_t n_batches, float lr, float *loss_out, const int32_t *tdef,
+                                  const int32_t *def_q, const int32_t *def_count_host, int64_t def_cap, int64_t def_limit,
+                                  void *workspace, uint32_t *sync, int64_t sync_words, hipStream_t stream,
+                                  void *const *events) {
+    const int64_t ws_one = step_ws_bytes(batch_size, D);
+    const StepWs w2[2] = {carve_step_ws(workspace, batch_size, D),
+                          carve_step_ws(reinterpret_cast<char *>(workspace) + ws_one, batch_size, D)};
+    const int64_t dwords = (batch_size + 31) / 32;
+    constexpr int TEAMS = kBlock / T;
+    const dim3 block(kBlock);
+    const AdamArgs ad{};
+    // sync: one sharded counter per step of this call, zeroed here (the block starts the allocation and is a multiple of 16
+    // bytes); the sticky timeout word is the first of the buffer's last four words
+    const int64_t n_ctr = n_batches * kChainStepWords;
+    WR_HIP(hipMemsetAsync(sync, 0, (size_t)n_ctr * 4, stream));
+    uint32_t *timeout = sync + (sync_words - 4);
+    auto ev = [&](int64_t k, int j) { return events ? reinterpret_cast<hipEvent_t>(events[4 * k + j]) : (hipEvent_t) nullptr; };
+    // the item phase of the previous step, not yet launched: its arrays and what its loss needs
+    struct Pending { bool on; int64_t off, Bk; int n_partials; int64_t k; } pend{false, 0, 0, 0, 0};
+    auto launch_item = [&](const Pending &q, hipEvent_t e0, hipEvent_t e1) -> int32_t {
+        const StepWs &w = w2[q.k & 1];
+        const dim3 gridB((unsigned)((2 * q.Bk + kItemTile - 1) / kItemTile));
+        if (e0 != nullptr || e1 != nullptr)
+            hipExtLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, 0, false>), gridB, block, 0, stream, e0, e1, 0, I, D,
+                                  oc_item + 2 * q.off, oc_src + 2 * q.off, (int)(2 * q.Bk), w.Z, lr, 0.f, (float *)nullptr,
+                                  (int *)nullptr, 0, w.partials, q.n_partials, (float)q.Bk, loss_out ? loss_out + q.k : nullptr, 0,
+                                  (const unsigned long long *)nullptr, (int)gridB.x, (const int *)nullptr, (const int *)nullptr,
+                                  (float *)nullptr, ad);
+        else
+            hipLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, 0, false>), gridB, block, 0, stream, I, D, oc_item + 2 * q.off,
+                               oc_src + 2 * q.off, (int)(2 * q.Bk), w.Z, lr, 0.f, (float *)nullptr, (int *)nullptr, 0, w.partials,
+                               q.n_partials, (float)q.Bk, loss_out ? loss_out + q.k : nullptr, 0,
+                               (const unsigned long long *)nullptr, (int)gridB.x, (const int *)nullptr, (const int *)nullptr,
+                               (float *)nullptr, ad);
+        WR_LAUNCH_CHECK("bprmf_item_phase (chain)");
+        return WR_OK;
+    };
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t b = first_batch + k;
+        const int64_t off = b * batch_size;
+        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
+        const StepWs &w = w2[k & 1];
+        const int nA = (int)n_blocks_for(Bk, D);
+        const int n_def = (k == 0 || !pend.on) ? -1 : def_count_host[b];
+        const bool chained = pend.on && n_def >= 0 && n_def <= def_cap && n_def <= def_limit;
+        if (chained) {
+            const int n_chunks = (WR_CHAIN_DBG & 16) ? 0 : (n_def + TEAMS - 1) / TEAMS;
+            const int nD = n_chunks < kChainDefBlocks ? n_chunks : kChainDefBlocks;
+            const int nI = (int)((2 * pend.Bk + WR_CHAIN_TILE - 1) / WR_CHAIN_TILE);
+            const int item_at = (int)((int64_t)nA * WR_CHAIN_ITEM_AT / 16), def_at = (int)((int64_t)nA * WR_CHAIN_DEF_AT / 16);
+            const StepWs &wp = w2[pend.k & 1];
+            const dim3 grid((unsigned)(nA + nI + nD));
+            hipEvent_t e0 = ev(k, 0), e1 = ev(k, 1);
+#define WR_CHAIN_ARGS                                                                                                       \
+    U, I, D, oc_item + 2 * pend.off, oc_src + 2 * pend.off, (int)(2 * pend.Bk), wp.Z, wp.partials, pend.n_partials,           \
+        (float)pend.Bk, loss_out ? loss_out + pend.k : (float *)nullptr, nI, item_at, tu + off, tp + off, tn + off, (int)Bk, lr,  \
+        w.Z, w.partials, (float)Bk, tdef + b * dwords, def_q + b * def_cap, n_def, nA, def_at, nD, sync + k * kChainStepWords,   \
+        timeout
+            if (e0 != nullptr || e1 != nullptr)
+                hipExtLaunchKernelGGL((bprmf_chain_step<T, NV, FULL, WR_CHAIN_TILE>), grid, block, 0, stream, e0, e1, 0,
+                                      WR_CHAIN_ARGS);
+            else
+                hipLaunchKernelGGL((bprmf_chain_step<T, NV, FULL, WR_CHAIN_TILE>), grid, block, 0, stream, WR_CHAIN_ARGS);
+#undef WR_CHAIN_ARGS
+            WR_LAUNCH_CHECK("bprmf_chain_step");
+            pend = Pending{true, off, Bk, nA + n_chunks, k};
+        } else {
+            if (pend.on) {
+                const int32_t rc = launch_item(pend, ev(pend.k, 2), ev(pend.k, 3));
+                if (rc != WR_OK) return rc;
+            }
+            hipEvent_t e0 = ev(k, 0), e1 = ev(k, 1);
+#define WR_PLAIN_ARGS                                                                                                       \
+    U, I, D, tu + off, tp + off, tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr,              \
+        (float *)nullptr, (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, (const int *)nullptr, 0, (const int *)nullptr
+            if (e0 != nullptr || e1 != nullptr)
+                hipExtLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 0>), dim3((unsigned)nA), block, 0, stream, e0, e1,
+                                      0, WR_PLAIN_ARGS);
+            else
+                hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 0>), dim3((unsigned)nA), block, 0, stream,
+                                   WR_PLAIN_ARGS);
+#undef WR_PLAIN_ARGS
+            WR_LAUNCH_CHECK("bprmf_user_phase (chain, first)");
+            pend = Pending{true, off, Bk, nA, k};
+        }
+    }
+    if (pend.on) return launch_item(pend, ev(pend.k, 2), ev(pend.k, 3));
+    return WR_OK;
+}
+
 static int32_t check_plan_args(const void *tu, const void *tp, const void *tn, const void *oc_item, const void *oc_src,
                                int64_t B) {
     WR_REQUIRE(tu && tp && tn && oc_item && oc_src, WR_E_NULL, "plan arrays must not be NULL");
@@ -1363,5 +1608,48 @@ int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_t
 #undef WR_CALL_OVL
     return WR_OK;
 }
+
+int32_t wr_bprmf_chain_supported(const float *user_tab, const float *item_tab, int32_t D) {
+    return (user_tab && item_tab && D >= 4 && D <= 1024 && D % 4 == 0 && chain_shape_ok(user_tab, item_tab, D)) ? 1 : 0;
+}
+
+int64_t wr_bprmf_chain_sync_words(int64_t n_batches) { return n_batches < 0 ? WR_E_SHAPE : n_batches * kChainStepWords + 4; }
+
+int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                               const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                               const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                               int64_t n_batches, float lr, float *loss_out, const int32_t *tdef, const int32_t *def_q,
+                               const int32_t *def_count_host, int64_t def_cap, int64_t def_limit, void *const *events,
+                               void *workspace, int64_t workspace_bytes, int32_t *sync, int64_t sync_words, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, batch_size)) != WR_OK) return rc;
+    WR_REQUIRE(tdef && def_q && def_count_host && sync, WR_E_NULL, "chain marks / sync words must not be NULL");
+    WR_REQUIRE(chain_shape_ok(user_tab, item_tab, D), WR_E_ALIGN,
+               "wr_bprmf_run_sgd_chain: rows must be whole 128-B lines (D %% 32 == 0, tables 128-B aligned); D = %d", (int)D);
+    WR_REQUIRE(n_triplets > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(def_cap > 0 && def_limit >= 0, WR_E_RANGE, "bad deferred-run capacity");
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 2 * step_ws_bytes(batch_size, D), WR_E_WORKSPACE,
+               "wr_bprmf_run_sgd_chain: workspace %lld B < %lld B", (long long)workspace_bytes,
+               (long long)(2 * step_ws_bytes(batch_size, D)));
+    WR_REQUIRE(aligned16(sync) && sync_words >= n_batches * kChainStepWords + 4, WR_E_WORKSPACE,
+               "wr_bprmf_run_sgd_chain: %lld sync words < %lld", (long long)sync_words,
+               (long long)(n_batches * kChainStepWords + 4));
+    if (n_batches == 0) return WR_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+#define WR_CALL_CHAIN(T_, NV_, FULL_)                                                                                      \
+    return launch_chain_steps<T_, NV_, FULL_>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, n_triplets, batch_size,   \
+                                              first_batch, n_batches, lr, loss_out, tdef, def_q, def_count_host, def_cap,  \
+                                              def_limit, workspace, reinterpret_cast<uint32_t *>(sync), sync_words, stream, \
+                                              events)
+    WR_DISPATCH_D(D, WR_CALL_CHAIN);
+#undef WR_CALL_CHAIN
+    return WR_OK;
+}
+
 
 }  // extern "C"

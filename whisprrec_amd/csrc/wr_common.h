@@ -131,6 +131,26 @@ __device__ __forceinline__ void store_row(float *__restrict__ base, int64_t row,
     }
 }
 
+// 16-byte write-through store (`sc1`): the bytes go to memory at once instead of staying dirty in this XCD's L2 — the store
+// form for rows that another workgroup of the SAME launch reads after a counter hand-off (bprmf_chain_step, wr_bpr.hip).
+// The compiler does not count an asm store: the storing wave waits with its own s_waitcnt vmcnt(0) before it signals.
+// s_nop 1: the data registers may be rewritten by the next instruction only after the store has read them.
+typedef float wr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(float4 *p, const float4 &v) {
+    const wr_f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+}
+
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ void store_row_wt(float *__restrict__ base, int64_t row, int D, int lane, const Row<NV> &r) {
+    float4 *p = reinterpret_cast<float4 *>(base + row * (int64_t)D);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = chunk_of<T>(lane, k);
+        if (FULL || c * 4 < D) store16_wt(p + c, r.v[k]);
+    }
+}
+
 template <int NV>
 __device__ __forceinline__ float dot_partial(const Row<NV> &a, const Row<NV> &b) {
     float s = 0.f;

@@ -515,8 +515,12 @@ class BatchPlan:
         if self._want_overlap and self.hot is None:
             o, nb, cb = self.arena.overlap, self.n_batches, self._cap_batches
             dc = mh[self.META_HEAD + 4 * cb:self.META_HEAD + 4 * cb + nb]
-            if nb >= 2 and int(dc.min()) >= 0 and int(dc.max()) <= o["cap"]:
+            dcn = self.arena.meta_np[self.META_HEAD + 4 * cb:self.META_HEAD + 4 * cb + nb]
+            if nb >= 2 and int(dcn.min()) >= 0:
+                # "fits": every batch's list of deferred runs is within capacity (the two-stream form needs that; the
+                # chained launch decides per step)
                 self.overlap = {"tdef": o["tdef"], "def_q": o["def_q"], "def_count_host": dc, "cap": o["cap"],
+                                "def_count_np": dcn, "fits": int(dcn.max()) <= o["cap"],
                                 "def_count_dev": self.meta[self.META_HEAD + 4 * cb:self.META_HEAD + 5 * cb]}
         self._finished = True
         return self
@@ -665,6 +669,12 @@ class BprmfTables:
         return workspace(self.dev, "step_overlap").get(nbytes)
 
     def run_sgd_overlap(self, plan, first, count, lr, losses, side, events, static=False, ws=None):
+        if plan.overlap is None or not plan.overlap.get("fits", True):
+            raise abi.WhisprRecHipError("run_sgd_overlap: the plan does not qualify (hot rows, or deferred-run lists beyond "
+                                        "capacity)")
+        return self._run_sgd_overlap(plan, first, count, lr, losses, side, events, static, ws)
+
+    def _run_sgd_overlap(self, plan, first, count, lr, losses, side, events, static=False, ws=None):
         """`count` consecutive steps like run_sgd, as the overlapped stream (wr_bprmf_run_sgd_overlap): item phase of step k
         on stream `side` beside the user phase of step k+1 on the current stream.  plan.overlap must be set (BatchPlan
         built with overlap=True that qualified).  events: OverlapEvents.  Same tables, bit for bit, as run_sgd.
@@ -682,6 +692,62 @@ class BprmfTables:
                                              _p(o["def_count_dev"]) if static else None, o["cap"], _p(ws), ws.numel(),
                                              _stream(), side.cuda_stream, ctypes.addressof(events.array), events.n),
                   "wr_bprmf_run_sgd_overlap")
+        self.step_id += count
+        return losses
+
+    def chain_supported(self):
+        """rows are whole 128-byte lines (D % 32 == 0, tables 128-byte aligned): the chained step launch applies"""
+        return bool(abi.lib().wr_bprmf_chain_supported(_p(self.U), _p(self.I), self.D))
+
+    CHAIN_SYNC_STEPS = 256      # the hand-off counters are sized for calls of this many steps up front (1 MB): growing
+                                # them means an allocation in the middle of a step stream
+
+    def _chain_sync(self, count):
+        if not hasattr(self, "_syncs"):
+            self._syncs = []
+        if not self._syncs or self._syncs[-1].numel() < int(abi.lib().wr_bprmf_chain_sync_words(count)):
+            words = int(abi.lib().wr_bprmf_chain_sync_words(max(count, self.CHAIN_SYNC_STEPS)))
+            self._syncs.append(torch.zeros(words, dtype=torch.int32, device=self.dev))   # older ones stay for check_chain
+        return self._syncs[-1]
+
+    def check_chain(self):
+        """raises if a bounded wait inside a chained step launch ever expired on these tables (synchronises; call it where
+        the caller waits for the device anyway: end of an epoch, end of a benchmark)"""
+        for buf in getattr(self, "_syncs", []):
+            if int(buf[-4].item()) != 0:
+                raise abi.WhisprRecHipError("chained step launch: a wait for the item tiles expired — the tables are not valid")
+
+    def run_sgd_chain(self, plan, first, count, lr, losses=None, phase_events=None, ws=None, def_limit=None):
+        """`count` consecutive steps like run_sgd, one launch per step (wr_bprmf_run_sgd_chain): the item phase of step k-1
+        rides in the launch of step k's user phase.  plan.overlap must be set (BatchPlan built with overlap=True that
+        qualified: no hot rows, deferred-run lists within capacity).  Same tables, bit for bit, as run_sgd."""
+        L = abi.lib()
+        o = plan.overlap
+        if ws is None:
+            ws = self.overlap_workspace(plan.batch_size)
+        if losses is None:
+            losses = torch.empty(count, dtype=torch.float32, device=self.dev)
+        ev = None
+        if phase_events is not None:
+            if len(phase_events) != 4 * count:
+                raise ValueError("phase_events must hold 4 events per step")
+            handles = []
+            for e in phase_events:
+                if e is None:
+                    handles.append(None)
+                    continue
+                if not e.cuda_event:
+                    e.record()
+                handles.append(e.cuda_event)
+            ev = (ctypes.c_void_p * len(handles))(*handles)
+        sync = self._chain_sync(count)
+        abi.check(L.wr_bprmf_run_sgd_chain(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(plan.tu),
+                                           _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets,
+                                           plan.batch_size, first, count, lr, _p(losses), _p(o["tdef"]), _p(o["def_q"]),
+                                           o["def_count_host"].data_ptr(), o["cap"],
+                                           o["cap"] if def_limit is None else int(def_limit),
+                                           ctypes.addressof(ev) if ev is not None else None, _p(ws), ws.numel(), _p(sync),
+                                           sync.numel(), _stream()), "wr_bprmf_run_sgd_chain")
         self.step_id += count
         return losses
 
@@ -885,8 +951,16 @@ class PipelinedSgd:
     PLAN_TRIPLETS = 1 << 22
     OVERLAP_MIN_BATCH = 8192      # below this a step is launch-bound and a third launch per step costs more than it hides
 
-    def __init__(self, chunk=64, min_triplets=None, overlap=False):
-        """overlap: run plans that qualify (no hot rows; B >= OVERLAP_MIN_BATCH) as the overlapped stream — item phase of
+    CHAIN_MIN_BATCH = 8192        # below this the step is launch-bound: nothing to hide the item phase behind
+    CHAIN_MIN_ITEMS_PER_TRIPLET = 6   # item rows per triplet of a batch: with fewer, too many runs are deferred (uniform ids:
+                                      # 2 * (1 - exp(-x)(1 + x)), x = 2 B / rows, of the runs: 1/20 at 6 rows per triplet)
+
+    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True):
+        """chain (default): steps of plans that qualify (no hot rows; B >= CHAIN_MIN_BATCH; rows = whole 128-B lines; item
+        table large against the batch) go out as ONE launch per step — the item phase of step k-1 inside the launch of step
+        k's user phase (wr_bprmf_run_sgd_chain; same tables bit for bit; MI355X, 1M x 1M x 64, B = 65,536, steps only:
+        27.3 -> 24.7 us/step).
+        overlap: run plans that qualify (no hot rows; B >= OVERLAP_MIN_BATCH) as the overlapped stream — item phase of
         step k beside the user phase of step k+1 (wr_bprmf_run_sgd_overlap); same tables bit for bit.  OFF by default: on
         MI355X / ROCm 7.2 the cross-stream event hand-offs it needs cost more than the item phase they hide (measured at
         1M x 1M, D = 64, B = 65,536: ordinary stream 29.1-30.2 us/step, overlapped 38.3-39.3 eagerly — host-bound on seven
@@ -895,10 +969,11 @@ class PipelinedSgd:
         self.ops = sys.modules[__name__]
         self.chunk = int(chunk)
         self.overlap = bool(overlap)
+        self.chain = bool(chain)
         self.item_stream = None
         self._ovl_events = None
         self._graphs = {}
-        self.stats = {"graph_replays": 0, "plain_calls": 0}
+        self.stats = {"graph_replays": 0, "plain_calls": 0, "chain_calls": 0}
         if min_triplets is not None:
             self.PLAN_TRIPLETS = int(min_triplets)
         self.plan_stream = None
@@ -947,12 +1022,15 @@ class PipelinedSgd:
         if use_overlap and self.item_stream is None:
             self.item_stream = side_stream(U.device)
             self._ovl_events = self.ops.OverlapEvents(U.device)
-        arenas = self._arena_pair(U.device, B, first, n_items if use_overlap else 0)
+        use_chain = self.chain and not use_overlap and B >= self.CHAIN_MIN_BATCH and first >= 2 and \
+            min([s[0].shape[0] for s in live] or [0]) >= self.CHAIN_MIN_ITEMS_PER_TRIPLET * B and \
+            all(sg["tabs"].chain_supported() for sg in segs if sg["tabs"] is not None)
+        arenas = self._arena_pair(U.device, B, first, n_items if (use_overlap or use_chain) else 0)
         for a in arenas:                     # a previous handle may have left steps queued that read these arrays
             a.release_after(main)
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
-             "overlap": use_overlap, "prep": prep,
+             "overlap": use_overlap, "chain": use_chain, "prep": prep,
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
         if use_overlap:
             self._capture_graphs(h, segs[0]["tabs"], lr)
@@ -1001,7 +1079,7 @@ class PipelinedSgd:
 
     def _graph_for(self, h, plan, lr):
         """the captured stream for this plan, or None (partial plan, lists beyond capacity, hot rows: ordinary stream)"""
-        if plan.overlap is None or plan.n_triplets != plan.arena.max_triplets:
+        if plan.overlap is None or not plan.overlap["fits"] or plan.n_triplets != plan.arena.max_triplets:
             return None
         tabs = h["graph_tabs"]
         rec = self._graphs.get((id(plan.arena), plan.n_batches, tabs.U.data_ptr(), tabs.I.data_ptr(), tabs.D))
@@ -1027,7 +1105,7 @@ class PipelinedSgd:
                 h["prep"].fill(lo, hi)       # this chunk's rows: shuffle + negatives, on the plan stream, before its plan
             plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
                                       validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap, arena=h["arenas"][h["tag"]],
-                                      defer=True, overlap=h["overlap"])
+                                      defer=True, overlap=h["overlap"] or h["chain"])
         h["tag"] ^= 1
         h["next"] = (first, plan)
 
@@ -1052,6 +1130,11 @@ class PipelinedSgd:
                     # complete yet, the source columns have the same rows in another order
                     src = (h["prep"].users, h["prep"].items) if h["prep"] is not None else (h["u"], h["p"])
                     h["map"] = self.ops.BucketMap(src[0], src[1], h["n_users"], h["n_items"], h["B"])
+        if h["chain"] and plan.hot is None and plan.overlap is not None:
+            # ids that defer most runs (many shared item rows without any hot one): the marks are wasted plan work
+            dcn = plan.overlap["def_count_np"]
+            if int((dcn[1:] > plan.overlap["cap"]).sum()) * 2 > plan.n_batches - 1:
+                h["chain"] = False
         h["cur"], h["next"] = cur, None
         return cur
 
@@ -1070,6 +1153,9 @@ class PipelinedSgd:
                 self.stats["graph_replays"] += 1
                 losses[loss_off:loss_off + c].copy_(graph[1])
                 sg["tabs"].step_id += c
+            elif h["chain"] and plan.overlap is not None and c >= 2:
+                sg["tabs"].run_sgd_chain(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
+                self.stats["chain_calls"] += 1
             else:
                 sg["tabs"].run_sgd(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
                 self.stats["plain_calls"] += 1
