@@ -52,6 +52,9 @@ def parse(argv=None):
     ap.add_argument("--overlap", action="store_true",
                     help="A/B: overlapped step stream (item phase of step k beside the user phase of step k+1, hipGraph replays); "
                          "slower than the ordinary stream on this stack, see DESIGN.md section 4")
+    ap.add_argument("--plan-stream", choices=["auto", "side", "inline"], default="auto",
+                    help="N=1: where the next chunk's plan is built: on a side stream beside the steps, or on the step stream "
+                         "between the halves of the current chunk (auto: in-stream from 16,384 triplets per batch on)")
     ap.add_argument("--no-chain", action="store_true",
                     help="N=1: two launches per step (user phase, item phase) instead of the chained step launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -224,7 +227,8 @@ def single_gpu(args, local_rank):
     # steps — and the timed region builds the plans of the chunks that FOLLOW its own chunks, the last of which is the spare
     # one: K batches' worth of plan builds between the two timestamps, K steps trained.
     u, p, n = synth_triplets((K + W + C) * B, args.users, args.items, dev, 3407, args.zipf)
-    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=args.overlap, chain=not args.no_chain)
+    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=args.overlap, chain=not args.no_chain,
+                                inline_plan={"auto": None, "side": False, "inline": True}[args.plan_stream])
     losses_w = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
     losses = torch.empty(K, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -349,6 +353,8 @@ def single_gpu(args, local_rank):
                       "overlapped_item_phase": bool(plan.overlap is not None and handle["overlap"]),
                       "chained_step_launch": bool(plan.overlap is not None and handle["chain"]),
                       "step_stream_calls": dict(pipe.stats),
+                      "plan_build": "on the step stream, between the halves of the chunk before" if handle["inline"]
+                                    else "on a side stream, beside the steps of the chunk before",
                       "untimed_priming_steps": 2 * C if args.overlap else 0},
            "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
            "roofline": roofline}

@@ -112,6 +112,21 @@ int32_t wr_bprmf_plan_build_fast_i32(const int32_t *u, const int32_t *p, const i
                                      int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
                                      void *workspace, int64_t workspace_bytes, void *stream);
 
+/* wr_bprmf_plan_build_fast_* that also writes, per batch, the bitmap "item row has several occurrences in the batch"
+ * (bitmap [n_batches * ceil(n_items/32)], zeroed and filled here): the workgroup that sorts a bucket of item rows owns the
+ * bucket's bitmap words, so no global atomics are needed (wr_bprmf_plan_overlap_marks spends one per such occurrence).
+ * Applies to equal-width buckets spanning whole bitmap words: wr_bprmf_plan_fast_marks_supported() == 1 (WR_E_RANGE
+ * otherwise).  After a bucket overflow (flags[1]) the bitmap is as incomplete as the plan. */
+int32_t wr_bprmf_plan_fast_marks_supported(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items);
+int32_t wr_bprmf_plan_build_fast_marks_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                           int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                           int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
+                                           void *workspace, int64_t workspace_bytes, int32_t *bitmap, void *stream);
+int32_t wr_bprmf_plan_build_fast_marks_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                           int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                           int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
+                                           void *workspace, int64_t workspace_bytes, int32_t *bitmap, void *stream);
+
 /* Bucket map for the hand-written plan builder on skewed ids.  The builder's first stage appends every triplet (item
  * occurrence) to a (batch, row-range) bucket of FIXED capacity (twice the mean load + 64).  Without a map the ranges have
  * equal width, and popularity-skewed ids overflow them (flags[1], rebuild with wr_bprmf_plan_build_*).  A map makes the
@@ -296,6 +311,12 @@ int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab
 int32_t wr_bprmf_plan_overlap_marks(const int32_t *tu, const int32_t *tp, const int32_t *tn, int64_t n_triplets,
                                     int64_t batch_size, int64_t n_items, const int32_t *prev_bitmap, int32_t *bitmap,
                                     int32_t *tdef, int32_t *def_q, int64_t def_cap, int32_t *def_count, void *stream);
+
+/* The second half of wr_bprmf_plan_overlap_marks for a `bitmap` that is already complete (written by
+ * wr_bprmf_plan_build_fast_marks_*): deferred-run mask, list and counts only. */
+int32_t wr_bprmf_plan_overlap_deferred(const int32_t *tu, const int32_t *tp, const int32_t *tn, int64_t n_triplets,
+                                       int64_t batch_size, int64_t n_items, const int32_t *prev_bitmap, const int32_t *bitmap,
+                                       int32_t *tdef, int32_t *def_q, int64_t def_cap, int32_t *def_count, void *stream);
 
 /* Same two kernels in gradient-emitting mode: instead of updating the tables, writes the reduced
  * gradient rows (embedding_dense_backward of BaseRunner.py:198) to grad_u[r,:] / grad_i[r,:] for rows in

@@ -64,6 +64,13 @@ SIGNATURES = {
     "wr_bprmf_run_sgd_chain": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                        c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
                                        c_vp]),
+    "wr_bprmf_plan_overlap_deferred": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                               c_vp]),
+    "wr_bprmf_plan_fast_marks_supported": (c_i32, [c_i64, c_i64, c_i64, c_i64]),
+    "wr_bprmf_plan_build_fast_marks_i64": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                   c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "wr_bprmf_plan_build_fast_marks_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                   c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "wr_bprmf_plan_overlap_marks": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
                                             c_vp]),
     "wr_bprmf_grads": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,

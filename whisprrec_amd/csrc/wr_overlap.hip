@@ -19,9 +19,11 @@ namespace wr {
 __global__ __launch_bounds__(kBlock) void overlap_mark_multi(const int *__restrict__ tp, const int *__restrict__ tn, int64_t n,
                                                               int64_t B, int64_t n_items, int64_t words,
                                                               unsigned *__restrict__ bitmap) {
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= n) return;
-    const int64_t b = t / B;
+    // grid: (workgroups per batch, batches) — no 64-bit division per thread
+    const int64_t b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t = b * B + j;
+    if (j >= B || t >= n) return;
     const int pr = tp[t], nr = tn[t];
     if (pr < 0) {
         const unsigned r = (unsigned)pr & 0x7fffffffu;
@@ -41,9 +43,10 @@ __global__ __launch_bounds__(kBlock) void overlap_mark_deferred(const int *__res
                                                                  const unsigned *__restrict__ prev_bitmap,
                                                                  const unsigned *__restrict__ bitmap,
                                                                  unsigned *__restrict__ tdef) {
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= n) return;
-    const int64_t b = t / B;
+    const int64_t b = blockIdx.y;
+    const int64_t j0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t = b * B + j0;
+    if (j0 >= B || t >= n) return;
     const unsigned *bm = b == 0 ? prev_bitmap : bitmap + (b - 1) * words;
     if (bm == nullptr) return;
     const unsigned p = (unsigned)tp[t] & 0x7fffffffu, q = (unsigned)tn[t] & 0x7fffffffu;
@@ -102,11 +105,9 @@ __global__ __launch_bounds__(kBlock) void overlap_compact(const unsigned *__rest
 
 using namespace wr;
 
-extern "C" {
-
-int32_t wr_bprmf_plan_overlap_marks(const int32_t *tu, const int32_t *tp, const int32_t *tn, int64_t n_triplets,
-                                    int64_t batch_size, int64_t n_items, const int32_t *prev_bitmap, int32_t *bitmap,
-                                    int32_t *tdef, int32_t *def_q, int64_t def_cap, int32_t *def_count, void *stream_) {
+static int32_t overlap_marks(const int32_t *tu, const int32_t *tp, const int32_t *tn, int64_t n_triplets, int64_t batch_size,
+                             int64_t n_items, const int32_t *prev_bitmap, int32_t *bitmap, bool bitmap_ready, int32_t *tdef,
+                             int32_t *def_q, int64_t def_cap, int32_t *def_count, void *stream_) {
     WR_REQUIRE(tu && tp && tn && bitmap && tdef && def_q && def_count, WR_E_NULL, "overlap marks: NULL argument");
     WR_REQUIRE(n_triplets > 0 && n_triplets < (int64_t(1) << 31) && batch_size > 0 && batch_size <= (int64_t(1) << 24) &&
                    n_items > 0 && n_items < (int64_t(1) << 31) && def_cap > 0,
@@ -114,13 +115,16 @@ int32_t wr_bprmf_plan_overlap_marks(const int32_t *tu, const int32_t *tp, const 
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int64_t nb = (n_triplets + batch_size - 1) / batch_size;
     const int64_t words = (n_items + 31) / 32, dwords = (batch_size + 31) / 32;
-    WR_HIP(hipMemsetAsync(bitmap, 0, (size_t)(nb * words * 4), stream));
     WR_HIP(hipMemsetAsync(tdef, 0, (size_t)(nb * dwords * 4), stream));
-    const unsigned grid = (unsigned)((n_triplets + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(overlap_mark_multi, dim3(grid), dim3(kBlock), 0, stream, tp, tn, n_triplets, batch_size, n_items, words,
-                       reinterpret_cast<unsigned *>(bitmap));
-    WR_LAUNCH_CHECK("overlap_mark_multi");
-    hipLaunchKernelGGL(overlap_mark_deferred, dim3(grid), dim3(kBlock), 0, stream, tu, tp, tn, n_triplets, batch_size, n_items,
+    WR_REQUIRE(nb <= 65535, WR_E_SHAPE, "overlap marks: %lld batches in one plan (at most 65535)", (long long)nb);
+    const dim3 grid((unsigned)((batch_size + kBlock - 1) / kBlock), (unsigned)nb);
+    if (!bitmap_ready) {
+        WR_HIP(hipMemsetAsync(bitmap, 0, (size_t)(nb * words * 4), stream));
+        hipLaunchKernelGGL(overlap_mark_multi, grid, dim3(kBlock), 0, stream, tp, tn, n_triplets, batch_size, n_items,
+                           words, reinterpret_cast<unsigned *>(bitmap));
+        WR_LAUNCH_CHECK("overlap_mark_multi");
+    }
+    hipLaunchKernelGGL(overlap_mark_deferred, grid, dim3(kBlock), 0, stream, tu, tp, tn, n_triplets, batch_size, n_items,
                        words, dwords, reinterpret_cast<const unsigned *>(prev_bitmap),
                        reinterpret_cast<const unsigned *>(bitmap), reinterpret_cast<unsigned *>(tdef));
     WR_LAUNCH_CHECK("overlap_mark_deferred");
@@ -128,6 +132,22 @@ int32_t wr_bprmf_plan_overlap_marks(const int32_t *tu, const int32_t *tp, const 
                        dwords, def_cap, def_q, def_count);
     WR_LAUNCH_CHECK("overlap_compact");
     return WR_OK;
+}
+
+extern "C" {
+
+int32_t wr_bprmf_plan_overlap_marks(const int32_t *tu, const int32_t *tp, const int32_t *tn, int64_t n_triplets,
+                                    int64_t batch_size, int64_t n_items, const int32_t *prev_bitmap, int32_t *bitmap,
+                                    int32_t *tdef, int32_t *def_q, int64_t def_cap, int32_t *def_count, void *stream) {
+    return overlap_marks(tu, tp, tn, n_triplets, batch_size, n_items, prev_bitmap, bitmap, false, tdef, def_q, def_cap,
+                         def_count, stream);
+}
+
+int32_t wr_bprmf_plan_overlap_deferred(const int32_t *tu, const int32_t *tp, const int32_t *tn, int64_t n_triplets,
+                                       int64_t batch_size, int64_t n_items, const int32_t *prev_bitmap, const int32_t *bitmap,
+                                       int32_t *tdef, int32_t *def_q, int64_t def_cap, int32_t *def_count, void *stream) {
+    return overlap_marks(tu, tp, tn, n_triplets, batch_size, n_items, prev_bitmap, const_cast<int32_t *>(bitmap), true, tdef,
+                         def_q, def_cap, def_count, stream);
 }
 
 }  // extern "C"

@@ -428,13 +428,21 @@ __global__ __launch_bounds__(kSortBlock) void fast_user_sort(const Idx *__restri
     }
 }
 
-template <int PER>
+// MARKS: the workgroup also writes its bucket's words of the batch's bitmap "item row has several occurrences in the batch"
+// (what wr_bprmf_plan_overlap_marks otherwise builds with one global atomicOr per such occurrence: 41 us per 64-batch plan
+// at the headline shape).  An equal-width bucket is the row range [bucket << shift, (bucket + 1) << shift): with shift >= 5
+// its bitmap words belong to this workgroup alone — bits are collected in LDS and the non-zero words stored plainly (the
+// bitmap was zeroed before the launch).
+constexpr int kMarkWordsMax = 2048;   // words of a bucket's row range: shift <= 16
+template <int PER, bool MARKS>
 __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t B, SideDev side, int cap_i, unsigned bin_bits,
                                                           const int *__restrict__ cnt_i, const unsigned long long *__restrict__ ibuf,
                                                           int *__restrict__ oc_item, int *__restrict__ oc_src, int *__restrict__ tp,
-                                                          int *__restrict__ tn, int *__restrict__ flags) {
+                                                          int *__restrict__ tn, int *__restrict__ flags,
+                                                          unsigned *__restrict__ bitmap, int64_t bitmap_words) {
     extern __shared__ unsigned long long lds[];  // out[cap] | cnt[1 << bin_bits] (ints)
     __shared__ int wave_tot[kSortBlock / 64], wave_pre[kSortBlock / 64];
+    __shared__ unsigned mark_words[MARKS ? kMarkWordsMax : 1];
     unsigned long long *out = lds;
     int *cnt = reinterpret_cast<int *>(lds + cap_i);
     // the buckets of one batch set flag bits all over the batch's tp[] / tn[]: keep them on one XCD's L2
@@ -444,6 +452,10 @@ __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t 
     const int bucket = lb % nbk;
     const int count = min(cnt_i[lb], cap_i);
     if (count == 0) return;
+    const unsigned side_shift = side.shift;
+    const int n_mark_words = MARKS ? (1 << (side_shift - 5)) : 0;
+    if constexpr (MARKS)
+        for (int i = threadIdx.x; i < n_mark_words; i += kSortBlock) mark_words[i] = 0u;   // bucket_bins below has the barrier
     const BinMap bm = make_binmap(side, bucket, bin_bits, b, B, true);
     // a heavy row's occurrences are spread over its sub-buckets: "several occurrences" is decided over all of them
     int row_total = 0;
@@ -472,6 +484,18 @@ __global__ __launch_bounds__(kSortBlock) void fast_item_sort(int64_t n, int64_t 
         if (same > 1 || row_total > 1) {
             int *dst = side ? tn : tp;
             dst[b * B + tloc] |= (int)0x80000000;  // one writer per (triplet, side)
+            if constexpr (MARKS) {
+                const unsigned in_bucket = (unsigned)item & ((1u << side_shift) - 1u);
+                atomicOr(&mark_words[in_bucket >> 5], 1u << (in_bucket & 31u));
+            }
+        }
+    }
+    if constexpr (MARKS) {
+        __syncthreads();
+        const int64_t w0 = ((int64_t)bucket << side_shift) >> 5;
+        for (int i = threadIdx.x; i < n_mark_words; i += kSortBlock) {
+            const unsigned w = mark_words[i];
+            if (w != 0u && w0 + i < bitmap_words) bitmap[b * bitmap_words + w0 + i] = w;
         }
     }
 }
@@ -489,11 +513,16 @@ static inline SideDev side_dev(const wr_bucket_side *m, int nbk, unsigned shift)
     return SideDev{nbk, 0u, m->row_bucket, m->bucket_start, m->bucket_rows, m->bucket_sub};
 }
 
+// in-build marks (fast_item_sort<.., true>): equal-width item buckets whose row range is a whole number of bitmap words
+static inline bool fast_marks_ok(const FastLayout &L, bool mapped_items) {
+    return !mapped_items && L.shift_i >= 5 && L.shift_i <= 16;
+}
+
 template <typename Idx>
 static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_t n, int64_t B, int64_t n_users,
                                int64_t n_items, const wr_bucket_side *map_u, const wr_bucket_side *map_i, int32_t *tu,
                                int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
-                               void *workspace, int64_t workspace_bytes, void *stream_) {
+                               void *workspace, int64_t workspace_bytes, void *stream_, int32_t *bitmap = nullptr) {
     WR_REQUIRE(u && p && nn, WR_E_NULL, "index arrays must not be NULL");
     WR_REQUIRE(tu && tp && tn && oc_item && oc_src && flags, WR_E_NULL, "plan output arrays / flags must not be NULL");
     int32_t rc;
@@ -551,9 +580,22 @@ static int32_t plan_build_fast(const Idx *u, const Idx *p, const Idx *nn, int64_
         hipLaunchKernelGGL((fast_item_scatter<false>), dim3((unsigned)(L.nb * tiles_i)), dim3(kBlock), 0, stream, tp, tn, n, B,
                            tiles_i, si, n_items, L.cap_i, cnt_i, ibuf, flags);
     WR_LAUNCH_CHECK("fast_item_scatter");
+    const int64_t bitmap_words = (n_items + 31) / 32;
+    if (bitmap != nullptr) {
+        WR_REQUIRE(fast_marks_ok(L, map_i != nullptr), WR_E_RANGE, "fast plan builder: no in-build marks for this shape");
+        WR_HIP(hipMemsetAsync(bitmap, 0, (size_t)(L.nb * bitmap_words * 4), stream));
+    }
 #define WR_ITEM_SORT(PER_)                                                                                                 \
-    hipLaunchKernelGGL((fast_item_sort<PER_>), dim3(gb_i), dim3(kSortBlock), lds_i, stream, n, B, si, L.cap_i, bb_i, cnt_i,  \
-                       ibuf, oc_item, oc_src, tp, tn, flags)
+    do {                                                                                                                   \
+        if (bitmap != nullptr)                                                                                             \
+            hipLaunchKernelGGL((fast_item_sort<PER_, true>), dim3(gb_i), dim3(kSortBlock), lds_i, stream, n, B, si, L.cap_i, \
+                               bb_i, cnt_i, ibuf, oc_item, oc_src, tp, tn, flags, reinterpret_cast<unsigned *>(bitmap),     \
+                               bitmap_words);                                                                              \
+        else                                                                                                               \
+            hipLaunchKernelGGL((fast_item_sort<PER_, false>), dim3(gb_i), dim3(kSortBlock), lds_i, stream, n, B, si,         \
+                               L.cap_i, bb_i, cnt_i, ibuf, oc_item, oc_src, tp, tn, flags, (unsigned *)nullptr,             \
+                               (int64_t)0);                                                                                \
+    } while (0)
     if (per_i <= 3) WR_ITEM_SORT(3);
     else if (per_i <= 5) WR_ITEM_SORT(5);
     else if (per_i <= 9) WR_ITEM_SORT(9);
@@ -596,6 +638,29 @@ int32_t wr_bprmf_plan_build_fast_i32(const int32_t *u, const int32_t *p, const i
                                      void *workspace, int64_t workspace_bytes, void *stream) {
     return plan_build_fast<int32_t>(u, p, n, n_triplets, batch_size, n_users, n_items, nullptr, nullptr, tu, tp, tn, torig,
                                     oc_item, oc_src, flags, workspace, workspace_bytes, stream);
+}
+
+int32_t wr_bprmf_plan_fast_marks_supported(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items) {
+    FastLayout L;
+    return (fast_layout(n_triplets, batch_size, n_users, n_items, 0, 0, L) && fast_marks_ok(L, false)) ? 1 : 0;
+}
+
+int32_t wr_bprmf_plan_build_fast_marks_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
+                                           int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                           int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
+                                           void *workspace, int64_t workspace_bytes, int32_t *bitmap, void *stream) {
+    WR_REQUIRE(bitmap != nullptr, WR_E_NULL, "bitmap must not be NULL");
+    return plan_build_fast<int64_t>(u, p, n, n_triplets, batch_size, n_users, n_items, nullptr, nullptr, tu, tp, tn, torig,
+                                    oc_item, oc_src, flags, workspace, workspace_bytes, stream, bitmap);
+}
+
+int32_t wr_bprmf_plan_build_fast_marks_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets,
+                                           int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
+                                           int32_t *tn, int32_t *torig, int32_t *oc_item, int32_t *oc_src, int32_t *flags,
+                                           void *workspace, int64_t workspace_bytes, int32_t *bitmap, void *stream) {
+    WR_REQUIRE(bitmap != nullptr, WR_E_NULL, "bitmap must not be NULL");
+    return plan_build_fast<int32_t>(u, p, n, n_triplets, batch_size, n_users, n_items, nullptr, nullptr, tu, tp, tn, torig,
+                                    oc_item, oc_src, flags, workspace, workspace_bytes, stream, bitmap);
 }
 
 int32_t wr_bprmf_plan_build_fast_mapped_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,

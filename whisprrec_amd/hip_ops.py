@@ -371,7 +371,14 @@ class BatchPlan:
             self._sides = self._hot_arrays(dev)      # before the plan kernels: no host-side allocation between build and scan
         outs = (_p(self.tu), _p(self.tp), _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.flags),
                 _p(ws), ws.numel(), _stream())
-        if mapped:
+        self._bitmap_ready = False
+        if self._want_overlap and not mapped and L.wr_bprmf_plan_fast_marks_supported(*args):
+            # the item-sort workgroups write the batch's "several occurrences" bitmap themselves (no global atomics)
+            fn = L.wr_bprmf_plan_build_fast_marks_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_marks_i32
+            abi.check(fn(_p(u), _p(p), _p(n), *args, *outs[:-1], _p(self.arena.overlap["bitmap"]), _stream()),
+                      "wr_bprmf_plan_build_fast_marks")
+            self._bitmap_ready = True
+        elif mapped:
             fn = L.wr_bprmf_plan_build_fast_mapped_i64 if dt == torch.int64 else L.wr_bprmf_plan_build_fast_mapped_i32
             abi.check(fn(_p(u), _p(p), _p(n), *args, ctypes.addressof(mu["struct"]) if mu else None,
                          ctypes.addressof(mi["struct"]) if mi else None, *outs), "wr_bprmf_plan_build_fast_mapped")
@@ -398,6 +405,7 @@ class BatchPlan:
                      _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.err), _stream()),
                   "wr_bprmf_plan_build_small")
         self.builder = self._tried = "small"
+        self._bitmap_ready = False
         if self._want_hot:
             self._sides = self._hot_arrays(u.device)
             self._enqueue_hot_runs()
@@ -417,6 +425,7 @@ class BatchPlan:
                   "wr_bprmf_plan_build")
         self.builder = "generic"
         self._tried = "generic"
+        self._bitmap_ready = False
         if self._want_hot:
             if self._sides is None:
                 self._sides = self._hot_arrays(dev)
@@ -457,9 +466,10 @@ class BatchPlan:
         rewrites (index work only).  The first batch of a plan defers nothing: the stream joins at plan boundaries."""
         o, cb = self.arena.overlap, self._cap_batches
         counts = self.meta[self.META_HEAD + 4 * cb:self.META_HEAD + 5 * cb]
-        abi.check(abi.lib().wr_bprmf_plan_overlap_marks(_p(self.tu), _p(self.tp), _p(self.tn), self.n_triplets,
-                                                        self.batch_size, self.n_items, None, _p(o["bitmap"]), _p(o["tdef"]),
-                                                        _p(o["def_q"]), o["cap"], _p(counts), _stream()),
+        L = abi.lib()
+        fn = L.wr_bprmf_plan_overlap_deferred if getattr(self, "_bitmap_ready", False) else L.wr_bprmf_plan_overlap_marks
+        abi.check(fn(_p(self.tu), _p(self.tp), _p(self.tn), self.n_triplets, self.batch_size, self.n_items, None,
+                     _p(o["bitmap"]), _p(o["tdef"]), _p(o["def_q"]), o["cap"], _p(counts), _stream()),
                   "wr_bprmf_plan_overlap_marks")
 
     def _queue_readback(self):
@@ -955,11 +965,21 @@ class PipelinedSgd:
     CHAIN_MIN_ITEMS_PER_TRIPLET = 6   # item rows per triplet of a batch: with fewer, too many runs are deferred (uniform ids:
                                       # 2 * (1 - exp(-x)(1 + x)), x = 2 B / rows, of the runs: 1/20 at 6 rows per triplet)
 
-    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True):
+    INLINE_MIN_BATCH = 16384      # from this batch size on a step kernel fills the GPU and a plan kernel running beside it
+                                  # costs more step time than its own duration (see inline_plan)
+
+    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True, inline_plan=None):
         """chain (default): steps of plans that qualify (no hot rows; B >= CHAIN_MIN_BATCH; rows = whole 128-B lines; item
         table large against the batch) go out as ONE launch per step — the item phase of step k-1 inside the launch of step
         k's user phase (wr_bprmf_run_sgd_chain; same tables bit for bit; MI355X, 1M x 1M x 64, B = 65,536, steps only:
         27.3 -> 24.7 us/step).
+        inline_plan: where the plan of the NEXT chunk is built.  False: on a side stream, beside the steps of the current
+        chunk — right while the steps leave the GPU idle part of the time (small batches: launch-bound).  True: on the step
+        stream itself, between the two halves of the current chunk's steps — a whole-GPU step kernel and the plan kernels
+        (atomics, LDS sorts) slow each other down when they run together: in a kernel trace of 1M x 1M x 64, B = 65,536 the 11
+        step kernels per chunk that overlapped a plan kernel took 49 us instead of 24, ~280 us per chunk for a plan that runs
+        in ~130 us alone.  In-stream the build costs exactly its own duration, and its read-back is on the host long before
+        the second half of the chunk has run.  None (default): in-stream from INLINE_MIN_BATCH triplets per batch on.
         overlap: run plans that qualify (no hot rows; B >= OVERLAP_MIN_BATCH) as the overlapped stream — item phase of
         step k beside the user phase of step k+1 (wr_bprmf_run_sgd_overlap); same tables bit for bit.  OFF by default: on
         MI355X / ROCm 7.2 the cross-stream event hand-offs it needs cost more than the item phase they hide (measured at
@@ -970,6 +990,7 @@ class PipelinedSgd:
         self.chunk = int(chunk)
         self.overlap = bool(overlap)
         self.chain = bool(chain)
+        self.inline_plan = inline_plan
         self.item_stream = None
         self._ovl_events = None
         self._graphs = {}
@@ -1031,6 +1052,8 @@ class PipelinedSgd:
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
              "overlap": use_overlap, "chain": use_chain, "prep": prep,
+             "inline": (not use_overlap) and (B >= self.INLINE_MIN_BATCH if self.inline_plan is None
+                                              else bool(self.inline_plan)),
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
         if use_overlap:
             self._capture_graphs(h, segs[0]["tabs"], lr)
@@ -1088,6 +1111,9 @@ class PipelinedSgd:
         g = self._graph_of(rec, tabs, plan.n_batches, lr)
         return g, rec["stage"]
 
+    def _build_stream(self, h):
+        return torch.cuda.current_stream(h["u"].device) if h["inline"] else self.plan_stream
+
     def _prefetch(self, h):
         """enqueue the plan of the next chunk of batches on the side stream (no host wait, no allocation)"""
         if h["at"] >= h["nb"]:
@@ -1099,7 +1125,7 @@ class PipelinedSgd:
             c = min(c, h["lead"].pop(0))
         h["at"] += c
         lo, hi = first * B, min(h["u"].numel(), (first + c) * B)
-        with torch.cuda.stream(self.plan_stream):
+        with torch.cuda.stream(self._build_stream(h)):
             bmap = h["map"] if h["map"] else None
             if h["prep"] is not None:
                 h["prep"].fill(lo, hi)       # this chunk's rows: shuffle + negatives, on the plan stream, before its plan
@@ -1125,7 +1151,7 @@ class PipelinedSgd:
             if plan._mapped():
                 h["map"] = False
             elif h["map"] is None:
-                with torch.cuda.stream(self.plan_stream):
+                with torch.cuda.stream(self._build_stream(h)):
                     # row shares from the whole epoch: with a pipelined preparation the batch-order columns are not
                     # complete yet, the source columns have the same rows in another order
                     src = (h["prep"].users, h["prep"].items) if h["prep"] is not None else (h["u"], h["p"])
@@ -1147,6 +1173,13 @@ class PipelinedSgd:
                 cur = self._take_next(h, pos, main)
             base, plan = cur
             c = min(end, base + plan.n_batches) - pos
+            if h["inline"] and h["next"] is None and h["at"] < h["nb"]:
+                # in-stream plan build: the next chunk's plan goes between the two halves of this chunk's steps
+                mid = base + plan.n_batches // 2
+                if pos >= mid:
+                    self._prefetch(h)
+                else:
+                    c = min(c, mid - pos)
             graph = self._graph_for(h, plan, lr) if (h["overlap"] and pos == base and c == plan.n_batches) else None
             if graph is not None:
                 graph[0].replay()                                    # the whole plan as the overlapped stream, one launch
@@ -1163,7 +1196,7 @@ class PipelinedSgd:
             loss_off += c
             if pos >= base + plan.n_batches:
                 plan.arena.release_after(main)                       # every step that reads the plan's arrays is queued
-            if h["next"] is None:
+            if h["next"] is None and not h["inline"]:
                 self._prefetch(h)                                    # the next plan is built beside the queued steps
         h["pos"] = pos
 
