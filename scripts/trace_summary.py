@@ -21,8 +21,11 @@ def main():
     print("%-100s %7s %10s %10s %6s" % ("kernel", "calls", "avg_us", "total_us", "%"))
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:16]:
         print("%-100s %7d %10.2f %10.1f %6.2f" % (k[:100], len(v), sum(v) / len(v) / 1e3, sum(v) / 1e3, 100.0 * sum(v) / tot))
-    idx = [i for i, r in enumerate(rows) if "bprmf_user_phase" in r["Kernel_Name"]]
-    if len(idx) > 20:
+    # the step stream: chained launches where the run used them, else the two-launch form
+    idx = [i for i, r in enumerate(rows) if "bprmf_chain_step" in r["Kernel_Name"]]
+    if len(idx) <= 20:
+        idx = [i for i, r in enumerate(rows) if "bprmf_user_phase" in r["Kernel_Name"]]
+    if len(idx) > 16:
         i0 = idx[len(idx) // 2]
         prev = None
         print("\ntimeline (mid-run): kernel, duration us, gap before it us")

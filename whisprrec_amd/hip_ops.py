@@ -5,6 +5,7 @@ call into libwhisprrec_hip.so on ``torch.cuda.current_stream()``.  Nothing in th
 tensors must live on a ROCm device and the library must be built.
 """
 import ctypes
+import os
 
 import torch
 
@@ -72,7 +73,7 @@ def side_stream(device):
     other (seen in a kernel trace: plan stream and main stream both on queue 4, every plan build waiting for the step
     kernels to drain).  A high-priority stream has its own queue, and the small kernels it carries should not wait behind
     the whole-GPU step kernels anyway."""
-    return torch.cuda.Stream(device=device, priority=-1)
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get("WR_SIDE_PRIORITY", "-1")))
 
 
 def device_info():
@@ -965,21 +966,16 @@ class PipelinedSgd:
     CHAIN_MIN_ITEMS_PER_TRIPLET = 6   # item rows per triplet of a batch: with fewer, too many runs are deferred (uniform ids:
                                       # 2 * (1 - exp(-x)(1 + x)), x = 2 B / rows, of the runs: 1/20 at 6 rows per triplet)
 
-    INLINE_MIN_BATCH = 16384      # from this batch size on a step kernel fills the GPU and a plan kernel running beside it
-                                  # costs more step time than its own duration (see inline_plan)
-
-    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True, inline_plan=None):
+    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True, inline_plan=False):
         """chain (default): steps of plans that qualify (no hot rows; B >= CHAIN_MIN_BATCH; rows = whole 128-B lines; item
         table large against the batch) go out as ONE launch per step — the item phase of step k-1 inside the launch of step
         k's user phase (wr_bprmf_run_sgd_chain; same tables bit for bit; MI355X, 1M x 1M x 64, B = 65,536, steps only:
         27.3 -> 24.7 us/step).
-        inline_plan: where the plan of the NEXT chunk is built.  False: on a side stream, beside the steps of the current
-        chunk — right while the steps leave the GPU idle part of the time (small batches: launch-bound).  True: on the step
-        stream itself, between the two halves of the current chunk's steps — a whole-GPU step kernel and the plan kernels
-        (atomics, LDS sorts) slow each other down when they run together: in a kernel trace of 1M x 1M x 64, B = 65,536 the 11
-        step kernels per chunk that overlapped a plan kernel took 49 us instead of 24, ~280 us per chunk for a plan that runs
-        in ~130 us alone.  In-stream the build costs exactly its own duration, and its read-back is on the host long before
-        the second half of the chunk has run.  None (default): in-stream from INLINE_MIN_BATCH triplets per batch on.
+        inline_plan: build the plan of the NEXT chunk on the step stream itself, between the two halves of the current
+        chunk's steps, instead of on a side stream beside them.  OFF by default — measured, not assumed: in a kernel trace of
+        1M x 1M x 64, B = 65,536 the ~11 step kernels per chunk that overlap a plan kernel take 49 us instead of 24 (~280 us
+        per chunk), which looks like a reason to serialise; but the plan of a chunk takes ~330 us when it runs alone (it is
+        latency-bound: 32 K short workgroups), so in-stream costs MORE (29.9 against 29.4 us/step).
         overlap: run plans that qualify (no hot rows; B >= OVERLAP_MIN_BATCH) as the overlapped stream — item phase of
         step k beside the user phase of step k+1 (wr_bprmf_run_sgd_overlap); same tables bit for bit.  OFF by default: on
         MI355X / ROCm 7.2 the cross-stream event hand-offs it needs cost more than the item phase they hide (measured at
@@ -1052,8 +1048,7 @@ class PipelinedSgd:
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
              "overlap": use_overlap, "chain": use_chain, "prep": prep,
-             "inline": (not use_overlap) and (B >= self.INLINE_MIN_BATCH if self.inline_plan is None
-                                              else bool(self.inline_plan)),
+             "inline": (not use_overlap) and bool(self.inline_plan),
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
         if use_overlap:
             self._capture_graphs(h, segs[0]["tabs"], lr)
