@@ -5,17 +5,22 @@ wr_bprmf_step_adam: 12 row transfers per touched row) against the catch-up folde
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from whisprrec_amd import abi
+if os.environ.get("WR_LIB"):            # A/B builds (build_ab/*.so)
+    abi.LIB_PATH = os.path.abspath(os.environ["WR_LIB"])
 from whisprrec_amd import hip_ops
 
 dev = torch.device("cuda:0")
 nU = nI = 1_000_000; D = int(os.environ.get("WR_D", "64"))
-for B, NB in ((65536, 48), (2048, 512)):
+CASES = [tuple(int(x) for x in c.split(":")) for c in os.environ["WR_BATCHES"].split(",")] if os.environ.get("WR_BATCHES") \
+    else [(65536, 48), (2048, 512)]
+for B, NB in CASES[:int(os.environ.get("WR_CASES", "99"))]:
     g = torch.Generator(device=dev); g.manual_seed(1)
     u = torch.randint(0, nU, (NB * B,), generator=g, device=dev, dtype=torch.int32)
     p = torch.randint(0, nI, (NB * B,), generator=g, device=dev, dtype=torch.int32)
     n = torch.randint(1, nI, (NB * B,), generator=g, device=dev, dtype=torch.int32)
     plan = hip_ops.BatchPlan(u, p, n, B, nU, nI)
-    for l2 in (0.0, 1e-6):
+    for l2 in ((0.0, 1e-6) if not os.environ.get("WR_BATCHES") else (0.0,)):
         res = {}
         for fold in (False, True):
             U = torch.randn(nU, D, generator=g, device=dev) * 0.01

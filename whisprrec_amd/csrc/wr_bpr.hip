@@ -30,6 +30,11 @@
 #ifndef WR_USER_WAVES
 #define WR_USER_WAVES 8      // waves per SIMD the headline instantiation of the user phase is held to (64 VGPRs)
 #endif
+#ifndef WR_ADAM_WAVES
+#define WR_ADAM_WAVES 5      // the same for the folded-Adam instantiation (MODE 4): 96 VGPRs + 8 spilled; A/B on MI355X, us per
+                             // step at 1M x 1M x 64, B = 65,536: unconstrained (103 VGPRs, 4 waves) 107-111, 5 waves 104-106,
+                             // 6 waves (35 spilled) 116
+#endif
 
 namespace wr {
 
@@ -135,6 +140,63 @@ __device__ __forceinline__ void adam_load_caught_up(const float *__restrict__ W,
         replay(k0); replay(k1); replay(k2); replay(k3);
     }
     for (; s < a.t; ++s) replay(c2[s]);
+}
+
+// The same replay for the FOUR rows a wave's four 16-lane teams hold, without divergence.  Rows miss different numbers of
+// steps (geometric: the longest of four is ~2.1x the mean), and in adam_load_caught_up every team of the wave pays for the
+// longest.  Here the wave first transposes its data — lane (team a, position p) trades its float4 (elements 4p..4p+3 of row
+// a) for element 4p+a of each of the four rows: two butterfly stages over lanes ^16 and ^32, four ds_bpermute per float4 —
+// so that in every replay iteration ALL 64 lanes work on the same row: the loop over row k's missed steps is uniform
+// (constants through scalar loads), the wave spends sum(gaps) single-element iterations instead of 4 * max(gaps), and the
+// transpose back restores the team layout.  Every element goes through exactly the same operations in the same order:
+// the same bits.  Must be called by all 64 lanes (teams without a row pass from = t - 1: nothing to replay).
+__device__ __forceinline__ void wave_transpose4(float4 &x, bool a0, bool a1) {
+    float s, r;
+    s = a0 ? x.x : x.y; r = __shfl_xor(s, 16, 64); if (a0) x.x = r; else x.y = r;
+    s = a0 ? x.z : x.w; r = __shfl_xor(s, 16, 64); if (a0) x.z = r; else x.w = r;
+    s = a1 ? x.x : x.z; r = __shfl_xor(s, 32, 64); if (a1) x.x = r; else x.z = r;
+    s = a1 ? x.y : x.w; r = __shfl_xor(s, 32, 64); if (a1) x.y = r; else x.w = r;
+}
+
+template <int NV>
+__device__ __forceinline__ void adam_replay_balanced(Row<NV> &w, Row<NV> &m, Row<NV> &v, int from, const AdamArgs &a) {
+    const int l64 = (int)(threadIdx.x & 63u);
+    const bool a0 = (l64 & 16) != 0, a1 = (l64 & 32) != 0;
+    const int f0 = __builtin_amdgcn_readlane(from, 0), f1 = __builtin_amdgcn_readlane(from, 16),
+              f2 = __builtin_amdgcn_readlane(from, 32), f3 = __builtin_amdgcn_readlane(from, 48);
+    if (f0 + 1 >= a.t && f1 + 1 >= a.t && f2 + 1 >= a.t && f3 + 1 >= a.t) return;   // uniform: nothing missed anywhere
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        wave_transpose4(w.v[q], a0, a1);
+        wave_transpose4(m.v[q], a0, a1);
+        wave_transpose4(v.v[q], a0, a1);
+    }
+    const float2 *__restrict__ c2 = reinterpret_cast<const float2 *>(a.consts);
+    auto run = [&](int fk, auto comp) {   // comp(float4&) -> the component that now holds row k's element
+        auto replay = [&](float2 k) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (a.l2 != 0.f) adam_elem<true>(comp(w.v[q]), comp(m.v[q]), comp(v.v[q]), 0.f, a.l2, a.b1, a.b2, a.eps, k.x, k.y);
+                else adam_elem_zero_grad(comp(w.v[q]), comp(m.v[q]), comp(v.v[q]), a.b1, a.b2, a.eps, k.x, k.y);
+            }
+        };
+        int s = fk + 1;
+        for (; s + 3 < a.t; s += 4) {
+            const float2 k0 = c2[s], k1 = c2[s + 1], k2 = c2[s + 2], k3 = c2[s + 3];
+            replay(k0); replay(k1); replay(k2); replay(k3);
+        }
+        for (; s < a.t; ++s) replay(c2[s]);
+    };
+    run(f0, [](float4 &x) -> float & { return x.x; });
+    run(f1, [](float4 &x) -> float & { return x.y; });
+    run(f2, [](float4 &x) -> float & { return x.z; });
+    run(f3, [](float4 &x) -> float & { return x.w; });
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        wave_transpose4(w.v[q], a0, a1);
+        wave_transpose4(m.v[q], a0, a1);
+        wave_transpose4(v.v[q], a0, a1);
+    }
 }
 
 // step t on a row whose caught-up weights and moments are in registers
@@ -436,7 +498,32 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
     Moments<NV, MODE == 4> umv[SLOTS], pmv0[SLOTS], nmv0[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        if (head[s]) {
+        if constexpr (MODE == 4 && T == 16) {
+            // all nine row loads of the position go out together, then the three replays, each balanced over the wave's four
+            // teams (adam_replay_balanced: every lane takes part, teams without a head replay nothing)
+            int fu = ad.t - 1, fp = fu, fn = fu;
+            const Row<NV> zero{};
+            ur[s] = pr0[s] = nr0[s] = zero;
+            umv[s].m = umv[s].v = pmv0[s].m = pmv0[s].v = nmv0[s].m = nmv0[s].v = zero;
+            if (head[s]) {
+                const int p = praw0[s] & 0x7fffffff, n = nraw0[s] & 0x7fffffff;
+                fu = ad.lastU[uu[s]];
+                fp = ad.lastI[p];
+                fn = ad.lastI[n];
+                ur[s] = load_row<T, NV, FULL>(U, uu[s], D, lane);
+                umv[s].m = load_row<T, NV, FULL>(ad.mU, uu[s], D, lane);
+                umv[s].v = load_row<T, NV, FULL>(ad.vU, uu[s], D, lane);
+                pr0[s] = load_row<T, NV, FULL>(I, p, D, lane);
+                pmv0[s].m = load_row<T, NV, FULL>(ad.mI, p, D, lane);
+                pmv0[s].v = load_row<T, NV, FULL>(ad.vI, p, D, lane);
+                nr0[s] = load_row<T, NV, FULL>(I, n, D, lane);
+                nmv0[s].m = load_row<T, NV, FULL>(ad.mI, n, D, lane);
+                nmv0[s].v = load_row<T, NV, FULL>(ad.vI, n, D, lane);
+            }
+            adam_replay_balanced<NV>(ur[s], umv[s].m, umv[s].v, fu, ad);
+            adam_replay_balanced<NV>(pr0[s], pmv0[s].m, pmv0[s].v, fp, ad);
+            adam_replay_balanced<NV>(nr0[s], nmv0[s].m, nmv0[s].v, fn, ad);
+        } else if (head[s]) {
             if constexpr (MODE == 4) {
                 adam_load_caught_up<T, NV, FULL>(U, ad.mU, ad.vU, ad.lastU, uu[s], D, lane, ad, ur[s], umv[s].m, umv[s].v);
                 adam_load_caught_up<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, praw0[s] & 0x7fffffff, D, lane, ad, pr0[s],
@@ -505,7 +592,8 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
 }
 
 template <int T, int NV, bool FULL, int MODE, int SLOTS, bool SKIP_HOT, int DEF = 0>
-__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? WR_USER_WAVES : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
+__global__ __launch_bounds__(kBlock, (NV == 1 && SLOTS == 1 && MODE == 0 && !SKIP_HOT) ? WR_USER_WAVES
+                                     : (NV == 1 && SLOTS == 1 && MODE == 4 && !SKIP_HOT) ? WR_ADAM_WAVES : 1) void bprmf_user_phase(float *__restrict__ U, float *I, int D,
                                                             const int *__restrict__ tu, const int *__restrict__ tp,
                                                             const int *__restrict__ tn, int B, float lr, float l2,
                                                             float *__restrict__ Z, float *__restrict__ partials,

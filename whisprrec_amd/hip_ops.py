@@ -1219,15 +1219,17 @@ class LazyOptimizerState:
     needs them and all together in ``flush()`` — call it before anything else reads the tables.  Bit-identical to the
     dense kernels (wr_adam_dense / wr_sgd_dense), without their table passes."""
 
-    FOLD_MAX_GAP = 24      # fold the catch-up into the step kernels while a row misses about this many steps between two uses
+    FOLD_MAX_GAP = 40      # fold the catch-up into the step kernels while a row misses about this many steps between two uses
 
     def __init__(self, tabs, name, lr, l2, betas=(0.9, 0.999), eps=1e-8, fold=None):
         """fold (Adam): the catch-up of a batch's rows happens inside the step kernels' row loads (wr_bprmf_step_adam_folded:
         6 instead of 12 row transfers per touched row) instead of in a pass of its own; same bits either way.  The folded
-        replay runs on 16-lane teams whose rows miss different numbers of steps (divergence) and repeats for every reader of a
-        shared row, so it pays while replays are short: None (default) = fold when a row misses about FOLD_MAX_GAP steps or
-        fewer between two batches that contain it (rows / batch size).  MI355X, 1M x 1M x 64: B = 65,536 (gap ~16) 165 ->
-        142 us/step folded; B = 2,048 (gap ~490) 56 us separate against 194 folded (scripts/ab_adam.py)."""
+        replay is balanced over the four rows a wave holds (adam_replay_balanced: the wave transposes its data so that all
+        64 lanes replay one row at a time — no team waits for the longest gap), but a row shared by several triplets is
+        replayed by each of its readers, and with few waves on the GPU the replay is latency-bound, so it pays while replays are
+        short: None (default) = fold when a row misses about FOLD_MAX_GAP steps or fewer between two batches that contain it
+        (rows / batch size).  MI355X, 1M x 1M x 64, us/step separate -> folded: B = 65,536 (gap ~16) 155 -> 105; B = 32,768
+        (~31) 105 -> 84; B = 16,384 (~61) 73 -> 91; B = 2,048 (~490) 55 -> 283 (scripts/ab_adam.py)."""
         if name not in ("SGD", "Adam"):
             raise ValueError(name)
         self.tabs, self.name, self.lr, self.l2, self.betas, self.eps = tabs, name, float(lr), float(l2), betas, float(eps)
