@@ -172,3 +172,73 @@ def test_pipeline_picks_the_form_per_plan_and_results_do_not_depend_on_it(ops, c
            for k in range(nb)]
     assert rel_err(res[0][2].cpu().numpy(), np.asarray(ref)) < TOL
     assert rel_err(res[0][0].cpu().numpy(), Uo) < TOL and rel_err(res[0][1].cpu().numpy(), Io) < TOL
+
+
+def test_multi_segment_handle_chains_inside_segments_only(ops):
+    """the stratified schedule's shape: several segments, each with its own view of the item rows, one plan sequence across
+    them — chained launches inside a segment, a two-launch step at every segment start; same tables as without chaining"""
+    dev = torch.device("cuda:0")
+    nU, rows, D, B, lr = 40_000, 60_000, 64, 8192, 0.05
+    U, I = _tables(9, nU, 3 * rows, D)
+    segs_np = []
+    for k, nb in enumerate((5, 3, 4)):
+        u, p, n = _epoch(30 + k, nU, rows, nb * B)
+        segs_np.append((k, u, p, n))
+    res = []
+    for chain in (True, False):
+        pipe = ops.PipelinedSgd(chunk=4, min_triplets=1, chain=chain)
+        Ud, Id = T(U, dev), T(I, dev)
+        # consecutive slices of one array per column, as the rotating schedule passes them
+        ua, pa, na = (T(np.concatenate([s[j] for s in segs_np]), dev) for j in (1, 2, 3))
+        segments, off = [], 0
+        for k, u, p, n in segs_np:
+            segments.append((Id[k * rows:(k + 1) * rows], ua[off:off + u.size], pa[off:off + u.size], na[off:off + u.size]))
+            off += u.size
+        h = pipe.plan(Ud, segments, B)
+        assert h["chain"] == chain
+        losses = []
+        for k in range(3):
+            l = torch.empty(h["segs"][k]["nb"], dtype=torch.float32, device=dev)
+            pipe.run(h, k, lr, l)
+            losses.append(l)
+        torch.cuda.synchronize()
+        for sg in h["segs"]:
+            sg["tabs"].check_chain()
+        res.append((Ud, Id, torch.cat(losses), dict(pipe.stats)))
+    assert res[0][3]["chain_calls"] >= 3 and res[1][3]["chain_calls"] == 0
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert rel_err(res[0][2].cpu().numpy(), res[1][2].cpu().numpy()) < 1e-6
+    Uo, Io = U.copy(), I.copy()
+    ref = []
+    for k, u, p, n in segs_np:
+        view = Io[k * rows:(k + 1) * rows]
+        for j in range(u.size // B):
+            ref.append(oracle.bprmf_step_sgd(Uo, view, u[j * B:(j + 1) * B], p[j * B:(j + 1) * B], n[j * B:(j + 1) * B], lr, 0.0))
+    assert rel_err(res[0][2].cpu().numpy(), np.asarray(ref)) < TOL
+    assert rel_err(res[0][0].cpu().numpy(), Uo) < TOL and rel_err(res[0][1].cpu().numpy(), Io) < TOL
+
+
+def test_c4_shape_chained(ops):
+    """BASELINE.json configs[3] tables (10M x 10M, D = 128, B = 65,536; 5.1 GB per table, rows beyond 4 GB): four chained
+    steps against four two-launch steps, every bit of both tables"""
+    dev = torch.device("cuda:0")
+    nU = nI = 10_000_000
+    D, B, nb, lr = 128, 65536, 4, 0.05
+    g = torch.Generator(device=dev).manual_seed(11)
+    u = torch.randint(0, nU, (nb * B,), device=dev, generator=g, dtype=torch.int32)
+    p = torch.randint(0, nI, (nb * B,), device=dev, generator=g, dtype=torch.int32)
+    n = torch.randint(1, nI, (nb * B,), device=dev, generator=g, dtype=torch.int32)
+    p[:64] = nI - 1 - torch.arange(64, device=dev, dtype=torch.int32)          # rows behind the 4 GB mark, for sure
+    U0 = torch.randn(nU, D, device=dev, generator=g) * 0.1
+    I0 = torch.randn(nI, D, device=dev, generator=g) * 0.1
+    arena = ops.PlanArena(dev, nb * B, B, overlap_items=nI)
+    plan = ops.BatchPlan(u, p, n, B, nU, nI, arena=arena, overlap=True)
+    assert plan.overlap is not None and plan._bitmap_ready                    # the builder wrote the bitmap itself (shift 16)
+    ref = ops.BprmfTables(U0.clone(), I0.clone())
+    l_ref = ref.run_sgd(plan, 0, nb, lr)
+    tabs = ops.BprmfTables(U0, I0)
+    l_chain = tabs.run_sgd_chain(plan, 0, nb, lr)
+    torch.cuda.synchronize()
+    tabs.check_chain()
+    assert torch.equal(tabs.U, ref.U) and torch.equal(tabs.I, ref.I)
+    assert rel_err(l_chain.cpu().numpy(), l_ref.cpu().numpy()) < 1e-6
