@@ -145,3 +145,28 @@ def test_end_to_end_run_matches_the_reference_train_loop(g8, tmp_path, tag, runn
     assert np.abs(dev - g9[tag + "_dev"]).max() <= flips, np.abs(dev - g9[tag + "_dev"]).max()
     tst = np.asarray([test[k] for k in g9[tag + "_test_keys"]])
     assert np.abs(tst - g9[tag + "_test"]).max() <= flips
+
+
+def test_token_ids_need_not_be_numbers(tmp_path):
+    """alphanumeric tokens (yelp / food style) and integers beyond 2^53 are ids like any other — the corpus
+    equals the one read from the same file with the tokens replaced by small integers"""
+    from whisprrec_amd import reader
+    rng = np.random.RandomState(3)
+    n_u, n_i, rows = 30, 50, 1500
+    u = rng.randint(0, n_u, rows)
+    i = rng.randint(0, n_i, rows)
+    r = rng.randint(1, 6, rows)
+    t = np.arange(rows) + 1_000_000
+    big = 2 ** 60
+    for tag, fu, fi in (("num", lambda x: str(x + 7), lambda x: str(x + 3)),
+                        ("tok", lambda x: "u_%dx" % (x * 13), lambda x: str(big + x))):
+        d = tmp_path / tag / "toy"
+        d.mkdir(parents=True)
+        with open(d / "toy.inter", "w") as f:
+            f.write("user_id:token\titem_id:token\trating:float\ttimestamp:float\n")
+            for a, b, c, e in zip(u, i, r, t):
+                f.write("%s\t%s\t%d\t%d\n" % (fu(a), fi(b), c, e))
+    cols_num = reader.count_statics(reader.read_inter(str(tmp_path / "num" / "toy" / "toy.inter")), "toy")
+    cols_tok = reader.count_statics(reader.read_inter(str(tmp_path / "tok" / "toy" / "toy.inter")), "toy")
+    for k in cols_num:
+        assert np.array_equal(cols_num[k], cols_tok[k]), k

@@ -24,16 +24,30 @@ _COLUMNS = {"user_id:token": "user_id", "item_id:token": "item_id", "rating:floa
 
 
 def read_inter(path, sep="\t"):
-    """-> dict column -> float64/int64 array, in file order"""
+    """-> dict column -> float64/int64 array, in file order.  The id columns are TOKENS (the reference reads them with
+    pandas and renumbers whatever they are, sample.py:47-51): integer literals are taken as they stand, anything else
+    (alphanumeric ids of the yelp / food files, integers beyond 2^63) is numbered by first appearance here — the
+    renumbering after the filters (count_statics) then yields the same ids as renumbering the strings would."""
     with open(path, "r") as f:
         header = f.readline().rstrip("\n").split(sep)
     names = [_COLUMNS.get(h, h) for h in header]
-    raw = np.loadtxt(path, delimiter=sep, skiprows=1, dtype=np.float64, ndmin=2)
+    id_cols = [j for j, nm in enumerate(names) if nm in ("user_id", "item_id")]
+    num_cols = [j for j in range(len(names)) if j not in id_cols]
     out = {}
-    for j, nm in enumerate(names):
-        col = raw[:, j]
-        out[nm] = col.astype(np.int64) if nm in ("user_id", "item_id") or np.all(col == np.floor(col)) else col
-    return out
+    if id_cols:
+        tok = np.loadtxt(path, delimiter=sep, skiprows=1, dtype=str, usecols=id_cols, ndmin=2, comments=None)
+        for k, j in enumerate(id_cols):
+            col = tok[:, k]
+            try:
+                out[names[j]] = col.astype(np.int64)
+            except (ValueError, OverflowError):
+                out[names[j]] = _first_appearance_ids(col)
+    if num_cols:
+        raw = np.loadtxt(path, delimiter=sep, skiprows=1, dtype=np.float64, usecols=num_cols, ndmin=2)
+        for k, j in enumerate(num_cols):
+            col = raw[:, k]
+            out[names[j]] = col.astype(np.int64) if np.all(col == np.floor(col)) else col
+    return {nm: out[nm] for nm in names}
 
 
 def _first_appearance_ids(a):
