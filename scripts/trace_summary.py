@@ -21,21 +21,32 @@ def main():
     print("%-100s %7s %10s %10s %6s" % ("kernel", "calls", "avg_us", "total_us", "%"))
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:16]:
         print("%-100s %7d %10.2f %10.1f %6.2f" % (k[:100], len(v), sum(v) / len(v) / 1e3, sum(v) / 1e3, 100.0 * sum(v) / tot))
-    # the step stream: chained launches where the run used them, else the two-launch form
-    idx = [i for i, r in enumerate(rows) if "bprmf_chain_step" in r["Kernel_Name"]]
-    if len(idx) <= 20:
-        idx = [i for i, r in enumerate(rows) if "bprmf_user_phase" in r["Kernel_Name"]]
-    if len(idx) > 16:
-        i0 = idx[len(idx) // 2]
-        prev = None
-        print("\ntimeline (mid-run): kernel, duration us, gap before it us")
-        for r in rows[i0:i0 + nshow]:
-            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-            print("  %-70s %8.2f %8.2f" % (r["Kernel_Name"][:70], (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0))
-            prev = e
-        half = idx[len(idx) // 2:]
-        span = (int(rows[half[-1]]["Start_Timestamp"]) - int(rows[half[0]]["Start_Timestamp"])) / 1e3 / (len(half) - 1)
-        print("\nsteady-state span per step (2nd half of run, incl. plan builds): %.2f us" % span)
+    # the step stream: chained launches where the run used them, else the two-launch form.  The timed region of bench.py is
+    # the FIRST long group of consecutive step kernels (groups are separated by host synchronisations: warm-up pieces before
+    # it, the per-kernel timing passes after it)
+    name = "bprmf_chain_step" if sum("bprmf_chain_step" in r["Kernel_Name"] for r in rows) > 12 else "bprmf_user_phase"
+    idx = [i for i, r in enumerate(rows) if name in r["Kernel_Name"]]
+    groups, cur = [], []
+    for i in idx:
+        if cur and int(rows[i]["Start_Timestamp"]) - int(rows[cur[-1]]["End_Timestamp"]) > 80_000:
+            groups.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    timed = next((g for g in groups if len(g) >= 12), None)
+    if timed is not None:
+        print("\ntimeline (first steps of the timed region; every kernel of every stream): kernel, start us, duration us")
+        t0 = int(rows[timed[0]]["Start_Timestamp"])
+        for r in rows[timed[0]:timed[min(nshow, len(timed) - 1)] + 1]:
+            s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            print("  %-70s %9.2f %8.2f" % (r["Kernel_Name"][:70], (s0 - t0) / 1e3, (e0 - s0) / 1e3))
+        clean = [g for g in zip(timed[:-1], timed[1:])]
+        span = (int(rows[timed[-1]]["Start_Timestamp"]) - t0) / 1e3 / (len(timed) - 1)
+        durs = [(int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3 for i in timed]
+        print("\n%s kernels of the timed region: %d, start-to-start %.2f us per step (plan builds of the other stream included), "
+              "duration min %.2f / median %.2f / max %.2f us" % (name, len(timed), span, min(durs), sorted(durs)[len(durs) // 2],
+                                                                 max(durs)))
 
 
 if __name__ == "__main__":
