@@ -270,6 +270,13 @@ def make_bprmf(general_model_cls):
             return self.user_embeddings.weight.data, self.item_embeddings.weight.data
 
         # ------------------------------------------------------------------ native epoch (used by HipRunner)
+        def check_step_stream(self):
+            """after an epoch's losses have been read (the device is idle anyway): raises if a bounded wait inside a chained
+            step launch expired during the epoch (hip_ops.BprmfTables.check_chain; never observed)"""
+            tabs = getattr(self, "_step_stream_tabs", None)
+            if tabs is not None:
+                tabs.check_chain()
+
         @torch.no_grad()
         def train_epoch(self, u, p, n, batch_size, lr, l2=0.0, optimizer="SGD", chunk=64, prep=None):
             """Runs one epoch over triplets already in batch order on the device; returns the per-batch losses
@@ -287,6 +294,7 @@ def make_bprmf(general_model_cls):
                     self._pipe = hip_ops.PipelinedSgd(chunk)
                 handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size, lr=lr, prep=prep)
                 self._pipe.run(handle, 0, lr, losses)
+                self._step_stream_tabs = handle["segs"][0]["tabs"]      # check_step_stream(): the chained launches' flag
                 return losses
             chunk = hip_ops.PipelinedSgd(chunk).chunk_batches(batch_size)   # small batches: more of them per plan
             done = 0

@@ -436,11 +436,14 @@ def make_hip_runner(base_runner_cls):
                                                float(self.l2), self.optimizer_name, prep=prep)
                     out = float(np.mean(losses.cpu().numpy()))
                     prep.check()
+                    model.check_step_stream()
                     return out
                 cols = self._epoch_columns(dataset, dev, epoch)
                 losses = model.train_epoch(cols[0], cols[1], cols[2], self.batch_size, self.learning_rate, float(self.l2),
                                            self.optimizer_name)
-                return float(np.mean(losses.cpu().numpy()))  # one sync per epoch instead of one per batch (:200)
+                out = float(np.mean(losses.cpu().numpy()))   # one sync per epoch instead of one per batch (:200)
+                model.check_step_stream()
+                return out
             # any other triplet model (LightGCN, SGL, ...): the reference loop (BaseRunner.py:196-200) over batches that are
             # slices of the epoch's device columns — the same batches the DataLoader would collate sample by sample in Python
             if model.optimizer is None:
