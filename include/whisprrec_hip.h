@@ -425,6 +425,19 @@ int32_t wr_bprmf_run_adam_folded(float *user_tab, int64_t n_users, float *item_t
                                  int64_t adam_step0, float lr, const float *consts, int64_t n_consts, float l2, float beta1,
                                  float beta2, float eps, float *loss_out, const wr_hot_runs *hot, void *workspace,
                                  int64_t workspace_bytes, void *stream);
+/* wr_bprmf_run_adam_lazy with a bounded lag: before every step a rotating window of ceil(rows / max_lag) consecutive rows
+ * of each table is brought to the previous step (wr_adam_catchup_all on the sub-range), so that no row ever misses more
+ * than max_lag steps and the replays of a batch's rows stay short (small batches on big tables: a geometric tail of
+ * thousands of missed steps otherwise makes every catch-up launch wait for its unluckiest wave).  Same bits as the dense
+ * optimizer.  sweep_pos (HOST memory, in/out): [0] next user row, [1] next item row of the window; start at {0, 0}. */
+int32_t wr_bprmf_run_adam_lazy_bounded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                                       float *m_u, float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i,
+                                       const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                                       const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                                       int64_t n_batches, int64_t adam_step0, float lr, const float *consts, int64_t n_consts,
+                                       float l2, float beta1, float beta2, float eps, float *loss_out, const wr_hot_runs *hot,
+                                       int64_t max_lag, int64_t *sweep_pos, void *workspace, int64_t workspace_bytes,
+                                       void *stream);
 /* n_batches consecutive optimizer steps over batches [first_batch, first_batch + n_batches) of a plan, issued from native
  * code (the inner loop of BaseRunner.fit, BaseRunner.py:196-199, with the lazy optimizers): per batch
  *   Adam:  wr_adam_rows_lazy(NULL) on U and I rows -> wr_bprmf_step_adam (gradients + Adam on the rows it finishes);

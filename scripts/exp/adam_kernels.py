@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from whisprrec_amd import hip_ops
 dev = torch.device("cuda:0")
-nU = nI = 1_000_000; D = 64; B = 65536; NB = 48
+nU = nI = 1_000_000; D = 64; B = int(os.environ.get("WR_B", "65536")); NB = int(os.environ.get("WR_NB", "48"))
 g = torch.Generator(device=dev); g.manual_seed(1)
 u = torch.randint(0, nU, (NB * B,), generator=g, device=dev, dtype=torch.int32)
 p = torch.randint(0, nI, (NB * B,), generator=g, device=dev, dtype=torch.int32)

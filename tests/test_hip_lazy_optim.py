@@ -63,6 +63,38 @@ def test_lazy_adam_bit_identical_to_dense(l2, D, zipf, fold):
     assert int(st.last_u.min()) == steps and int(st.last_i.min()) == steps
 
 
+@pytest.mark.parametrize("max_lag", [1, 5, 64])
+@pytest.mark.parametrize("l2,D,zipf", [(0.0, 64, False), (1e-3, 32, True), (0.0, 20, False)])
+def test_bounded_lag_bit_identical_to_dense(l2, D, zipf, max_lag):
+    """wr_bprmf_run_adam_lazy_bounded: a rotating window of rows / max_lag rows per table is replayed before every step, so no
+    row misses more than max_lag steps — and nothing else changes: the dense optimizer's bits, native loop in two calls."""
+    nU, nI, B, steps, lr = 3000, 2500, 256, 24, 1e-2
+    hip_ops, U, I, plan = _setup(nU, nI, D, B, steps, 11 + D, zipf)
+    Ud, Id = U.clone(), I.clone()
+    td = hip_ops.BprmfTables(Ud, Id)
+    z = torch.zeros_like
+    gU, gI, mU, vU, mI, vI = z(Ud), z(Id), z(Ud), z(Ud), z(Id), z(Id)
+    dense_loss = []
+    for k in range(steps):
+        loss, sid = td.grads(plan, k, gU, gI)
+        dense_loss.append(loss.clone())
+        hip_ops.adam_dense(Ud, mU, vU, gU, k + 1, lr, l2, stamp=td.stamp_u, step_id=sid)
+        hip_ops.adam_dense(Id, mI, vI, gI, k + 1, lr, l2, stamp=td.stamp_i, step_id=sid)
+    Ul, Il = U.clone(), I.clone()
+    st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ul, Il), "Adam", lr, l2, fold=False, max_lag=max_lag)
+    l1 = st.run(plan, 0, 10)
+    l2_ = st.run(plan, 10, steps - 10)
+    # the invariant the window maintains: after step t every row stands at step >= t - 1 - max_lag (rows of the last
+    # window were brought to t - 1 before the step, the window comes round every max_lag steps)
+    assert int(st.last_u.min()) >= steps - 1 - max_lag and int(st.last_i.min()) >= steps - 1 - max_lag
+    if max_lag >= 5:
+        assert int(st.last_u.min()) < steps                   # still lazy: not every row is current
+    st.flush()
+    assert torch.equal(torch.cat([l1, l2_]), torch.stack(dense_loss))
+    for a, b in ((Ul, Ud), (Il, Id), (st.m_u, mU), (st.v_u, vU), (st.m_i, mI), (st.v_i, vI)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("D", [64, 24])
 def test_lazy_sgd_weight_decay_bit_identical_to_dense(D):
     nU, nI, B, steps, lr, l2 = 4000, 1500, 512, 20, 0.1, 1e-2

@@ -99,6 +99,9 @@ SIGNATURES = {
     "wr_bprmf_run_adam_folded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                          c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                          c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_run_adam_lazy_bounded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32,
+                                               c_f32, c_f32, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_run_adam_lazy": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                        c_vp, c_vp, c_vp, c_i64, c_vp]),

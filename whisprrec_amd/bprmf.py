@@ -296,28 +296,19 @@ def make_bprmf(general_model_cls):
                 self._pipe.run(handle, 0, lr, losses)
                 self._step_stream_tabs = handle["segs"][0]["tabs"]      # check_step_stream(): the chained launches' flag
                 return losses
-            chunk = hip_ops.PipelinedSgd(chunk).chunk_batches(batch_size)   # small batches: more of them per plan
-            done = 0
-            bmap = None       # skewed ids: after the first bucket overflow the builder gets a load-balanced map of this epoch
-            while done < nb:
-                c = min(chunk, nb - done)
-                lo, hi = done * batch_size, min(N, (done + c) * batch_size)
-                if prep is not None:
-                    prep.fill(lo, hi)
-                plan = hip_ops.BatchPlan(u[lo:hi], p[lo:hi], n[lo:hi], batch_size, self.user_num, self.item_num,
-                                         bucket_map=bmap or None)
-                if plan.fast_overflowed:
-                    src = (prep.users, prep.items) if prep is not None else (u, p)
-                    bmap = hip_ops.BucketMap(src[0], src[1], self.user_num, self.item_num, batch_size) if bmap is None else False
-                if FusedOptimizer.supports(optimizer, l2):
-                    if opt is None or opt.name != optimizer or opt.lr != float(lr) or opt.l2 != float(l2):
-                        if opt is not None and opt.adam_step > 0 and opt.name == optimizer:
-                            raise ValueError("lr / l2 changed after optimizer steps had been taken")
-                        opt = self.optimizer = FusedOptimizer(self, optimizer, lr, l2, getattr(opt, "lazy", -1))
-                    opt.run_batches(tabs, plan, 0, c, losses[done:done + c])
-                else:
-                    raise ValueError("train_epoch supports SGD and Adam; use BaseRunner.fit for %r" % optimizer)
-                done += c
+            if not FusedOptimizer.supports(optimizer, l2):
+                raise ValueError("train_epoch supports SGD and Adam; use BaseRunner.fit for %r" % optimizer)
+            if opt is None or opt.name != optimizer or opt.lr != float(lr) or opt.l2 != float(l2):
+                if opt is not None and opt.adam_step > 0 and opt.name == optimizer:
+                    raise ValueError("lr / l2 changed after optimizer steps had been taken")
+                opt = self.optimizer = FusedOptimizer(self, optimizer, lr, l2, getattr(opt, "lazy", -1))
+            # updates with optimizer state: the same plan pipeline (plans built on a side stream one chunk ahead, skewed ids
+            # switched to load-balanced buckets after the first overflow), steps issued by the fused optimizer
+            if getattr(self, "_pipe", None) is None:
+                self._pipe = hip_ops.PipelinedSgd(chunk)
+            handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size, prep=prep,
+                                     runner=lambda plan, first, count, out: opt.run_batches(tabs, plan, first, count, out))
+            self._pipe.run(handle, 0, lr, losses)
             return losses
 
     BPRMF.__qualname__ = "BPRMF"

@@ -108,18 +108,20 @@ __global__ __launch_bounds__(kBlock) void adam_lazy_rows_kernel(float *__restric
     adam_rows<L2, R>(w, m, v, last, rows, D, upto, grad, consts, l2, b1, b2, eps, threadIdx.x % kWave);
 }
 
-template <bool L2>
+// R rows per wave and trip: kRowsPerWave for whole tables (memory parallelism), 1 for a window of a few thousand rows (the
+// bounded-lag sweep: one wave per row keeps every SIMD busy)
+template <bool L2, int R>
 __global__ __launch_bounds__(kBlock) void adam_catchup_all_kernel(float *__restrict__ w, float *__restrict__ m,
                                                                    float *__restrict__ v, int *__restrict__ last,
                                                                    int64_t n_rows, int D, int upto,
                                                                    const float *__restrict__ consts, float l2, float b1,
                                                                    float b2, float eps) {
-    const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * kRowsPerWave;
-    for (int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * kRowsPerWave; r0 < n_rows; r0 += stride) {
-        int64_t rows[kRowsPerWave];
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * R;
+    for (int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * R; r0 < n_rows; r0 += stride) {
+        int64_t rows[R];
 #pragma unroll
-        for (int j = 0; j < kRowsPerWave; ++j) rows[j] = r0 + j < n_rows ? r0 + j : -1;
-        adam_rows<L2, kRowsPerWave>(w, m, v, last, rows, D, upto, nullptr, consts, l2, b1, b2, eps, threadIdx.x % kWave);
+        for (int j = 0; j < R; ++j) rows[j] = r0 + j < n_rows ? r0 + j : -1;
+        adam_rows<L2, R>(w, m, v, last, rows, D, upto, nullptr, consts, l2, b1, b2, eps, threadIdx.x % kWave);
     }
 }
 
@@ -234,7 +236,10 @@ int32_t wr_adam_catchup_all(float *tab, float *exp_avg, float *exp_avg_sq, int32
     WR_REQUIRE(last_step != nullptr && consts != nullptr, WR_E_NULL, "last_step / consts is NULL");
     WR_REQUIRE(adam_step >= 0 && adam_step < n_consts && adam_step < INT32_MAX, WR_E_RANGE,
                "adam_step %lld outside the consts table (%lld entries)", (long long)adam_step, (long long)n_consts);
-    hipLaunchKernelGGL(l2 != 0.f ? adam_catchup_all_kernel<true> : adam_catchup_all_kernel<false>, dim3(all_grid(n_rows)), dim3(kBlock), 0,
+    const bool small = n_rows < kSmallBatchKeys;
+    auto kern = small ? (l2 != 0.f ? adam_catchup_all_kernel<true, 1> : adam_catchup_all_kernel<false, 1>)
+                      : (l2 != 0.f ? adam_catchup_all_kernel<true, kRowsPerWave> : adam_catchup_all_kernel<false, kRowsPerWave>);
+    hipLaunchKernelGGL(kern, dim3(small ? rows_grid(n_rows, 1) : all_grid(n_rows)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream_), tab, exp_avg, exp_avg_sq, last_step, n_rows, D, (int)adam_step,
                        consts, l2, beta1, beta2, eps);
     WR_LAUNCH_CHECK("adam_catchup_all_kernel");
@@ -311,6 +316,68 @@ int32_t wr_bprmf_run_adam_lazy(float *user_tab, int64_t n_users, float *item_tab
                                      tp + off, tn + off, oc_item + 2 * off, oc_src + 2 * off, Bk, t, lr, l2, beta1, beta2, eps,
                                      loss_out ? loss_out + k : nullptr, hot ? &hb : nullptr, workspace, workspace_bytes,
                                      stream)) != WR_OK) return rc;
+    }
+    return WR_OK;
+}
+
+// The same loop with a BOUNDED LAG.  Between two uses a row misses (rows / batch rows) steps on average, geometrically
+// distributed: with small batches on big tables (the reference's defaults: Adam, B = 2,048; 1M-row tables -> ~490 on
+// average) the longest replay among a batch's rows is ~8x the mean, and a row's replay is one wave's serial chain — the
+// catch-up kernels then last as long as their unluckiest wave (steady state at 1M x 1M x 64, B = 2,048: 99 us per catch-up
+// launch, 196 at worst; the ~20 us figures of short runs only hold while no row has been idle for long).  Here every
+// step first sweeps ceil(rows / max_lag) consecutive rows of each table (a rotating window; wr_adam_catchup_all on the
+// sub-range) up to step t-1: after max_lag steps the whole table has been visited, so no row ever lags more than max_lag
+// steps, the batch rows' replays are short, and the bulk of the replay work — which exact dense-Adam semantics owe for every
+// row and step anyway — runs as uniform-length replays over thousands of waves.  A replay is a replay: the same
+// operations per row in the same order, so the tables stay bit-identical to the dense optimizer's.
+// sweep_pos (host, in/out): [0] next user row of the window, [1] next item row.
+static int32_t sweep_window(float *tab, float *m, float *v, int32_t *last, int64_t n_rows, int32_t D, int64_t rows, int64_t *pos,
+                            int64_t upto, const float *consts, int64_t n_consts, float l2, float b1, float b2, float eps,
+                            void *stream) {
+    int64_t lo = *pos % n_rows, left = rows < n_rows ? rows : n_rows;
+    while (left > 0) {
+        const int64_t c = left < n_rows - lo ? left : n_rows - lo;
+        const int32_t rc = wr_adam_catchup_all(tab + lo * (int64_t)D, m + lo * (int64_t)D, v + lo * (int64_t)D, last + lo, c, D,
+                                               upto, consts, n_consts, l2, b1, b2, eps, stream);
+        if (rc != WR_OK) return rc;
+        lo = (lo + c) % n_rows;
+        left -= c;
+    }
+    *pos = lo;
+    return WR_OK;
+}
+
+int32_t wr_bprmf_run_adam_lazy_bounded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                                       float *m_u, float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i,
+                                       const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                                       const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                                       int64_t n_batches, int64_t adam_step0, float lr, const float *consts, int64_t n_consts,
+                                       float l2, float beta1, float beta2, float eps, float *loss_out, const wr_hot_runs *hot,
+                                       int64_t max_lag, int64_t *sweep_pos, void *workspace, int64_t workspace_bytes,
+                                       void *stream) {
+    WR_REQUIRE(n_triplets > 0 && batch_size > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
+    WR_REQUIRE(max_lag >= 1 && sweep_pos != nullptr, WR_E_RANGE, "max_lag must be >= 1 and sweep_pos given");
+    WR_REQUIRE(n_users > 0 && n_items > 0 && sweep_pos[0] >= 0 && sweep_pos[1] >= 0, WR_E_SHAPE, "bad sweep position");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(adam_step0 >= 1 && adam_step0 + n_batches <= n_consts, WR_E_RANGE,
+               "adam steps [%lld,%lld) outside the consts table (%lld entries)", (long long)adam_step0,
+               (long long)(adam_step0 + n_batches), (long long)n_consts);
+    const int64_t rows_u = (n_users + max_lag - 1) / max_lag, rows_i = (n_items + max_lag - 1) / max_lag;
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t t = adam_step0 + k;
+        int32_t rc;
+        if (t > 1) {   // rows of the window -> step t-1 (zero-gradient steps; nothing to do before the first step)
+            if ((rc = sweep_window(user_tab, m_u, v_u, last_u, n_users, D, rows_u, &sweep_pos[0], t - 1, consts, n_consts, l2,
+                                   beta1, beta2, eps, stream)) != WR_OK) return rc;
+            if ((rc = sweep_window(item_tab, m_i, v_i, last_i, n_items, D, rows_i, &sweep_pos[1], t - 1, consts, n_consts, l2,
+                                   beta1, beta2, eps, stream)) != WR_OK) return rc;
+        }
+        if ((rc = wr_bprmf_run_adam_lazy(user_tab, n_users, item_tab, n_items, D, m_u, v_u, m_i, v_i, last_u, last_i, tu, tp, tn,
+                                         oc_item, oc_src, n_triplets, batch_size, first_batch + k, 1, t, lr, consts, n_consts,
+                                         l2, beta1, beta2, eps, loss_out ? loss_out + k : nullptr, hot, workspace,
+                                         workspace_bytes, stream)) != WR_OK) return rc;
     }
     return WR_OK;
 }

@@ -1010,11 +1010,14 @@ class PipelinedSgd:
             self._arenas[key] = pair
         return pair
 
-    def plan(self, U, segments, batch, first_chunk=None, lr=None, prep=None):
+    def plan(self, U, segments, batch, first_chunk=None, lr=None, prep=None, runner=None):
         """segments: [(item rows view [rows, D], u, p, n)] — u rows of U, p and n rows of the view, in batch order.
         Only the last segment may end with a short batch.  first_chunk: batches in the first plan, or a list with the sizes
         of the first few plans (default: full chunks) — lets a caller that consumes the stream piecewise (bench.py: warm-up,
-        then timed steps) put a plan boundary where its pieces meet."""
+        then timed steps) put a plan boundary where its pieces meet.
+        runner: callable(plan, first, count, losses) that issues `count` steps of `plan` from batch `first` — for updates
+        other than plain SGD (the exact-lazy Adam / weight-decay steps, Adagrad, Adadelta: FusedOptimizer.run_batches); the
+        plan pipeline (arenas, builds one chunk ahead on the side stream, asynchronous read-back) is the same."""
         if self.plan_stream is None:
             self.plan_stream = side_stream(U.device)
         B = int(batch)
@@ -1039,7 +1042,9 @@ class PipelinedSgd:
         if use_overlap and self.item_stream is None:
             self.item_stream = side_stream(U.device)
             self._ovl_events = self.ops.OverlapEvents(U.device)
-        use_chain = self.chain and not use_overlap and B >= self.CHAIN_MIN_BATCH and first >= 2 and \
+        if runner is not None:
+            use_overlap = False
+        use_chain = self.chain and runner is None and not use_overlap and B >= self.CHAIN_MIN_BATCH and first >= 2 and \
             min([s[0].shape[0] for s in live] or [0]) >= self.CHAIN_MIN_ITEMS_PER_TRIPLET * B and \
             all(sg["tabs"].chain_supported() for sg in segs if sg["tabs"] is not None)
         arenas = self._arena_pair(U.device, B, first, n_items if (use_overlap or use_chain) else 0)
@@ -1047,7 +1052,7 @@ class PipelinedSgd:
             a.release_after(main)
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
-             "overlap": use_overlap, "chain": use_chain, "prep": prep,
+             "overlap": use_overlap, "chain": use_chain, "prep": prep, "runner": runner,
              "inline": (not use_overlap) and bool(self.inline_plan),
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
         if use_overlap:
@@ -1181,6 +1186,9 @@ class PipelinedSgd:
                 self.stats["graph_replays"] += 1
                 losses[loss_off:loss_off + c].copy_(graph[1])
                 sg["tabs"].step_id += c
+            elif h["runner"] is not None:
+                h["runner"](plan, pos - base, c, losses[loss_off:loss_off + c])
+                self.stats["plain_calls"] += 1
             elif h["chain"] and plan.overlap is not None and c >= 2:
                 sg["tabs"].run_sgd_chain(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
                 self.stats["chain_calls"] += 1
@@ -1221,7 +1229,10 @@ class LazyOptimizerState:
 
     FOLD_MAX_GAP = 40      # fold the catch-up into the step kernels while a row misses about this many steps between two uses
 
-    def __init__(self, tabs, name, lr, l2, betas=(0.9, 0.999), eps=1e-8, fold=None):
+    MAX_LAG = 64           # bounded lag (Adam): rows of a rotating window are replayed every step so that none misses more
+    LAG_MIN_GAP = 64       # ... used when a row misses more than this many steps between two uses on average (rows / batch)
+
+    def __init__(self, tabs, name, lr, l2, betas=(0.9, 0.999), eps=1e-8, fold=None, max_lag=None):
         """fold (Adam): the catch-up of a batch's rows happens inside the step kernels' row loads (wr_bprmf_step_adam_folded:
         6 instead of 12 row transfers per touched row) instead of in a pass of its own; same bits either way.  The folded
         replay is balanced over the four rows a wave holds (adam_replay_balanced: the wave transposes its data so that all
@@ -1229,11 +1240,23 @@ class LazyOptimizerState:
         replayed by each of its readers, and with few waves on the GPU the replay is latency-bound, so it pays while replays are
         short: None (default) = fold when a row misses about FOLD_MAX_GAP steps or fewer between two batches that contain it
         (rows / batch size).  MI355X, 1M x 1M x 64, us/step separate -> folded: B = 65,536 (gap ~16) 155 -> 105; B = 32,768
-        (~31) 105 -> 84; B = 16,384 (~61) 73 -> 91; B = 2,048 (~490) 55 -> 283 (scripts/ab_adam.py)."""
+        (~31) 105 -> 84; B = 16,384 (~61) 73 -> 91; B = 2,048 (~490) 55 -> 283 (scripts/ab_adam.py).
+        max_lag (Adam, separate catch-up): None (default) = MAX_LAG when a row misses more than LAG_MIN_GAP steps between
+        two uses on average, else unbounded; 0 = unbounded; n = before every step a rotating window of rows / n rows per
+        table is brought up to date, so that no row ever misses more than n steps (wr_bprmf_run_adam_lazy_bounded).  Missed
+        steps are geometrically distributed: at B = 2,048 on 1M-row tables the mean is ~490 and the longest among a batch's
+        rows ~3,700 — one wave's serial chain that the whole launch waits for (steady state 206 us/step; the 44-56 us of
+        short runs only hold until rows have been idle for long).  The window does the replays every row is owed anyway as
+        uniform-length work over thousands of waves.  Same bits.  MI355X, 1M x 1M x 64, whole epochs in steady state
+        (scripts/exp/adam_epoch.py), us/step at max_lag = unbounded / 1024 / 512 / 256 / 128 / 64 / 32 / 16: B = 2,048: 206 /
+        151 / 96 / 76 / 66 / 61.6 / 62.4 / 78 (the window's row traffic grows as the lag shrinks); B = 8,192: - / 133 / 109 /
+        - / 80 / 72.5 / 73.5 / 89; B = 16,384 (a row misses ~61 steps): 88 either way."""
         if name not in ("SGD", "Adam"):
             raise ValueError(name)
         self.tabs, self.name, self.lr, self.l2, self.betas, self.eps = tabs, name, float(lr), float(l2), betas, float(eps)
         self.fold = fold if fold is None else bool(fold)
+        self.max_lag = max_lag if max_lag is None else int(max_lag)
+        self._sweep_pos = (ctypes.c_int64 * 2)(0, 0)
         dev = tabs.dev
         self.t = 0                                                       # optimizer steps taken
         self.flushed_at = 0
@@ -1250,6 +1273,12 @@ class LazyOptimizerState:
             gap = max(self.tabs.U.shape[0], self.tabs.I.shape[0]) / float(max(plan.batch_size, 1))
             return gap <= self.FOLD_MAX_GAP
         return self.fold
+
+    def _lag(self, plan):
+        if self.max_lag is None:
+            gap = max(self.tabs.U.shape[0], self.tabs.I.shape[0]) / float(max(plan.batch_size, 1))
+            return self.MAX_LAG if gap > self.LAG_MIN_GAP else 0
+        return self.max_lag
 
     def _grow_consts(self, n):
         host = torch.empty(2 * n, dtype=torch.float32)
@@ -1317,13 +1346,19 @@ class LazyOptimizerState:
         if self.name == "Adam":
             while self.t + count >= self.n_consts:
                 self._grow_consts(2 * self.n_consts)
-            fn = L.wr_bprmf_run_adam_folded if self._folds(plan) else L.wr_bprmf_run_adam_lazy
-            abi.check(fn(
-                _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.m_u), _p(self.v_u), _p(self.m_i),
-                _p(self.v_i), _p(self.last_u), _p(self.last_i),
-                _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets, plan.batch_size,
-                first, count, t0, self.lr, _p(self.consts), self.n_consts, self.l2, self.betas[0], self.betas[1], self.eps,
-                _p(losses), hp, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_adam_lazy")
+            head = (_p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.m_u), _p(self.v_u), _p(self.m_i),
+                    _p(self.v_i), _p(self.last_u), _p(self.last_i),
+                    _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets, plan.batch_size,
+                    first, count, t0, self.lr, _p(self.consts), self.n_consts, self.l2, self.betas[0], self.betas[1], self.eps,
+                    _p(losses), hp)
+            lag = self._lag(plan)
+            if self._folds(plan):
+                abi.check(L.wr_bprmf_run_adam_folded(*head, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_adam_folded")
+            elif lag > 0:
+                abi.check(L.wr_bprmf_run_adam_lazy_bounded(*head, lag, ctypes.addressof(self._sweep_pos), _p(ws), ws.numel(),
+                                                           _stream()), "wr_bprmf_run_adam_lazy_bounded")
+            else:
+                abi.check(L.wr_bprmf_run_adam_lazy(*head, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_adam_lazy")
         else:
             abi.check(L.wr_bprmf_run_sgd_lazy(
                 _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.last_u), _p(self.last_i), _p(su),
