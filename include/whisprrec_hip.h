@@ -438,6 +438,27 @@ int32_t wr_bprmf_run_adam_lazy_bounded(float *user_tab, int64_t n_users, float *
                                        float l2, float beta1, float beta2, float eps, float *loss_out, const wr_hot_runs *hot,
                                        int64_t max_lag, int64_t *sweep_pos, void *workspace, int64_t workspace_bytes,
                                        void *stream);
+/* The bounded-lag forms of wr_bprmf_run_sgd_lazy and wr_bprmf_run_stateful (Adadelta), as wr_bprmf_run_adam_lazy_bounded:
+ * a rotating window of ceil(rows / max_lag) rows per table takes the zero-gradient steps it missed before every step
+ * (wr_sgd_catchup_all / wr_adadelta_decay_all on the sub-range).  Same bits as without the window. */
+int32_t wr_bprmf_run_sgd_lazy_bounded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                                      int32_t *last_u, int32_t *last_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0,
+                                      const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                                      const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                                      int64_t n_batches, int64_t step0, float lr, float l2, float *loss_out,
+                                      const wr_hot_runs *hot, int64_t max_lag, int64_t *sweep_pos, void *workspace,
+                                      int64_t workspace_bytes, void *stream);
+int32_t wr_bprmf_run_stateful_bounded(int32_t kind, float *user_tab, int64_t n_users, float *item_tab, int64_t n_items,
+                                      int32_t D, float *s1_u, float *s2_u, float *s1_i, float *s2_i, int32_t *last_u,
+                                      int32_t *last_i, const int32_t *tu, const int32_t *tp, const int32_t *tn,
+                                      const int32_t *oc_item, const int32_t *oc_src, int64_t n_triplets, int64_t batch_size,
+                                      int64_t first_batch, int64_t n_batches, int64_t step0, float lr, float rho, float eps,
+                                      float *loss_out, const wr_hot_runs *hot, int64_t max_lag, int64_t *sweep_pos,
+                                      void *workspace, int64_t workspace_bytes, void *stream);
+/* Adadelta's zero-gradient steps on rows [0, n_rows): both state rows times rho once per missed step (step - last_step[r]
+ * multiplications), last_step[r] = step. */
+int32_t wr_adadelta_decay_all(float *square_avg, float *acc_delta, int32_t *last_step, int64_t n_rows, int32_t D, int64_t step,
+                              float rho, void *stream);
 /* n_batches consecutive optimizer steps over batches [first_batch, first_batch + n_batches) of a plan, issued from native
  * code (the inner loop of BaseRunner.fit, BaseRunner.py:196-199, with the lazy optimizers): per batch
  *   Adam:  wr_adam_rows_lazy(NULL) on U and I rows -> wr_bprmf_step_adam (gradients + Adam on the rows it finishes);

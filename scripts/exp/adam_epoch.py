@@ -30,6 +30,6 @@ for B, nb in [tuple(int(x) for x in c.split(":")) for c in os.environ.get("WR_CA
     n = torch.randint(1, nI, (N,), device=dev, generator=g)
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        losses = model.train_epoch(u, p, n, B, 1e-3, 0.0, "Adam")
+        losses = model.train_epoch(u, p, n, B, 1e-3, float(os.environ.get("WR_L2", "0")), os.environ.get("WR_OPT", "Adam"))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print("B=%d: %d steps in %.1f ms = %.1f us/step, loss %.4f" % (B, nb, dt * 1e3, dt / nb * 1e6, float(losses.mean())))

@@ -95,16 +95,20 @@ def test_bounded_lag_bit_identical_to_dense(l2, D, zipf, max_lag):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("max_lag", [0, 3])
 @pytest.mark.parametrize("D", [64, 24])
-def test_lazy_sgd_weight_decay_bit_identical_to_dense(D):
+def test_lazy_sgd_weight_decay_bit_identical_to_dense(D, max_lag):
+    """max_lag = 3: with the rotating window (wr_bprmf_run_sgd_lazy_bounded) no row misses more than 3 decay steps"""
     nU, nI, B, steps, lr, l2 = 4000, 1500, 512, 20, 0.1, 1e-2
     hip_ops, U, I, plan = _setup(nU, nI, D, B, steps, 3 + D, True)
     Ud, Id = U.clone(), I.clone()
     td = hip_ops.BprmfTables(Ud, Id)
     dense_loss = [td.step_sgd(plan, k, lr, l2).clone() for k in range(steps)]
     Ul, Il = U.clone(), I.clone()
-    st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ul, Il), "SGD", lr, l2)
+    st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(Ul, Il), "SGD", lr, l2, max_lag=max_lag)
     lazy_loss = [st.step(plan, k).clone() for k in range(steps)]
+    if max_lag:
+        assert int(st.last_u.min()) >= steps - 1 - max_lag and int(st.last_i.min()) >= steps - 1 - max_lag
     st.flush()
     assert torch.equal(torch.stack(lazy_loss), torch.stack(dense_loss))
     assert torch.equal(Ul, Ud) and torch.equal(Il, Id)

@@ -57,16 +57,20 @@ def test_sparse_fused_equals_dense_restatement(name, D, zipf):
     if zipf:
         assert plan.hot is not None
     outs = []
-    for native in (True, False):
+    for native in (True, False, "lag3", "lag1"):              # lagN: a rotating window keeps every row within N steps (Adadelta)
         Ud, Id = T(U, dev), T(I, dev)
-        st = hip_ops.StatefulSparseState(hip_ops.BprmfTables(Ud, Id), name, lr)
+        st = hip_ops.StatefulSparseState(hip_ops.BprmfTables(Ud, Id), name, lr,
+                                         max_lag=int(native[3:]) if isinstance(native, str) else 0)
         if native:
             losses = torch.cat([st.run(plan, 0, 5), st.run(plan, 5, steps - 5)])
         else:
             losses = torch.stack([st.step(plan, k).clone() for k in range(steps)])
         torch.cuda.synchronize()
         outs.append((Ud, Id, losses, st))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
+    if name == "Adadelta":
+        assert int(outs[2][3].last_u.min()) >= steps - 1 - 3 and int(outs[0][3].last_u.min()) == 0
     Uo, Io = U.copy(), I.copy()
     z = np.zeros_like
     su, si, au, ai = z(Uo), z(Io), z(Uo), z(Io)

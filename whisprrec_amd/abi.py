@@ -99,6 +99,13 @@ SIGNATURES = {
     "wr_bprmf_run_adam_folded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                          c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                          c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_run_sgd_lazy_bounded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp,
+                                              c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_vp, c_vp, c_i64,
+                                              c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_run_stateful_bounded": (c_i32, [c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                              c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_f32,
+                                              c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "wr_adadelta_decay_all": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_vp]),
     "wr_bprmf_run_adam_lazy_bounded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32,
                                                c_f32, c_f32, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),

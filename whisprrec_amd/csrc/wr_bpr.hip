@@ -1639,6 +1639,46 @@ int32_t wr_bprmf_run_stateful(int32_t kind, float *user_tab, int64_t n_users, fl
     return WR_OK;
 }
 
+// wr_bprmf_run_stateful with a bounded lag for Adadelta's state rows (kind 2; Adagrad has nothing to replay): before every
+// step a rotating window of ceil(rows / max_lag) consecutive rows of each table takes the decays it missed
+// (wr_adadelta_decay_all on the sub-range) — the finisher of a row otherwise replays them itself, and with small batches on
+// big tables the longest such replay among a batch's rows holds the launch (see wr_bprmf_run_adam_lazy_bounded).
+int32_t wr_bprmf_run_stateful_bounded(int32_t kind, float *user_tab, int64_t n_users, float *item_tab, int64_t n_items,
+                                      int32_t D, float *s1_u, float *s2_u, float *s1_i, float *s2_i, int32_t *last_u,
+                                      int32_t *last_i, const int32_t *tu, const int32_t *tp, const int32_t *tn,
+                                      const int32_t *oc_item, const int32_t *oc_src, int64_t n_triplets, int64_t batch_size,
+                                      int64_t first_batch, int64_t n_batches, int64_t step0, float lr, float rho, float eps,
+                                      float *loss_out, const wr_hot_runs *hot, int64_t max_lag, int64_t *sweep_pos,
+                                      void *workspace, int64_t workspace_bytes, void *stream) {
+    WR_REQUIRE(max_lag >= 1 && sweep_pos != nullptr && sweep_pos[0] >= 0 && sweep_pos[1] >= 0, WR_E_RANGE,
+               "max_lag must be >= 1 and sweep_pos given");
+    WR_REQUIRE(n_users > 0 && n_items > 0 && n_batches >= 0 && step0 >= 1, WR_E_SHAPE, "bad sizes");
+    const int64_t rows[2] = {(n_users + max_lag - 1) / max_lag, (n_items + max_lag - 1) / max_lag};
+    float *s1[2] = {s1_u, s1_i}, *s2[2] = {s2_u, s2_i};
+    int32_t *lasts[2] = {last_u, last_i};
+    const int64_t n_rows[2] = {n_users, n_items};
+    for (int64_t k = 0; k < n_batches; ++k) {
+        int32_t rc;
+        const int64_t t = step0 + k;
+        for (int side = 0; side < 2 && kind == 2 && t > 1; ++side) {
+            int64_t lo = sweep_pos[side] % n_rows[side], left = rows[side] < n_rows[side] ? rows[side] : n_rows[side];
+            while (left > 0) {
+                const int64_t c = left < n_rows[side] - lo ? left : n_rows[side] - lo;
+                if ((rc = wr_adadelta_decay_all(s1[side] + lo * (int64_t)D, s2[side] + lo * (int64_t)D, lasts[side] + lo, c, D,
+                                                t - 1, rho, stream)) != WR_OK) return rc;
+                lo = (lo + c) % n_rows[side];
+                left -= c;
+            }
+            sweep_pos[side] = lo;
+        }
+        if ((rc = wr_bprmf_run_stateful(kind, user_tab, n_users, item_tab, n_items, D, s1_u, s2_u, s1_i, s2_i, last_u, last_i, tu,
+                                        tp, tn, oc_item, oc_src, n_triplets, batch_size, first_batch + k, 1, t, lr, rho, eps,
+                                        loss_out ? loss_out + k : nullptr, hot, workspace, workspace_bytes, stream)) != WR_OK)
+            return rc;
+    }
+    return WR_OK;
+}
+
 int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,
                             const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                             const int32_t *oc_src, int64_t B, int64_t global_batch, float lr, float *grad_slots,

@@ -168,14 +168,40 @@ __global__ __launch_bounds__(kBlock) void sgd_lazy_rows_kernel(float *__restrict
     sgd_rows<R>(w, last, rows, D, upto, mark, lr, l2, threadIdx.x % kWave);
 }
 
+template <int R>
 __global__ __launch_bounds__(kBlock) void sgd_catchup_all_kernel(float *__restrict__ w, int *__restrict__ last, int64_t n_rows,
                                                                   int D, int upto, float lr, float l2) {
-    const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * kRowsPerWave;
-    for (int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * kRowsPerWave; r0 < n_rows; r0 += stride) {
-        int64_t rows[kRowsPerWave];
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave) * R;
+    for (int64_t r0 = ((int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * R; r0 < n_rows; r0 += stride) {
+        int64_t rows[R];
 #pragma unroll
-        for (int j = 0; j < kRowsPerWave; ++j) rows[j] = r0 + j < n_rows ? r0 + j : -1;
-        sgd_rows<kRowsPerWave>(w, last, rows, D, upto, upto, lr, l2, threadIdx.x % kWave);
+        for (int j = 0; j < R; ++j) rows[j] = r0 + j < n_rows ? r0 + j : -1;
+        sgd_rows<R>(w, last, rows, D, upto, upto, lr, l2, threadIdx.x % kWave);
+    }
+}
+
+// torch.optim.Adadelta with a zero gradient multiplies both state rows by rho (wr_bpr.hip, MODE 6: the finisher of a row
+// replays the multiplications the row missed).  This kernel applies the missed ones of rows [0, n_rows) up to step `upto`
+// and marks the rows — the bounded-lag window of wr_bprmf_run_stateful_bounded.  k multiplications are k multiplications,
+// whoever applies them: same bits.
+__global__ __launch_bounds__(kBlock) void adadelta_decay_all_kernel(float *__restrict__ sq, float *__restrict__ ac,
+                                                                     int *__restrict__ last, int64_t n_rows, int D, int upto,
+                                                                     float rho) {
+    const int lane = threadIdx.x % kWave;
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; r < n_rows; r += stride) {
+        const int missed = upto - __builtin_amdgcn_readfirstlane(last[r]);
+        if (missed <= 0) continue;
+        for (int e = lane; e < D; e += kWave) {
+            float a = sq[r * (int64_t)D + e], b = ac[r * (int64_t)D + e];
+            for (int j = 0; j < missed; ++j) {
+                a *= rho;
+                b *= rho;
+            }
+            sq[r * (int64_t)D + e] = a;
+            ac[r * (int64_t)D + e] = b;
+        }
+        if (lane == 0) last[r] = upto;
     }
 }
 
@@ -268,8 +294,12 @@ int32_t wr_sgd_catchup_all(float *tab, int32_t *last_step, int64_t n_rows, int32
     if ((rc = check_table(tab, n_rows, D, "tab")) != WR_OK) return rc;
     WR_REQUIRE(last_step != nullptr, WR_E_NULL, "last_step is NULL");
     WR_REQUIRE(step >= 0 && step < INT32_MAX, WR_E_RANGE, "step must be >= 0");
-    hipLaunchKernelGGL(sgd_catchup_all_kernel, dim3(all_grid(n_rows)), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(stream_), tab, last_step, n_rows, D, (int)step, lr, l2);
+    if (n_rows < kSmallBatchKeys)     // a window of rows (bounded lag): one wave per row
+        hipLaunchKernelGGL(sgd_catchup_all_kernel<1>, dim3(rows_grid(n_rows, 1)), dim3(kBlock), 0,
+                           reinterpret_cast<hipStream_t>(stream_), tab, last_step, n_rows, D, (int)step, lr, l2);
+    else
+        hipLaunchKernelGGL(sgd_catchup_all_kernel<kRowsPerWave>, dim3(all_grid(n_rows)), dim3(kBlock), 0,
+                           reinterpret_cast<hipStream_t>(stream_), tab, last_step, n_rows, D, (int)step, lr, l2);
     WR_LAUNCH_CHECK("sgd_catchup_all_kernel");
     return WR_OK;
 }
@@ -452,6 +482,59 @@ int32_t wr_bprmf_run_sgd_lazy(float *user_tab, int64_t n_users, float *item_tab,
                                     loss_out ? loss_out + k : nullptr, hot ? &hb : nullptr, workspace, workspace_bytes,
                                     stream)) != WR_OK) return rc;
     }
+    return WR_OK;
+}
+
+// wr_bprmf_run_sgd_lazy with a bounded lag (see wr_bprmf_run_adam_lazy_bounded): before every step a rotating window of
+// ceil(rows / max_lag) consecutive rows of each table takes the weight-decay steps it missed (wr_sgd_catchup_all on the
+// sub-range).  sweep_pos (host, in/out): next user row, next item row.
+int32_t wr_bprmf_run_sgd_lazy_bounded(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                                      int32_t *last_u, int32_t *last_i, int32_t *stamp_u, int32_t *stamp_i, int32_t step_id0,
+                                      const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                                      const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                                      int64_t n_batches, int64_t step0, float lr, float l2, float *loss_out,
+                                      const wr_hot_runs *hot, int64_t max_lag, int64_t *sweep_pos, void *workspace,
+                                      int64_t workspace_bytes, void *stream) {
+    WR_REQUIRE(max_lag >= 1 && sweep_pos != nullptr && sweep_pos[0] >= 0 && sweep_pos[1] >= 0, WR_E_RANGE,
+               "max_lag must be >= 1 and sweep_pos given");
+    WR_REQUIRE(n_users > 0 && n_items > 0 && n_batches >= 0 && step0 >= 1, WR_E_SHAPE, "bad sizes");
+    const int64_t rows[2] = {(n_users + max_lag - 1) / max_lag, (n_items + max_lag - 1) / max_lag};
+    float *tabs[2] = {user_tab, item_tab};
+    int32_t *lasts[2] = {last_u, last_i};
+    const int64_t n_rows[2] = {n_users, n_items};
+    for (int64_t k = 0; k < n_batches; ++k) {
+        int32_t rc;
+        const int64_t t = step0 + k;
+        for (int side = 0; side < 2 && t > 1; ++side) {
+            int64_t lo = sweep_pos[side] % n_rows[side], left = rows[side] < n_rows[side] ? rows[side] : n_rows[side];
+            while (left > 0) {
+                const int64_t c = left < n_rows[side] - lo ? left : n_rows[side] - lo;
+                if ((rc = wr_sgd_catchup_all(tabs[side] + lo * (int64_t)D, lasts[side] + lo, c, D, t - 1, lr, l2, stream)) != WR_OK)
+                    return rc;
+                lo = (lo + c) % n_rows[side];
+                left -= c;
+            }
+            sweep_pos[side] = lo;
+        }
+        if ((rc = wr_bprmf_run_sgd_lazy(user_tab, n_users, item_tab, n_items, D, last_u, last_i, stamp_u, stamp_i,
+                                        step_id0 + (int32_t)k, tu, tp, tn, oc_item, oc_src, n_triplets, batch_size,
+                                        first_batch + k, 1, t, lr, l2, loss_out ? loss_out + k : nullptr, hot, workspace,
+                                        workspace_bytes, stream)) != WR_OK) return rc;
+    }
+    return WR_OK;
+}
+
+int32_t wr_adadelta_decay_all(float *square_avg, float *acc_delta, int32_t *last_step, int64_t n_rows, int32_t D, int64_t step,
+                              float rho, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(square_avg, n_rows, D, "square_avg")) != WR_OK) return rc;
+    if ((rc = check_table(acc_delta, n_rows, D, "acc_delta")) != WR_OK) return rc;
+    WR_REQUIRE(last_step != nullptr, WR_E_NULL, "last_step is NULL");
+    WR_REQUIRE(step >= 0 && step < INT32_MAX, WR_E_RANGE, "step must be >= 0");
+    const int64_t g = (n_rows + kBlock / kWave - 1) / (kBlock / kWave), cap = 256 * 64;
+    hipLaunchKernelGGL(adadelta_decay_all_kernel, dim3((unsigned)(g < 1 ? 1 : (g > cap ? cap : g))), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream_), square_avg, acc_delta, last_step, n_rows, D, (int)step, rho);
+    WR_LAUNCH_CHECK("adadelta_decay_all_kernel");
     return WR_OK;
 }
 

@@ -1294,6 +1294,9 @@ class LazyOptimizerState:
     def step(self, plan, k, loss_out=None):
         """optimizer step on batch k of the plan (gradient computation included); returns the loss tensor"""
         tabs = self.tabs
+        if self._lag(plan) > 0 and not (self.name == "Adam" and self._folds(plan)):
+            out = self.run(plan, k, 1, losses=None if loss_out is None else loss_out.reshape(1))   # keeps the window turning
+            return out.reshape(()) if loss_out is None else loss_out
         self.t += 1
         tu, _, _, oi, _, B = tabs._plan_ptrs(plan, k)
         if self.name == "Adam":
@@ -1360,11 +1363,15 @@ class LazyOptimizerState:
             else:
                 abi.check(L.wr_bprmf_run_adam_lazy(*head, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_adam_lazy")
         else:
-            abi.check(L.wr_bprmf_run_sgd_lazy(
-                _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.last_u), _p(self.last_i), _p(su),
-                _p(si), tabs.step_id + 1, _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src),
-                plan.n_triplets, plan.batch_size, first, count, t0, self.lr, self.l2, _p(losses), hp, _p(ws), ws.numel(),
-                _stream()), "wr_bprmf_run_sgd_lazy")
+            head = (_p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.last_u), _p(self.last_i), _p(su),
+                    _p(si), tabs.step_id + 1, _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src),
+                    plan.n_triplets, plan.batch_size, first, count, t0, self.lr, self.l2, _p(losses), hp)
+            lag = self._lag(plan)
+            if lag > 0:
+                abi.check(L.wr_bprmf_run_sgd_lazy_bounded(*head, lag, ctypes.addressof(self._sweep_pos), _p(ws), ws.numel(),
+                                                          _stream()), "wr_bprmf_run_sgd_lazy_bounded")
+            else:
+                abi.check(L.wr_bprmf_run_sgd_lazy(*head, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_sgd_lazy")
         self.t += count
         tabs.step_id += count
         return losses
@@ -1394,9 +1401,15 @@ class StatefulSparseState:
 
     KIND = {"Adagrad": 1, "Adadelta": 2}
 
-    def __init__(self, tabs, name, lr, rho=0.9, eps=None):
+    MAX_LAG, LAG_MIN_GAP = 64, 64       # Adadelta: bounded lag as in LazyOptimizerState
+
+    def __init__(self, tabs, name, lr, rho=0.9, eps=None, max_lag=None):
+        """max_lag (Adadelta): a rotating window of rows / max_lag rows per table takes its missed decays before every step
+        (wr_bprmf_run_stateful_bounded) — None = MAX_LAG when a row misses more than LAG_MIN_GAP steps on average, 0 = never."""
         if name not in self.KIND:
             raise ValueError(name)
+        self.max_lag = max_lag if max_lag is None else int(max_lag)
+        self._sweep_pos = (ctypes.c_int64 * 2)(0, 0)
         self.tabs, self.name, self.lr, self.rho = tabs, name, float(lr), float(rho)
         self.eps = float(eps) if eps is not None else (1e-10 if name == "Adagrad" else 1e-6)   # torch.optim defaults
         z = torch.zeros_like
@@ -1414,11 +1427,19 @@ class StatefulSparseState:
             losses = torch.empty(count, dtype=torch.float32, device=tabs.dev)
         ws = tabs._ws(plan.batch_size)
         hot = plan.hot_struct()
-        abi.check(abi.lib().wr_bprmf_run_stateful(
-            self.KIND[self.name], _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.s1_u), _p(self.s2_u),
-            _p(self.s1_i), _p(self.s2_i), _p(self.last_u), _p(self.last_i), _p(plan.tu), _p(plan.tp), _p(plan.tn), _p(plan.oc_item),
-            _p(plan.oc_src), plan.n_triplets, plan.batch_size, first, count, self.t + 1, self.lr, self.rho, self.eps, _p(losses),
-            ctypes.addressof(hot) if hot is not None else None, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_stateful")
+        head = (self.KIND[self.name], _p(tabs.U), tabs.U.shape[0], _p(tabs.I), tabs.I.shape[0], tabs.D, _p(self.s1_u),
+                _p(self.s2_u), _p(self.s1_i), _p(self.s2_i), _p(self.last_u), _p(self.last_i), _p(plan.tu), _p(plan.tp), _p(plan.tn),
+                _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets, plan.batch_size, first, count, self.t + 1, self.lr, self.rho,
+                self.eps, _p(losses), ctypes.addressof(hot) if hot is not None else None)
+        lag = self.max_lag
+        if lag is None:
+            gap = max(tabs.U.shape[0], tabs.I.shape[0]) / float(max(plan.batch_size, 1))
+            lag = self.MAX_LAG if gap > self.LAG_MIN_GAP else 0
+        if self.name == "Adadelta" and lag > 0:
+            abi.check(abi.lib().wr_bprmf_run_stateful_bounded(*head, lag, ctypes.addressof(self._sweep_pos), _p(ws), ws.numel(),
+                                                              _stream()), "wr_bprmf_run_stateful_bounded")
+        else:
+            abi.check(abi.lib().wr_bprmf_run_stateful(*head, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_stateful")
         self.t += count
         tabs.step_id += count
         return losses
