@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--plan-stream", choices=["side", "inline"], default="side",
                     help="N=1: where the next chunk's plan is built: on a side stream beside the steps (default), or on the "
                          "step stream between the halves of the current chunk (measured slower; kept for the A/B)")
+    ap.add_argument("--no-adam", action="store_true",
+                    help="N=1: skip the Adam figure reported under `extra` (the reference's default optimizer on the same shape)")
     ap.add_argument("--no-chain", action="store_true",
                     help="N=1: two launches per step (user phase, item phase) instead of the chained step launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -358,11 +360,47 @@ def single_gpu(args, local_rank):
                       "untimed_priming_steps": 2 * C if args.overlap else 0},
            "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
            "roofline": roofline}
+    if not args.no_adam:
+        out["extra"] = {"adam": adam_extra(args, hip_ops, U, I, u, p, n, dev)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         out["cpu_baseline_torch"] = cpu_torch_sequence(args, max(4.0, args.cpu_seconds / 2))
     print(json.dumps(out))
     return 0
+
+
+def adam_extra(args, hip_ops, U, I, u, p, n, dev):
+    """The same tables, batch size and data under torch.optim.Adam semantics — what the reference's main.py runs unless
+    --optimizer SGD is passed (src/helpers/BaseRunner.py:36,120-124): every row moves at every step.  Exact lazy rows
+    (hip_ops.LazyOptimizerState: bit-identical to the dense optimizer), plans built in the timed region by the same pipeline.
+    Not the headline: BASELINE.json's metric is quoted on SGD; reported beside it."""
+    import torch
+    B = args.batch
+    warm = 96                       # rows must have been idle for a realistic number of steps before the clock starts
+    steps = max(32, min(args.steps, 128))
+    total = warm + steps + 64       # + one spare chunk: its plan is built beside the last timed steps, as in an epoch
+    u, p, n = synth_triplets(total * B, args.users, args.items, dev, 3408, args.zipf)   # its own stream of batches
+    st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(U, I), "Adam", 1e-3, 0.0)
+    pipe = hip_ops.PipelinedSgd(chunk=64, min_triplets=1)
+    nn = total * B
+    handle = pipe.plan(U, [(I, u[:nn], p[:nn], n[:nn])], B, first_chunk=[warm],
+                       runner=lambda plan, first, count, out: st.run(plan, first, count, out))
+    lw = torch.empty(max(warm, 1), dtype=torch.float32, device=dev)
+    lt = torch.empty(steps, dtype=torch.float32, device=dev)
+    if warm > 0:
+        pipe.run_steps(handle, warm, 0.0, lw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run_steps(handle, steps, 0.0, lt)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st.flush()
+    torch.cuda.synchronize()
+    return {"metric": "BPR training triplets/sec, Adam (lr 1e-3, l2 0)", "value": steps * B / dt, "unit": "triplets/s",
+            "us_per_step": dt / steps * 1e6, "steps": steps, "warmup": warm,
+            "how": "exact lazy rows, catch-up %s; plan builds inside the timed region" %
+                   ("folded into the step kernels' row loads" if st._folds(handle["cur"][1]) else "in a pass of its own"),
+            "loss_last": float(lt[-1])}
 
 
 # --------------------------------------------------------------------------------------------------- N > 1
