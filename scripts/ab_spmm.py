@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import oracle
+from whisprrec_amd import abi
+if os.environ.get("WR_LIB"):
+    abi.LIB_PATH = os.path.abspath(os.environ["WR_LIB"])
 from whisprrec_amd import hip_ops
 from test_hip_config_shapes import ml1m_shaped_pairs
 
@@ -44,7 +47,7 @@ def err(y):
 out = {"graph": {"users": nU, "items": nI, "nnz": int(rp[-1]), "D": D}}
 f_csr = lambda: hip_ops.spmm_csr_chunked(cptr, crow, cold, vald, Xd, Y=Y, acc=acc, partials=partials)
 out["csr_chunked"] = {"us": timeit(f_csr), "err": err(Y), "flops": 2.0 * rp[-1] * D}
-for mx in (64, 128):
+for mx in [int(x) for x in os.environ.get("WR_CHUNKS", "64,128").split(",")]:
     cp2, cr2 = hip_ops.spmm_chunks(rp, max_nnz=mx)
     cp2, cr2 = cp2.to(dev), cr2.to(dev)
     pt2 = torch.empty((cr2.numel(), D), device=dev)

@@ -147,6 +147,13 @@ def test_chunked_spmm_matches_oracle_on_power_law_graph(D, L):
     assert not Y[5].any()
     Y3 = hip_ops.spmm_csr(t(rp), t(col), t(val), t(X))
     assert rel_err(Y3.cpu().numpy(), ref) < TOL
+    # both combine forms (one level: the row's first chunk adds all the others; two: groups of 16 chunk slots first), whatever
+    # spmm_chunks picked for this graph; each reproducible
+    assert crow._wr_levels == (1 if -(-2500 // L) <= hip_ops.SPMM_ONE_LEVEL_MAX_CHUNKS else 2)
+    for lv in (1, 2):
+        Ya = hip_ops.spmm_csr_chunked(cptr.to(dev), crow.to(dev), t(col), t(val), t(X), levels=lv)
+        Yb = hip_ops.spmm_csr_chunked(cptr.to(dev), crow.to(dev), t(col), t(val), t(X), levels=lv)
+        assert torch.equal(Ya, Yb) and rel_err(Ya.cpu().numpy(), ref) < TOL
 
 
 @pytest.mark.gpu

@@ -548,11 +548,14 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
 // Fixed order, no atomics.
 constexpr int kGroup = 16;
 
+#ifndef WR_SPMM_COMBINE_FLY
+#define WR_SPMM_COMBINE_FLY 8
+#endif
 template <int T, int NV, bool FULL>
 __device__ __forceinline__ Row<NV> sum_partials(const float *__restrict__ partials, const int *__restrict__ chunk_row, int row,
                                                 int first, int next, int step, int end, int D, int lane) {
     Row<NV> s = load_row<T, NV, FULL>(partials, first, D, lane);
-    constexpr int kFly = 8;   // partial rows in flight per trip, added in order
+    constexpr int kFly = WR_SPMM_COMBINE_FLY;   // partial rows in flight per trip, added in order
     for (int j = next; j < end && chunk_row[j] == row; j += kFly * step) {
         Row<NV> x[kFly];
         bool ok[kFly];
@@ -588,7 +591,9 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_groups_kernel(int n_chunk
     store_row<T, NV, FULL>(partials, c, D, lane, s);
 }
 
-template <int T, int NV, bool FULL>
+// ONE: no group level — the head adds all the row's chunks itself (eight partial rows in flight).  One launch less per
+// product; right while no row has more than a few dozen chunks (the caller decides: wr_spmm_csr_chunked_levels).
+template <int T, int NV, bool FULL, bool ONE>
 __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, const int *__restrict__ chunk_row,
                                                                const float *__restrict__ partials, int D, float *__restrict__ Y,
                                                                float *__restrict__ acc,
@@ -603,7 +608,8 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, cons
     const int mode = row_mode != nullptr ? (int)row_mode[row] : 0;
     if (mode == 2) return;
     // the head's own partial holds its group's sum; the row's other group leaders sit at the following group boundaries
-    Row<NV> s = sum_partials<T, NV, FULL>(partials, chunk_row, row, c, (c / kGroup + 1) * kGroup, kGroup, n_chunks, D, lane);
+    Row<NV> s = ONE ? sum_partials<T, NV, FULL>(partials, chunk_row, row, c, c + 1, 1, n_chunks, D, lane)
+                    : sum_partials<T, NV, FULL>(partials, chunk_row, row, c, (c / kGroup + 1) * kGroup, kGroup, n_chunks, D, lane);
     if (mode == 1) {
         const Row<NV> y0 = load_row<T, NV, FULL>(Y, row, D, lane);
 #pragma unroll
@@ -976,8 +982,9 @@ int32_t wr_spmm_csr(int64_t n_rows, const int64_t *row_ptr, const int32_t *col, 
 
 static int32_t spmm_chunked_impl(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
                                  const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
-                                 float *partials, const signed char *row_mode, void *stream_) {
+                                 float *partials, const signed char *row_mode, void *stream_, int levels = 2) {
     int32_t rc;
+    WR_REQUIRE(levels == 1 || levels == 2, WR_E_RANGE, "combine levels must be 1 or 2");
     if ((rc = check_table(X, n_rows, D, "X")) != WR_OK) return rc;
     if ((rc = check_table(Y, n_rows, D, "Y")) != WR_OK) return rc;
     WR_REQUIRE(chunk_ptr && chunk_row && col && val && partials, WR_E_NULL, "chunked CSR arrays must not be NULL");
@@ -991,10 +998,15 @@ static int32_t spmm_chunked_impl(int64_t n_rows, int64_t n_chunks, const int64_t
     do {                                                                                                                \
         hipLaunchKernelGGL((spmm_chunk_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,      \
                            chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials, row_mode);                           \
-        hipLaunchKernelGGL((spmm_combine_groups_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream,            \
-                           (int)n_chunks, chunk_row, partials, D);                                                      \
-        hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,    \
-                           chunk_row, partials, D, Y, acc, row_mode);                                                   \
+        if (levels == 1) {                                                                                              \
+            hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_, true>), dim3(grid), dim3(kBlock), 0, stream,         \
+                               (int)n_chunks, chunk_row, partials, D, Y, acc, row_mode);                                \
+        } else {                                                                                                        \
+            hipLaunchKernelGGL((spmm_combine_groups_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream,        \
+                               (int)n_chunks, chunk_row, partials, D);                                                  \
+            hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_, false>), dim3(grid), dim3(kBlock), 0, stream,        \
+                               (int)n_chunks, chunk_row, partials, D, Y, acc, row_mode);                                \
+        }                                                                                                               \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_MC);
 #undef WR_CALL_MC
@@ -1014,6 +1026,13 @@ int32_t wr_spmm_csr_chunked_modes(int64_t n_rows, int64_t n_chunks, const int64_
     WR_REQUIRE(row_mode != nullptr, WR_E_NULL, "row_mode is NULL");
     return spmm_chunked_impl(n_rows, n_chunks, chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials,
                              reinterpret_cast<const signed char *>(row_mode), stream_);
+}
+
+int32_t wr_spmm_csr_chunked_levels(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                                   const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
+                                   float *partials, const int8_t *row_mode, int32_t levels, void *stream_) {
+    return spmm_chunked_impl(n_rows, n_chunks, chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials,
+                             reinterpret_cast<const signed char *>(row_mode), stream_, (int)levels);
 }
 
 int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream_) {

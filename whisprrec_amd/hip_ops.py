@@ -1512,9 +1512,17 @@ def spmm_csr(row_ptr, col, val, X, Y=None, acc=None):
     return Y
 
 
-def spmm_chunks(row_ptr, max_nnz=32):
+SPMM_CHUNK_NNZ = int(os.environ.get("WR_SPMM_CHUNK", "96"))            # non-zeros per chunk of the load-balanced CSR product
+SPMM_ONE_LEVEL_MAX_CHUNKS = int(os.environ.get("WR_SPMM_ONE_LEVEL_MAX", "48"))   # one combine level while no row has more chunks
+
+
+def spmm_chunks(row_ptr, max_nnz=SPMM_CHUNK_NNZ):
     """Cut CSR rows into chunks of at most `max_nnz` non-zeros (host, once per graph).  Returns (chunk_ptr int64
-    [n_chunks+1], chunk_row int32 [n_chunks]) as CPU tensors; every row gets at least one chunk."""
+    [n_chunks+1], chunk_row int32 [n_chunks]) as CPU tensors; every row gets at least one chunk.  chunk_row carries the
+    number of combine levels spmm_csr_chunked should use (``_wr_levels``: 1 while no row has more than
+    SPMM_ONE_LEVEL_MAX_CHUNKS chunks).  MI355X, ml-1m-shaped graph (1.41 M non-zeros, hub rows of 3.4 K), us per product
+    (scripts/ab_spmm.py), two levels / one level: 32 per chunk 39.3 / 41.2; 64: 37.6 / 34.8; 96: 34.9 / 31.5; 128: 35.8 /
+    32.4; 192: 44 / 41; 256: 48 / 45."""
     import numpy as np
     rp = row_ptr.cpu().numpy() if isinstance(row_ptr, torch.Tensor) else np.asarray(row_ptr)
     deg = np.diff(rp)
@@ -1524,10 +1532,28 @@ def spmm_chunks(row_ptr, max_nnz=32):
     within = np.arange(chunk_row.size) - np.repeat(first, per)
     start = rp[:-1][chunk_row] + within * max_nnz
     chunk_ptr = np.concatenate([start, rp[-1:]]).astype(np.int64)
-    return torch.from_numpy(chunk_ptr), torch.from_numpy(chunk_row)
+    crow = torch.from_numpy(chunk_row)
+    crow._wr_levels = 1 if int(per.max(initial=1)) <= SPMM_ONE_LEVEL_MAX_CHUNKS else 2
+    return torch.from_numpy(chunk_ptr), crow
 
 
-def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partials=None):
+def spmm_levels_of(chunk_row):
+    """combine levels for a chunk_row tensor (the attribute set by spmm_chunks does not survive .to(device): recomputed once
+    per tensor from the longest run of equal rows)"""
+    lv = getattr(chunk_row, "_wr_levels", None)
+    if lv is None:
+        cr = chunk_row
+        if cr.numel() <= 1:
+            lv = 1
+        else:
+            change = torch.nonzero(cr[1:] != cr[:-1]).flatten() + 1
+            edges = torch.cat([change.new_zeros(1), change, change.new_full((1,), cr.numel())])
+            lv = 1 if int((edges[1:] - edges[:-1]).max()) <= SPMM_ONE_LEVEL_MAX_CHUNKS else 2
+        chunk_row._wr_levels = lv
+    return lv
+
+
+def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partials=None, levels=None):
     _req(chunk_ptr, torch.int64, "chunk_ptr", 1)
     _req(chunk_row, torch.int32, "chunk_row", 1)
     _req(col, torch.int32, "col", 1)
@@ -1537,9 +1563,10 @@ def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partia
         Y = torch.empty_like(X)
     if partials is None:
         partials = torch.empty((chunk_row.numel(), X.shape[1]), dtype=torch.float32, device=X.device)
-    abi.check(abi.lib().wr_spmm_csr_chunked(X.shape[0], chunk_row.numel(), _p(chunk_ptr), _p(chunk_row), _p(col), _p(val),
-                                            _p(X), X.shape[1], _p(Y), _p(acc), _p(partials), _stream()),
-              "wr_spmm_csr_chunked")
+    abi.check(abi.lib().wr_spmm_csr_chunked_levels(X.shape[0], chunk_row.numel(), _p(chunk_ptr), _p(chunk_row), _p(col),
+                                                   _p(val), _p(X), X.shape[1], _p(Y), _p(acc), _p(partials), None,
+                                                   spmm_levels_of(chunk_row) if levels is None else int(levels), _stream()),
+              "wr_spmm_csr_chunked_levels")
     return Y
 
 

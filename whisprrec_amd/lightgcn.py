@@ -154,7 +154,7 @@ def make_lightgcn(general_model_cls):
             self.item_embedding = nn.Embedding(self.n_items, self.emb_size)
             rp, col, val = build_norm_adj_csr(self.n_users, self.n_items, corpus.train_clicked_set)
             # plain attributes like the reference's norm_adj (not buffers: absent from state_dict, LightGCN.py:49-51)
-            cptr, crow = hip_ops.spmm_chunks(rp)   # rows cut into <= 32-non-zero chunks: hubs do not serialise on one team
+            cptr, crow = hip_ops.spmm_chunks(rp)   # rows cut into chunks of <= 96 non-zeros: hubs do not serialise on one team
             self._csr_host = (cptr, crow, torch.from_numpy(col), torch.from_numpy(val))
             self._csr_full = (rp, col, val)
             self._use_mfma = bool(getattr(args, "spmm_mfma", SPMM_MFMA_DEFAULT)) and self.emb_size in (32, 64, 96, 128)
@@ -173,6 +173,7 @@ def make_lightgcn(general_model_cls):
             dev = self.user_embedding.weight.device
             if self._csr_dev is None or self._csr_dev[0].device != dev:
                 self._csr_dev = tuple(t.to(dev) for t in self._csr_host)
+                self._csr_dev[1]._wr_levels = self._csr_host[1]._wr_levels      # combine levels of the product (spmm_chunks)
             return self._csr_dev
 
         def _propagate(self, E0):

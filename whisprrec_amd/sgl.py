@@ -101,8 +101,10 @@ class CsrGraph:
     @staticmethod
     def _upload(row_ptr, col, val, device):
         cptr, crow = hip_ops.spmm_chunks(row_ptr)
-        return tuple(t.to(device) for t in (cptr, crow, torch.from_numpy(np.ascontiguousarray(col)),
-                                            torch.from_numpy(np.ascontiguousarray(val))))
+        out = tuple(t.to(device) for t in (cptr, crow, torch.from_numpy(np.ascontiguousarray(col)),
+                                           torch.from_numpy(np.ascontiguousarray(val))))
+        out[1]._wr_levels = crow._wr_levels                                     # combine levels of the product (spmm_chunks)
+        return out
 
     def propagate(self, E0, layers, transpose=False):
         """mean over l = 0..layers of A^l E0 (SGL.forward, SGL.py:148-164), or of (A^T)^l E0"""
