@@ -101,58 +101,86 @@ __global__ __launch_bounds__(kBlock) void plan_unpack_item(const Key *__restrict
 constexpr int kSmallBatch = 4096;
 constexpr int kSmallThreads = 1024;
 
-__device__ __forceinline__ void bitonic_sort_lds(unsigned long long *__restrict__ a, int n_pow2) {
+// Two compare-exchange stages per pass: a thread takes the four keys base + {0, s, 2s, 3s} (bits s and 2s of base clear),
+// applies the stage of stride 2s to (0, 2), (1, 3) and the stage of stride s to (0, 1), (2, 3) in registers, and writes them
+// back — every key moves through LDS once per TWO stages and the workgroup meets at half as many barriers (the kernel is
+// bound by the LDS pipe and its barriers: 144 stages for the 2,048 + 4,096 keys of a default batch).
+template <typename K>
+__device__ __forceinline__ void bitonic_sort_lds(K *__restrict__ a, int n_pow2) {
+    auto cx = [](K &x, K &y, bool up) {
+        if ((x > y) == up) { const K t = x; x = y; y = t; }
+    };
     for (int size = 2; size <= n_pow2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        int stride = size >> 1;
+        for (; stride >= 2; stride >>= 2) {               // strides (stride, stride / 2) together
+            const int s1 = stride >> 1;
+            for (int q = threadIdx.x; q < n_pow2 / 4; q += kSmallThreads) {
+                const int base = ((q & ~(s1 - 1)) << 2) | (q & (s1 - 1));
+                const bool up = (base & size) == 0;
+                K k0 = a[base], k1 = a[base + s1], k2 = a[base + 2 * s1], k3 = a[base + 3 * s1];
+                cx(k0, k2, up); cx(k1, k3, up);
+                cx(k0, k1, up); cx(k2, k3, up);
+                a[base] = k0; a[base + s1] = k1; a[base + 2 * s1] = k2; a[base + 3 * s1] = k3;
+            }
+            __syncthreads();
+        }
+        if (stride == 1) {                                 // an odd number of stages: the last one alone
             for (int t = threadIdx.x; t < n_pow2 / 2; t += kSmallThreads) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
+                const int lo = 2 * t;
                 const bool up = (lo & size) == 0;
-                const unsigned long long x = a[lo], y = a[hi];
-                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+                K x = a[lo], y = a[lo + 1];
+                if ((x > y) == up) { a[lo] = y; a[lo + 1] = x; }
             }
             __syncthreads();
         }
     }
 }
 
-template <typename Idx>
+// K: composite type.  64-bit: (row << 32) | (side << 31) | position.  32-bit, when the row bits, the side bit and the position
+// bits of a batch fit 31 bits together (ml-scale tables at the default batch: 13 + 1 + 11): (row << shift) | (side << (shift
+// - 1)) | position — same order, half the LDS traffic per compare-exchange stage (the kernel is bound by the LDS pipe:
+// 144 stages for 2,048 + 4,096 keys).  shift_u / shift_i: position of the row inside the user / item composites.
+template <typename Idx, typename K>
 __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(const Idx *__restrict__ u, const Idx *__restrict__ p,
                                                                     const Idx *__restrict__ nn, int64_t n, int64_t B,
                                                                     int64_t n_users, int64_t n_items, int *__restrict__ tu,
                                                                     int *__restrict__ tp, int *__restrict__ tn,
                                                                     int *__restrict__ torig, int *__restrict__ oc_item,
-                                                                    int *__restrict__ oc_src, int *__restrict__ err) {
-    extern __shared__ unsigned long long keys[];         // 2 * P composites | sp[P] | sn[P] (ints)
+                                                                    int *__restrict__ oc_src, int *__restrict__ err,
+                                                                    int shift_u, int shift_i) {
+    extern __shared__ unsigned long long lds_raw[];       // 2 * P composites | sp[P] | sn[P] (ints)
+    K *keys = reinterpret_cast<K *>(lds_raw);
     const int64_t b = blockIdx.x, lo = b * B;
     const int Bb = (int)((lo + B <= n) ? B : (n - lo));
     int P = 1;
     while (P < Bb) P <<= 1;
     int *sp = reinterpret_cast<int *>(keys + 2 * P), *sn = sp + P;
+    const K pad = ~(K)0;
+    const K pos_mask_u = (((K)1) << shift_u) - 1, pos_mask_i = (((K)1) << (shift_i - 1)) - 1;
     for (int i = threadIdx.x; i < P; i += kSmallThreads) {
-        unsigned long long k = ~0ull;
+        K k = pad;
         if (i < Bb) {
             int64_t uu = (int64_t)u[lo + i];
             if (uu < 0 || uu >= n_users) {
                 if (err) *err = 1;
                 uu = 0;
             }
-            k = ((unsigned long long)uu << 32) | (unsigned long long)(uint32_t)i;
+            k = ((K)uu << shift_u) | (K)(uint32_t)i;
         }
         keys[i] = k;
     }
     __syncthreads();
-    bitonic_sort_lds(keys, P);
+    bitonic_sort_lds<K>(keys, P);
     for (int t = threadIdx.x; t < Bb; t += kSmallThreads) {
-        const unsigned long long k = keys[t];
-        const int o = (int)(uint32_t)k;
+        const K k = keys[t];
+        const int o = (int)(uint32_t)(k & pos_mask_u);
         int64_t pi = (int64_t)p[lo + o], ni = (int64_t)nn[lo + o];
         if (pi < 0 || pi >= n_items || ni < 0 || ni >= n_items) {
             if (err) *err = 1;
             pi = (pi < 0 || pi >= n_items) ? 0 : pi;
             ni = (ni < 0 || ni >= n_items) ? 0 : ni;
         }
-        tu[lo + t] = (int)(k >> 32);
+        tu[lo + t] = (int)(k >> shift_u);
         if (torig) torig[lo + t] = (int)(lo + o);
         sp[t] = (int)pi;
         sn[t] = (int)ni;
@@ -160,21 +188,20 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(const Idx *__
     __syncthreads();
     const int P2 = 2 * P;
     for (int i = threadIdx.x; i < P2; i += kSmallThreads) {
-        unsigned long long k = ~0ull;
-        if (i < Bb) k = ((unsigned long long)(uint32_t)sp[i] << 32) | (unsigned long long)(uint32_t)i;
-        else if (i >= P && i - P < Bb) k = ((unsigned long long)(uint32_t)sn[i - P] << 32) | (1ull << 31) | (unsigned long long)(uint32_t)(i - P);
+        K k = pad;
+        if (i < Bb) k = ((K)(uint32_t)sp[i] << shift_i) | (K)(uint32_t)i;
+        else if (i >= P && i - P < Bb) k = ((K)(uint32_t)sn[i - P] << shift_i) | (((K)1) << (shift_i - 1)) | (K)(uint32_t)(i - P);
         keys[i] = k;
     }
     __syncthreads();
-    bitonic_sort_lds(keys, P2);
+    bitonic_sort_lds<K>(keys, P2);
     for (int q = threadIdx.x; q < 2 * Bb; q += kSmallThreads) {
-        const unsigned long long k = keys[q];
-        const int item = (int)(k >> 32);
-        const uint32_t low = (uint32_t)k;
-        const int side = (int)(low >> 31), t = (int)(low & 0x7fffffffu);
+        const K k = keys[q];
+        const int item = (int)(k >> shift_i);
+        const int side = (int)((k >> (shift_i - 1)) & 1), t = (int)(uint32_t)(k & pos_mask_i);
         oc_item[2 * lo + q] = item;
         oc_src[2 * lo + q] = (t << 1) | side;
-        const bool shared = (q > 0 && (int)(keys[q - 1] >> 32) == item) || (q + 1 < 2 * Bb && (int)(keys[q + 1] >> 32) == item);
+        const bool shared = (q > 0 && (int)(keys[q - 1] >> shift_i) == item) || (q + 1 < 2 * Bb && (int)(keys[q + 1] >> shift_i) == item);
         if (shared) {
             if (side) sn[t] |= (int)0x80000000; else sp[t] |= (int)0x80000000;   // one writer per (triplet, side)
         }
@@ -185,7 +212,6 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(const Idx *__
         tn[lo + t] = sn[t];
     }
 }
-
 template <typename Idx>
 static int32_t plan_build_small(const Idx *u, const Idx *p, const Idx *nn, int64_t n, int64_t B, int64_t n_users,
                                 int64_t n_items, int32_t *tu, int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item,
@@ -197,15 +223,24 @@ static int32_t plan_build_small(const Idx *u, const Idx *p, const Idx *nn, int64
     WR_REQUIRE(n_users > 0 && n_users < (int64_t(1) << 31) && n_items > 0 && n_items < (int64_t(1) << 31), WR_E_SHAPE,
                "small plan builder: table sizes out of range");
     const int64_t nb = (n + B - 1) / B;
-    int P = 1;
-    while (P < (B < n ? B : n)) P <<= 1;
-    const size_t lds = (size_t)2 * P * 8 + (size_t)2 * P * 4;
-    if (lds > 64 * 1024) {
-        WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<Idx>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int P = 1, pos_bits = 0;
+    while (P < (B < n ? B : n)) { P <<= 1; ++pos_bits; }
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    // 32-bit composites when rows + side + positions fit 31 bits (the all-ones padding key stays above every real one)
+    const bool narrow = (int)bits_for(n_users) + pos_bits <= 31 && (int)bits_for(n_items) + 1 + pos_bits <= 31;
+    if (narrow) {
+        const size_t lds = (size_t)2 * P * 4 + (size_t)2 * P * 4 + 8;
+        hipLaunchKernelGGL((plan_small_kernel<Idx, uint32_t>), dim3((unsigned)nb), dim3(kSmallThreads), lds, stream, u, p, nn, n, B,
+                           n_users, n_items, tu, tp, tn, torig, oc_item, oc_src, err_flag, pos_bits, pos_bits + 1);
+    } else {
+        const size_t lds = (size_t)2 * P * 8 + (size_t)2 * P * 4;
+        if (lds > 64 * 1024) {
+            WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<Idx, unsigned long long>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        hipLaunchKernelGGL((plan_small_kernel<Idx, unsigned long long>), dim3((unsigned)nb), dim3(kSmallThreads), lds, stream, u, p,
+                           nn, n, B, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src, err_flag, 32, 32);
     }
-    hipLaunchKernelGGL((plan_small_kernel<Idx>), dim3((unsigned)nb), dim3(kSmallThreads), lds, reinterpret_cast<hipStream_t>(stream_),
-                       u, p, nn, n, B, n_users, n_items, tu, tp, tn, torig, oc_item, oc_src, err_flag);
     WR_LAUNCH_CHECK("plan_small_kernel");
     return WR_OK;
 }
