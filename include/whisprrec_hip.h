@@ -558,10 +558,14 @@ int32_t wr_spmm_csr_chunked_modes(int64_t n_rows, int64_t n_chunks, const int64_
  * first added inside aligned groups of 16 chunk slots, then the group leaders (a hub row with hundreds of chunks is not one
  * team's chain of hundreds of dependent adds); 1 = the row's first chunk adds all the others itself — one launch less,
  * right while no row has more than a few dozen chunks.  The summation order (hence the rounding) differs between the two;
- * each is fixed and reproducible. */
+ * each is fixed and reproducible.
+ * acc (may be NULL) is the running layer sum: acc[r] = (base[r] + Y[r]) * acc_scale with base = acc, or = X when
+ * acc_from_x != 0 (first layer: no copy of the input into acc beforehand); acc_scale = 1 except for the last layer's
+ * 1 / (layers + 1) (LightGCN.py:142-143: mean over the layers). */
 int32_t wr_spmm_csr_chunked_levels(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
                                    const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
-                                   float *partials, const int8_t *row_mode, int32_t levels, void *stream);
+                                   float *partials, const int8_t *row_mode, int32_t levels, int32_t acc_from_x,
+                                   float acc_scale, void *stream);
 /* out = alpha * x  /  y += alpha * x  over numel floats (layer-mean scaling, gradient accumulation) */
 int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream);
 /* EmbLoss pieces (src/utils/loss.py:94-98): sq[0..2] = sum of squares of the gathered U[u], I[p], I[n] blocks */

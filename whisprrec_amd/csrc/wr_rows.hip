@@ -456,6 +456,21 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(int64_t n_rows, const 
 // on the host).  One team per chunk, four neighbour rows requested per round.  A row with a single chunk is written
 // directly; the chunks of a longer row go to `partials` and are summed in chunk order by the second kernel, so the
 // result is reproducible and a power-law hub (thousands of neighbours) no longer serialises on one team.
+// The running layer sum of LightGCN's propagation (acc = E0 + A E0 + A^2 E0 + ..., then the mean): acc[row] = (base[row] +
+// y[row]) * scale, base = acc itself or — first layer — the product's input X (saves the copy of E0 into acc), scale = 1
+// or — last layer — 1 / (layers + 1) (saves the scaling pass).  The same operations in the same order as copy / += / scale.
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ void acc_update(float *__restrict__ acc, const float *__restrict__ acc_src, float acc_scale, int row,
+                                           int D, int lane, const Row<NV> &y) {
+    Row<NV> a = load_row<T, NV, FULL>(acc_src != nullptr ? acc_src : acc, row, D, lane);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        a.v[q].x = (a.v[q].x + y.v[q].x) * acc_scale; a.v[q].y = (a.v[q].y + y.v[q].y) * acc_scale;
+        a.v[q].z = (a.v[q].z + y.v[q].z) * acc_scale; a.v[q].w = (a.v[q].w + y.v[q].w) * acc_scale;
+    }
+    store_row<T, NV, FULL>(acc, row, D, lane, a);
+}
+
 #ifndef WR_SPMM_FLY
 #define WR_SPMM_FLY 8
 #endif
@@ -469,7 +484,8 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
                                                              const float *__restrict__ val, const float *__restrict__ X, int D,
                                                              float *__restrict__ Y, float *__restrict__ acc,
                                                              float *__restrict__ partials,
-                                                             const signed char *__restrict__ row_mode) {
+                                                             const signed char *__restrict__ row_mode,
+                                                             const float *__restrict__ acc_src, float acc_scale) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int c = blockIdx.x * TEAMS + threadIdx.x / T;
@@ -531,14 +547,7 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
         }
     }
     store_row<T, NV, FULL>(Y, row, D, lane, s);
-    if (acc != nullptr) {
-        Row<NV> a = load_row<T, NV, FULL>(acc, row, D, lane);
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            a.v[q].x += s.v[q].x; a.v[q].y += s.v[q].y; a.v[q].z += s.v[q].z; a.v[q].w += s.v[q].w;
-        }
-        store_row<T, NV, FULL>(acc, row, D, lane, a);
-    }
+    if (acc != nullptr) acc_update<T, NV, FULL>(acc, acc_src, acc_scale, row, D, lane, s);
 }
 
 // Rows cut into several chunks are put together in two levels, so that a hub row with hundreds of chunks is not one team's
@@ -597,7 +606,8 @@ template <int T, int NV, bool FULL, bool ONE>
 __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, const int *__restrict__ chunk_row,
                                                                const float *__restrict__ partials, int D, float *__restrict__ Y,
                                                                float *__restrict__ acc,
-                                                               const signed char *__restrict__ row_mode) {
+                                                               const signed char *__restrict__ row_mode,
+                                                               const float *__restrict__ acc_src, float acc_scale) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int c = blockIdx.x * TEAMS + threadIdx.x / T;
@@ -618,14 +628,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(int n_chunks, cons
         }
     }
     store_row<T, NV, FULL>(Y, row, D, lane, s);
-    if (acc != nullptr) {
-        Row<NV> a = load_row<T, NV, FULL>(acc, row, D, lane);
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            a.v[q].x += s.v[q].x; a.v[q].y += s.v[q].y; a.v[q].z += s.v[q].z; a.v[q].w += s.v[q].w;
-        }
-        store_row<T, NV, FULL>(acc, row, D, lane, a);
-    }
+    if (acc != nullptr) acc_update<T, NV, FULL>(acc, acc_src, acc_scale, row, D, lane, s);
 }
 
 // ------------------------------------------------------------------------------------------------ EmbLoss
@@ -982,7 +985,8 @@ int32_t wr_spmm_csr(int64_t n_rows, const int64_t *row_ptr, const int32_t *col, 
 
 static int32_t spmm_chunked_impl(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
                                  const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
-                                 float *partials, const signed char *row_mode, void *stream_, int levels = 2) {
+                                 float *partials, const signed char *row_mode, void *stream_, int levels = 2,
+                                 bool acc_from_x = false, float acc_scale = 1.0f) {
     int32_t rc;
     WR_REQUIRE(levels == 1 || levels == 2, WR_E_RANGE, "combine levels must be 1 or 2");
     if ((rc = check_table(X, n_rows, D, "X")) != WR_OK) return rc;
@@ -991,21 +995,23 @@ static int32_t spmm_chunked_impl(int64_t n_rows, int64_t n_chunks, const int64_t
     WR_REQUIRE(n_chunks >= n_rows && n_chunks < (int64_t(1) << 31), WR_E_SHAPE, "every row needs at least one chunk");
     WR_REQUIRE(X != Y, WR_E_SHAPE, "spmm: X and Y must not alias");
     WR_REQUIRE(aligned16(partials) && (acc == nullptr || aligned16(acc)), WR_E_ALIGN, "partials/acc not 16-byte aligned");
+    WR_REQUIRE(!acc_from_x || (acc != nullptr && acc != X), WR_E_SHAPE, "acc_from_x needs an acc buffer other than X");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int tpb = teams_per_block_for(D);
     const unsigned grid = (unsigned)((n_chunks + tpb - 1) / tpb);
+    const float *acc_src = acc_from_x ? X : nullptr;
 #define WR_CALL_MC(T_, NV_, FULL_)                                                                                      \
     do {                                                                                                                \
         hipLaunchKernelGGL((spmm_chunk_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,      \
-                           chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials, row_mode);                           \
+                           chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials, row_mode, acc_src, acc_scale);       \
         if (levels == 1) {                                                                                              \
             hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_, true>), dim3(grid), dim3(kBlock), 0, stream,         \
-                               (int)n_chunks, chunk_row, partials, D, Y, acc, row_mode);                                \
+                               (int)n_chunks, chunk_row, partials, D, Y, acc, row_mode, acc_src, acc_scale);            \
         } else {                                                                                                        \
             hipLaunchKernelGGL((spmm_combine_groups_kernel<T_, NV_, FULL_>), dim3(grid), dim3(kBlock), 0, stream,        \
                                (int)n_chunks, chunk_row, partials, D);                                                  \
             hipLaunchKernelGGL((spmm_combine_kernel<T_, NV_, FULL_, false>), dim3(grid), dim3(kBlock), 0, stream,        \
-                               (int)n_chunks, chunk_row, partials, D, Y, acc, row_mode);                                \
+                               (int)n_chunks, chunk_row, partials, D, Y, acc, row_mode, acc_src, acc_scale);            \
         }                                                                                                               \
     } while (0)
     WR_DISPATCH_D(D, WR_CALL_MC);
@@ -1030,9 +1036,10 @@ int32_t wr_spmm_csr_chunked_modes(int64_t n_rows, int64_t n_chunks, const int64_
 
 int32_t wr_spmm_csr_chunked_levels(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
                                    const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
-                                   float *partials, const int8_t *row_mode, int32_t levels, void *stream_) {
+                                   float *partials, const int8_t *row_mode, int32_t levels, int32_t acc_from_x,
+                                   float acc_scale, void *stream_) {
     return spmm_chunked_impl(n_rows, n_chunks, chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials,
-                             reinterpret_cast<const signed char *>(row_mode), stream_, (int)levels);
+                             reinterpret_cast<const signed char *>(row_mode), stream_, (int)levels, acc_from_x != 0, acc_scale);
 }
 
 int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream_) {

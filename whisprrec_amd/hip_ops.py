@@ -1553,7 +1553,10 @@ def spmm_levels_of(chunk_row):
     return lv
 
 
-def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partials=None, levels=None):
+def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partials=None, levels=None, acc_from_x=False,
+                     acc_scale=1.0):
+    """Y = A X (load-balanced CSR product); acc: running layer sum, acc = (acc + Y) * acc_scale, or (X + Y) * acc_scale with
+    acc_from_x (first layer of a propagation: acc need not be initialised)."""
     _req(chunk_ptr, torch.int64, "chunk_ptr", 1)
     _req(chunk_row, torch.int32, "chunk_row", 1)
     _req(col, torch.int32, "col", 1)
@@ -1565,7 +1568,8 @@ def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partia
         partials = torch.empty((chunk_row.numel(), X.shape[1]), dtype=torch.float32, device=X.device)
     abi.check(abi.lib().wr_spmm_csr_chunked_levels(X.shape[0], chunk_row.numel(), _p(chunk_ptr), _p(chunk_row), _p(col),
                                                    _p(val), _p(X), X.shape[1], _p(Y), _p(acc), _p(partials), None,
-                                                   spmm_levels_of(chunk_row) if levels is None else int(levels), _stream()),
+                                                   spmm_levels_of(chunk_row) if levels is None else int(levels),
+                                                   1 if acc_from_x else 0, float(acc_scale), _stream()),
               "wr_spmm_csr_chunked_levels")
     return Y
 

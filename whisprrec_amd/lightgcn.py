@@ -179,9 +179,9 @@ def make_lightgcn(general_model_cls):
         def _propagate(self, E0):
             """mean over layers of A^l E0, l = 0..L (LightGCN.py:134-143)."""
             cptr, crow, col, val = self._csr()
-            acc = E0.clone()
             cur = E0
             if self._use_mfma and E0.is_cuda:
+                acc = E0.clone()
                 if self._hybrid is None or self._hybrid.device != E0.device:
                     self._hybrid = hip_ops.HybridSpmm(*self._csr_full, self.n_users, self.n_items, E0.device)
                 if self._hybrid.enabled:
@@ -192,11 +192,15 @@ def make_lightgcn(general_model_cls):
                     return out
             if self._partials is None or self._partials.device != E0.device:
                 self._partials = torch.empty((crow.numel(), E0.shape[1]), dtype=torch.float32, device=E0.device)
-            for _ in range(self.gcn_layers):
-                cur = hip_ops.spmm_csr_chunked(cptr, crow, col, val, cur, acc=acc, partials=self._partials)
-            out = torch.empty_like(acc)
-            hip_ops.axpy(out, acc, 1.0 / (self.gcn_layers + 1), overwrite=True)
-            return out
+            if self.gcn_layers == 0:
+                return E0.clone()
+            # the layer sum lives in the products themselves: the first one starts it from its input (no copy of E0), the
+            # last one scales it to the mean (no scaling pass) — two graph nodes fewer per propagation
+            acc = torch.empty_like(E0)
+            for l in range(self.gcn_layers):
+                cur = hip_ops.spmm_csr_chunked(cptr, crow, col, val, cur, acc=acc, partials=self._partials, acc_from_x=l == 0,
+                                               acc_scale=1.0 / (self.gcn_layers + 1) if l == self.gcn_layers - 1 else 1.0)
+            return acc
 
         def forward(self):
             E0 = torch.cat([self.user_embedding.weight.data, self.item_embedding.weight.data], dim=0)

@@ -109,16 +109,17 @@ class CsrGraph:
     def propagate(self, E0, layers, transpose=False):
         """mean over l = 0..layers of A^l E0 (SGL.forward, SGL.py:148-164), or of (A^T)^l E0"""
         cptr, crow, col, val = self.bwd if transpose else self.fwd
-        acc = E0.clone()
+        if layers == 0:
+            return E0.clone()
         cur = E0
         need = (crow.numel(), E0.shape[1])
         if self._partials is None or tuple(self._partials.shape) != need or self._partials.device != E0.device:
             self._partials = torch.empty(need, dtype=torch.float32, device=E0.device)
-        for _ in range(layers):
-            cur = hip_ops.spmm_csr_chunked(cptr, crow, col, val, cur, acc=acc, partials=self._partials)
-        out = torch.empty_like(acc)
-        hip_ops.axpy(out, acc, 1.0 / (layers + 1), overwrite=True)
-        return out
+        acc = torch.empty_like(E0)       # started by the first product from its input, scaled to the mean by the last one
+        for l in range(layers):
+            cur = hip_ops.spmm_csr_chunked(cptr, crow, col, val, cur, acc=acc, partials=self._partials, acc_from_x=l == 0,
+                                           acc_scale=1.0 / (layers + 1) if l == layers - 1 else 1.0)
+        return acc
 
 
 class _IdentityView:
