@@ -160,6 +160,8 @@ def test_pipeline_picks_the_form_per_plan_and_results_do_not_depend_on_it(ops, c
         pipe.run(h, 0, lr, losses)
         torch.cuda.synchronize()
         h["segs"][0]["tabs"].check_chain()
+        if chain and case == "hot_rows":
+            assert h["chain"] is False          # after the first plan with hot rows the following plans skip the marks
         res.append((Ud, Id, losses))
         used.append(dict(pipe.stats))
     assert used[1]["chain_calls"] == 0 and used[1]["plain_calls"] == 3

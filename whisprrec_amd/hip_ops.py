@@ -1156,6 +1156,8 @@ class PipelinedSgd:
                     # complete yet, the source columns have the same rows in another order
                     src = (h["prep"].users, h["prep"].items) if h["prep"] is not None else (h["u"], h["p"])
                     h["map"] = self.ops.BucketMap(src[0], src[1], h["n_users"], h["n_items"], h["B"])
+        if h["chain"] and plan.hot is not None:
+            h["chain"] = False      # skewed ids stay skewed: the following plans skip the marks (hot batches take the two launches)
         if h["chain"] and plan.hot is None and plan.overlap is not None:
             # ids that defer most runs (many shared item rows without any hot one): the marks are wasted plan work
             dcn = plan.overlap["def_count_np"]
