@@ -589,6 +589,9 @@ class OverlapEvents:
         self.n = n
 
 
+_CHAIN_SYNC = {}      # (device, stream) -> [int32 tensors]: hand-off counters of the chained step launches (BprmfTables._chain_sync)
+
+
 class BprmfTables:
     """The two embedding tables plus the scratch the step kernels need.  Tables are plain fp32 tensors
     (row-major [n_rows, D]) that stay valid PyTorch tensors between steps."""
@@ -714,19 +717,26 @@ class BprmfTables:
                                 # them means an allocation in the middle of a step stream
 
     def _chain_sync(self, count):
-        if not hasattr(self, "_syncs"):
-            self._syncs = []
-        if not self._syncs or self._syncs[-1].numel() < int(abi.lib().wr_bprmf_chain_sync_words(count)):
+        """hand-off counters + sticky timeout word of the chained launches: ONE buffer per (device, stream) shared by every
+        tables object (the stratified schedule makes one per segment) — calls on a stream are ordered, each zeroes the
+        counters it uses"""
+        key = (str(self.dev), torch.cuda.current_stream(self.dev).cuda_stream)
+        bufs = _CHAIN_SYNC.setdefault(key, [])
+        if not bufs or bufs[-1].numel() < int(abi.lib().wr_bprmf_chain_sync_words(count)):
             words = int(abi.lib().wr_bprmf_chain_sync_words(max(count, self.CHAIN_SYNC_STEPS)))
-            self._syncs.append(torch.zeros(words, dtype=torch.int32, device=self.dev))   # older ones stay for check_chain
-        return self._syncs[-1]
+            bufs.append(torch.zeros(words, dtype=torch.int32, device=self.dev))      # older ones stay for check_chain
+        return bufs[-1]
 
     def check_chain(self):
-        """raises if a bounded wait inside a chained step launch ever expired on these tables (synchronises; call it where
+        """raises if a bounded wait inside a chained step launch ever expired on this device (synchronises; call it where
         the caller waits for the device anyway: end of an epoch, end of a benchmark)"""
-        for buf in getattr(self, "_syncs", []):
-            if int(buf[-4].item()) != 0:
-                raise abi.WhisprRecHipError("chained step launch: a wait for the item tiles expired — the tables are not valid")
+        for (dev, _), bufs in _CHAIN_SYNC.items():
+            if dev != str(self.dev):
+                continue
+            for buf in bufs:
+                if int(buf[-4].item()) != 0:
+                    raise abi.WhisprRecHipError("chained step launch: a wait for the item tiles expired — the tables are "
+                                                "not valid")
 
     def run_sgd_chain(self, plan, first, count, lr, losses=None, phase_events=None, ws=None, def_limit=None):
         """`count` consecutive steps like run_sgd, one launch per step (wr_bprmf_run_sgd_chain): the item phase of step k-1
