@@ -73,7 +73,7 @@ def side_stream(device):
     other (seen in a kernel trace: plan stream and main stream both on queue 4, every plan build waiting for the step
     kernels to drain).  A high-priority stream has its own queue, and the small kernels it carries should not wait behind
     the whole-GPU step kernels anyway."""
-    return torch.cuda.Stream(device=device, priority=int(os.environ.get("WR_SIDE_PRIORITY", "-1")))
+    return torch.cuda.Stream(device=device, priority=-1)
 
 
 def device_info():
@@ -1524,8 +1524,8 @@ def spmm_csr(row_ptr, col, val, X, Y=None, acc=None):
     return Y
 
 
-SPMM_CHUNK_NNZ = int(os.environ.get("WR_SPMM_CHUNK", "96"))            # non-zeros per chunk of the load-balanced CSR product
-SPMM_ONE_LEVEL_MAX_CHUNKS = int(os.environ.get("WR_SPMM_ONE_LEVEL_MAX", "48"))   # one combine level while no row has more chunks
+SPMM_CHUNK_NNZ = 96              # non-zeros per chunk of the load-balanced CSR product
+SPMM_ONE_LEVEL_MAX_CHUNKS = 48   # one combine level while no row has more chunks than this
 
 
 def spmm_chunks(row_ptr, max_nnz=SPMM_CHUNK_NNZ):

@@ -21,7 +21,6 @@ a side stream as soon as its last step is enqueued, while the next part trains; 
 its first step of the next stratum.  With 2 parts every transfer (one half of a block) runs beside the compute of a half.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -323,8 +322,7 @@ def bench_run(args, rank, world, dev):
     S = stratum_steps(args.interactions, world, B)
     from .hip_ops import PipelinedSgd
     chunk = args.chunk if args.chunk > 0 else max(1, min(64, K))
-    model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts,
-                          local=PipelinedSgd(chunk, min_triplets=1, chain=os.environ.get("WR_NO_CHAIN") != "1"))
+    model = RotatingBprmf(args.users, args.items, D, dev, parts=args.parts, local=PipelinedSgd(chunk, min_triplets=1))
     model.init_xavier(3407)
     g = torch.Generator(device=dev)
     g.manual_seed(3407 * 7919 + rank)
