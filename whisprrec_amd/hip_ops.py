@@ -5,7 +5,6 @@ call into libwhisprrec_hip.so on ``torch.cuda.current_stream()``.  Nothing in th
 tensors must live on a ROCm device and the library must be built.
 """
 import ctypes
-import os
 
 import torch
 
