@@ -34,7 +34,15 @@ def main():
         cur.append(i)
     if cur:
         groups.append(cur)
-    timed = next((g for g in groups if len(g) >= 12), None)
+    # (a region of fewer than 12 chained launches in a row — the stream is cut where the next plan's build is queued — still
+    # counts when the cuts are short: groups closer than 400 us are one region)
+    merged = []
+    for g in groups:
+        if merged and int(rows[g[0]]["Start_Timestamp"]) - int(rows[merged[-1][-1]]["End_Timestamp"]) < 400_000:
+            merged[-1] = merged[-1] + g
+        else:
+            merged.append(g)
+    timed = next((g for g in merged if len(g) >= 12), None)
     if timed is not None:
         print("\ntimeline (first steps of the timed region; every kernel of every stream): kernel, start us, duration us")
         t0 = int(rows[timed[0]]["Start_Timestamp"])

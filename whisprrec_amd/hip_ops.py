@@ -968,7 +968,8 @@ class PipelinedSgd:
     alternate, and a plan's flags and hot-run counts come back through an asynchronous copy into pinned memory that is read
     when the plan's first step is queued — by then the build has long run, one chunk ahead (BatchPlan.finish)."""
 
-    PREFETCH_AFTER = 8            # steps of a plan queued before the build of the next plan is queued
+    PREFETCH_AFTER_TRIPLETS = 1 << 20   # work of a plan queued before the build of the next plan is queued (16 steps of
+                                        # 65,536: ~350 us of GPU time, more than the ~150 us the host needs to queue a build)
     PLAN_TRIPLETS = 1 << 22
     OVERLAP_MIN_BATCH = 8192      # below this a step is launch-bound and a third launch per step costs more than it hides
 
@@ -1192,12 +1193,13 @@ class PipelinedSgd:
                     self._prefetch(h)
                 else:
                     c = min(c, mid - pos)
-            elif h["next"] is None and h["at"] < h["nb"] and not h["overlap"] and c > self.PREFETCH_AFTER:
+            elif h["next"] is None and h["at"] < h["nb"] and not h["overlap"] and \
+                    c > (self.PREFETCH_AFTER_TRIPLETS + h["B"] - 1) // h["B"]:
                 # the next plan's build is queued behind the first few steps of this one, not behind all of them: with a
                 # slow host (a profiler attached, busy cores) queueing a chunk's launches can take as long as the GPU needs to
                 # run them, and the build then starts when the steps end — a bubble of a whole plan build per chunk (seen in
                 # a rocprofv3 trace of the two-launch stream: 330 us of idle step stream per 64 steps)
-                c = self.PREFETCH_AFTER
+                c = (self.PREFETCH_AFTER_TRIPLETS + h["B"] - 1) // h["B"]
             graph = self._graph_for(h, plan, lr) if (h["overlap"] and pos == base and c == plan.n_batches) else None
             if graph is not None:
                 graph[0].replay()                                    # the whole plan as the overlapped stream, one launch
