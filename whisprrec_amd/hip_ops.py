@@ -968,8 +968,13 @@ class PipelinedSgd:
     alternate, and a plan's flags and hot-run counts come back through an asynchronous copy into pinned memory that is read
     when the plan's first step is queued — by then the build has long run, one chunk ahead (BatchPlan.finish)."""
 
-    PREFETCH_AFTER_TRIPLETS = 1 << 20   # work of a plan queued before the build of the next plan is queued (16 steps of
-                                        # 65,536: ~350 us of GPU time, more than the ~150 us the host needs to queue a build)
+    # Queue the build of the next plan behind the first N triplets' worth of steps of the current plan instead of behind all
+    # of them (0 = off, the default).  It removes a bubble when queueing launches is slow — under rocprofv3 the host needs as
+    # long to queue a 64-step chunk of the two-launch stream as the GPU to run it, and the build then starts when the steps end
+    # (330 us of idle step stream per chunk in such a trace) — but on an unburdened host it costs: the driver's 20-step
+    # command, same box, four runs each: off 30.3-32.8 us/step, 8 steps first 33.1-35.7, 16 steps first 31.5-37.3 (the build
+    # then runs beside more of the steps, and the chunk's steps go out in two calls).
+    PREFETCH_AFTER_TRIPLETS = 0
     PLAN_TRIPLETS = 1 << 22
     OVERLAP_MIN_BATCH = 8192      # below this a step is launch-bound and a third launch per step costs more than it hides
 
@@ -1193,13 +1198,9 @@ class PipelinedSgd:
                     self._prefetch(h)
                 else:
                     c = min(c, mid - pos)
-            elif h["next"] is None and h["at"] < h["nb"] and not h["overlap"] and \
+            elif self.PREFETCH_AFTER_TRIPLETS > 0 and h["next"] is None and h["at"] < h["nb"] and not h["overlap"] and \
                     c > (self.PREFETCH_AFTER_TRIPLETS + h["B"] - 1) // h["B"]:
-                # the next plan's build is queued behind the first few steps of this one, not behind all of them: with a
-                # slow host (a profiler attached, busy cores) queueing a chunk's launches can take as long as the GPU needs to
-                # run them, and the build then starts when the steps end — a bubble of a whole plan build per chunk (seen in
-                # a rocprofv3 trace of the two-launch stream: 330 us of idle step stream per 64 steps)
-                c = (self.PREFETCH_AFTER_TRIPLETS + h["B"] - 1) // h["B"]
+                c = (self.PREFETCH_AFTER_TRIPLETS + h["B"] - 1) // h["B"]      # see PREFETCH_AFTER_TRIPLETS
             graph = self._graph_for(h, plan, lr) if (h["overlap"] and pos == base and c == plan.n_batches) else None
             if graph is not None:
                 graph[0].replay()                                    # the whole plan as the overlapped stream, one launch
