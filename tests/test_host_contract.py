@@ -127,3 +127,27 @@ def test_model_refuses_cpu_execution(g2):
     loss.backward()
     with pytest.raises(abi.WhisprRecHipError):
         m.optimizer.step()
+
+
+def test_csr_chunk_cut_is_a_partition_and_picks_the_combine_form():
+    """hip_ops.spmm_chunks (host side of the load-balanced CSR product): every row gets at least one chunk, the chunks of a
+    row tile its non-zeros in order, none is longer than asked; one combine level while no row has many chunks"""
+    from whisprrec_amd import hip_ops
+    rng = np.random.RandomState(0)
+    deg = np.minimum((rng.pareto(0.8, 500) * 4).astype(np.int64), 4000)
+    deg[3] = 0
+    deg[4] = 10_000                                                # a hub
+    rp = np.zeros(deg.size + 1, np.int64)
+    np.cumsum(deg, out=rp[1:])
+    for max_nnz in (8, 96, 4096):
+        cptr, crow = hip_ops.spmm_chunks(rp, max_nnz)
+        cp, cr = cptr.numpy(), crow.numpy()
+        assert cp[0] == 0 and cp[-1] == rp[-1] and cr.size == cp.size - 1
+        assert np.all(np.diff(cr) >= 0) and np.array_equal(np.unique(cr), np.arange(deg.size))
+        ln = np.diff(cp)
+        assert ln.max() <= max_nnz and np.array_equal(np.bincount(cr, weights=ln, minlength=deg.size).astype(np.int64), deg)
+        first = np.r_[True, cr[1:] != cr[:-1]]
+        assert np.array_equal(cp[:-1][first], rp[:-1])             # a row's first chunk starts at the row's first non-zero
+        most = int(np.bincount(cr).max())
+        assert crow._wr_levels == (1 if most <= hip_ops.SPMM_ONE_LEVEL_MAX_CHUNKS else 2)
+        assert hip_ops.spmm_levels_of(torch.from_numpy(cr.copy())) == crow._wr_levels      # recomputed from the array itself
