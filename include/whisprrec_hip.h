@@ -186,6 +186,32 @@ int32_t wr_epoch_prepare_range_i32(const int32_t *users, const int32_t *items, i
                                    int64_t first, int64_t count, int32_t *out_users, int32_t *out_pos, int32_t *out_neg,
                                    int64_t *order_out, int32_t *err_flag, void *stream);
 
+/* The same membership test — "has this user clicked this item" (BaseModel.py:172-174) — against a HASH SET of the (user, item)
+ * pairs instead of the per-user lists: open addressing with linear probing over 64-bit keys (user << 32 | item), capacity a
+ * power of two, at most a third full.  One test then reads one random 64-byte sector where the binary search reads ~7: the
+ * sampler is bound by that traffic at 100 M rows.  Same answers, hence the same negatives, bit for bit.
+ *   wr_pairset_capacity(n_pairs)  -> entries (uint64 each) the table needs;
+ *   wr_pairset_build              fills `table` [capacity] from the clicked lists (once per training frame);
+ *                                 err_flag (may be NULL) is set to 3 if the table was too small;
+ *   wr_sample_negatives_set_*, wr_epoch_prepare_range_set_*   the two entry points above with the set in place of the lists. */
+int64_t wr_pairset_capacity(int64_t n_pairs);
+int32_t wr_pairset_build(const int64_t *clicked_ptr, const int32_t *clicked_idx, int64_t n_users, uint64_t *table,
+                         int64_t capacity, int32_t *err_flag, void *stream);
+int32_t wr_sample_negatives_set_i64(const int64_t *users, int64_t n, int64_t n_users, int64_t n_items, const uint64_t *pair_table,
+                                    int64_t pair_capacity, uint64_t seed, uint64_t epoch, int64_t *neg_items,
+                                    int32_t *err_flag, void *stream);
+int32_t wr_sample_negatives_set_i32(const int32_t *users, int64_t n, int64_t n_users, int64_t n_items, const uint64_t *pair_table,
+                                    int64_t pair_capacity, uint64_t seed, uint64_t epoch, int32_t *neg_items,
+                                    int32_t *err_flag, void *stream);
+int32_t wr_epoch_prepare_range_set_i64(const int64_t *users, const int64_t *items, int64_t n, int64_t n_users, int64_t n_items,
+                                       const uint64_t *pair_table, int64_t pair_capacity, uint64_t seed, uint64_t epoch,
+                                       int64_t first, int64_t count, int64_t *out_users, int64_t *out_pos, int64_t *out_neg,
+                                       int64_t *order_out, int32_t *err_flag, void *stream);
+int32_t wr_epoch_prepare_range_set_i32(const int32_t *users, const int32_t *items, int64_t n, int64_t n_users, int64_t n_items,
+                                       const uint64_t *pair_table, int64_t pair_capacity, uint64_t seed, uint64_t epoch,
+                                       int64_t first, int64_t count, int32_t *out_users, int32_t *out_pos, int32_t *out_neg,
+                                       int64_t *order_out, int32_t *err_flag, void *stream);
+
 /* Epoch shuffle on the device — the row order DataLoader(shuffle=True) gives an epoch (src/helpers/BaseRunner.py:188-193):
  * out_k[i] = col_k[perm(i)] for up to three index columns (NULL pairs are skipped), order_out[i] = perm(i) if not NULL.
  * perm is a keyed bijection of [0, n) evaluated per row (alternating Feistel network on ceil(log2 n) bits, splitmix64

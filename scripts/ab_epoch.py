@@ -15,16 +15,31 @@ ptr, idx = hip_ops.clicked_csr_from_pairs(users, items, nU, nI)
 U = torch.randn(nU, D, generator=g, device=dev) * 0.001; I = torch.randn(nI, D, generator=g, device=dev) * 0.001
 pipe = hip_ops.PipelinedSgd(64)
 nb = (n_inter + B - 1) // B
-for mode in ("upfront", "pipelined"):
+t0 = time.perf_counter()
+pairs = hip_ops.pair_set(ptr, idx, nU)
+torch.cuda.synchronize()
+print(json.dumps({"pair_set_build_ms": (time.perf_counter() - t0) * 1e3, "entries": pairs.numel(), "pairs": idx.numel()}))
+for epoch in (1, 2):            # the preparation alone: lists against the hash set
+    for name, pr in (("lists", None), ("hash set", pairs)):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        neg, err = hip_ops.sample_negatives(users, nU, nI, ptr, idx, 3407, epoch, pairs=pr)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch, pairs=pr)
+        prep.fill(0, n_inter)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(json.dumps({"membership": name, "sample_negatives_ms": (t1 - t0) * 1e3, "fused_prepare_ms": (t2 - t1) * 1e3}))
+        del prep, neg
+for mode in ("upfront", "pipelined", "upfront+set", "pipelined+set"):
     for epoch in (1, 2, 3):
         losses = torch.empty(nb, dtype=torch.float32, device=dev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        if mode == "upfront":
-            neg, err = hip_ops.sample_negatives(users, nU, nI, ptr, idx, 3407, epoch)
+        pr = pairs if mode.endswith("+set") else None
+        if mode.startswith("upfront"):
+            neg, err = hip_ops.sample_negatives(users, nU, nI, ptr, idx, 3407, epoch, pairs=pr)
             u, p, n = hip_ops.epoch_shuffle([users, items, neg], 3407, epoch)
             pipe.run(pipe.plan(U, [(I, u, p, n)], B, lr=0.05), 0, 0.05, losses)
         else:
-            prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch)
+            prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch, pairs=pr)
             pipe.run(pipe.plan(U, [(I, prep.cols[0], prep.cols[1], prep.cols[2])], B, lr=0.05, prep=prep), 0, 0.05, losses)
             prep.check()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

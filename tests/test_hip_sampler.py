@@ -159,7 +159,14 @@ def test_fused_range_preparation_equals_sampler_then_shuffle(dtype):
         prep = hip_ops.EpochPrep(tu, ti, nU, nI, tptr, tidx, 3407, epoch, want_order=True)
         for lo, hi in ((7000, 20011), (0, 1), (1, 7000)):           # ranges in any order, any cut
             prep.fill(lo, hi)
+        # membership through the hash set of the pairs (wr_pairset_build) instead of the lists: the same columns
+        pairs = hip_ops.pair_set(tptr, tidx, nU)
+        neg_set, _ = hip_ops.sample_negatives(tu, nU, nI, None, None, 3407, epoch, pairs=pairs)
+        prep_set = hip_ops.EpochPrep(tu, ti, nU, nI, None, None, 3407, epoch, want_order=True, pairs=pairs)
+        prep_set.fill(0, n)
         torch.cuda.synchronize()
+        assert torch.equal(neg_set, neg)
+        assert all(torch.equal(a, b) for a, b in zip(prep_set.cols, prep.cols)) and torch.equal(prep_set.order, prep.order)
         assert torch.equal(prep.cols[0], su) and torch.equal(prep.cols[1], si) and torch.equal(prep.cols[2], sn)
         assert torch.equal(prep.order, order)
         prep.check()
