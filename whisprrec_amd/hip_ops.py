@@ -206,6 +206,7 @@ class PlanArena:
         self.meta = torch.zeros(n_meta, **i32)
         self.meta_host = torch.zeros(n_meta, dtype=torch.int32, pin_memory=True)
         self.meta_np = self.meta_host.numpy()      # the same pinned words as a NumPy view: cheap scalar reads on the step path
+        self.views = {}                            # BatchPlan.finish: slices of the words above, by plan length
         self.hot_sides = None
         if hot:
             self.hot_sides = []
@@ -515,23 +516,27 @@ class BatchPlan:
         if self.builder is None:
             self.builder = self._tried
         if self._want_hot:
-            counts_host = mh[self.META_HEAD:self.META_HEAD + 4 * self.n_batches]
             if self._pinned is not None:
                 any_hot = bool(self.arena.meta_np[self.META_HEAD:self.META_HEAD + 4 * self.n_batches].any())
             else:
-                any_hot = int(counts_host.sum().item()) > 0
+                any_hot = int(mh[self.META_HEAD:self.META_HEAD + 4 * self.n_batches].sum().item()) > 0
             if any_hot:
-                self.hot = {"sides": self._sides, "counts_host": counts_host}
+                self.hot = {"sides": self._sides, "counts_host": mh[self.META_HEAD:self.META_HEAD + 4 * self.n_batches]}
         if self._want_overlap and self.hot is None:
             o, nb, cb = self.arena.overlap, self.n_batches, self._cap_batches
-            dc = mh[self.META_HEAD + 4 * cb:self.META_HEAD + 4 * cb + nb]
-            dcn = self.arena.meta_np[self.META_HEAD + 4 * cb:self.META_HEAD + 4 * cb + nb]
-            if nb >= 2 and int(dcn.min()) >= 0:
+            # views of the arena's words, made once per (arena, plan length): this runs on the step path, between a plan's
+            # read-back and its first launch
+            views = self.arena.views.get((nb, cb))
+            if views is None:
+                lo = self.META_HEAD + 4 * cb
+                views = self.arena.views[(nb, cb)] = (mh[lo:lo + nb], self.arena.meta_np[lo:lo + nb], self.meta[lo:lo + cb])
+            dc, dcn, dcd = views
+            lo_n, hi_n = (int(dcn.min()), int(dcn.max())) if nb >= 2 else (-1, -1)
+            if nb >= 2 and lo_n >= 0:
                 # "fits": every batch's list of deferred runs is within capacity (the two-stream form needs that; the
                 # chained launch decides per step)
                 self.overlap = {"tdef": o["tdef"], "def_q": o["def_q"], "def_count_host": dc, "cap": o["cap"],
-                                "def_count_np": dcn, "fits": int(dcn.max()) <= o["cap"],
-                                "def_count_dev": self.meta[self.META_HEAD + 4 * cb:self.META_HEAD + 5 * cb]}
+                                "def_count_np": dcn, "fits": hi_n <= o["cap"], "def_count_dev": dcd}
         self._finished = True
         return self
 
@@ -589,6 +594,7 @@ class OverlapEvents:
 
 
 _CHAIN_SYNC = {}      # (device, stream) -> [int32 tensors]: hand-off counters of the chained step launches (BprmfTables._chain_sync)
+_OVERLAP_WS_BYTES = {}       # (batch size, D) -> bytes of the two-slot step workspace
 
 
 class BprmfTables:
@@ -678,7 +684,10 @@ class BprmfTables:
         return losses
 
     def overlap_workspace(self, batch_size):
-        nbytes = 2 * abi.check_size(abi.lib().wr_bprmf_step_workspace_bytes(batch_size, self.D), "wr_bprmf_step_workspace_bytes")
+        nbytes = _OVERLAP_WS_BYTES.get((batch_size, self.D))
+        if nbytes is None:
+            nbytes = _OVERLAP_WS_BYTES[(batch_size, self.D)] = 2 * abi.check_size(
+                abi.lib().wr_bprmf_step_workspace_bytes(batch_size, self.D), "wr_bprmf_step_workspace_bytes")
         return workspace(self.dev, "step_overlap").get(nbytes)
 
     def run_sgd_overlap(self, plan, first, count, lr, losses, side, events, static=False, ws=None):
@@ -721,6 +730,8 @@ class BprmfTables:
         counters it uses"""
         key = (str(self.dev), torch.cuda.current_stream(self.dev).cuda_stream)
         bufs = _CHAIN_SYNC.setdefault(key, [])
+        if bufs and count <= self.CHAIN_SYNC_STEPS:
+            return bufs[-1]                              # sized for CHAIN_SYNC_STEPS steps or more
         if not bufs or bufs[-1].numel() < int(abi.lib().wr_bprmf_chain_sync_words(count)):
             words = int(abi.lib().wr_bprmf_chain_sync_words(max(count, self.CHAIN_SYNC_STEPS)))
             bufs.append(torch.zeros(words, dtype=torch.int32, device=self.dev))      # older ones stay for check_chain
@@ -1211,7 +1222,7 @@ class PipelinedSgd:
                     h["map"] = self.ops.BucketMap(src[0], src[1], h["n_users"], h["n_items"], h["B"])
         if h["chain"] and plan.hot is not None:
             h["chain"] = False      # skewed ids stay skewed: the following plans skip the marks (hot batches take the two launches)
-        if h["chain"] and plan.hot is None and plan.overlap is not None:
+        if h["chain"] and plan.hot is None and plan.overlap is not None and not plan.overlap["fits"]:
             # ids that defer most runs (many shared item rows without any hot one): the marks are wasted plan work
             dcn = plan.overlap["def_count_np"]
             if int((dcn[1:] > plan.overlap["cap"]).sum()) * 2 > plan.n_batches - 1:
