@@ -347,7 +347,8 @@ int32_t wr_bprmf_plan_overlap_deferred(const int32_t *tu, const int32_t *tp, con
 /* Same two kernels in gradient-emitting mode: instead of updating the tables, writes the reduced
  * gradient rows (embedding_dense_backward of BaseRunner.py:198) to grad_u[r,:] / grad_i[r,:] for rows in
  * the batch and sets stamp[r] = step_id.  Rows not in the batch are not written: a consumer treats
- * stamp[r] != step_id as a zero gradient row (wr_adam_dense / wr_sgd_dense below). */
+ * stamp[r] != step_id as a zero gradient row (wr_adam_dense / wr_sgd_dense below).  stamp_u / stamp_i may be
+ * NULL (a caller that zero-filled grad_u / grad_i and reads them densely). */
 int32_t wr_bprmf_grads(const float *user_tab, int64_t n_users, const float *item_tab, int64_t n_items, int32_t D,
                        const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                        const int32_t *oc_src, int64_t B, float *grad_u, float *grad_i, int32_t *stamp_u,
@@ -377,6 +378,13 @@ int32_t wr_adam_dense(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_r
 int32_t wr_adam_dense_dev(float *tab, float *exp_avg, float *exp_avg_sq, int64_t n_rows, int32_t D, const float *grad,
                           const float *consts, int64_t n_consts, const int32_t *step_dev, float l2, float beta1, float beta2,
                           float eps, void *stream);
+
+/* wr_adam_dense_dev for two tables of the same width in ONE launch (a model's user and item embeddings; one graph node and
+ * one launch latency fewer per step).  Same arithmetic per element. */
+int32_t wr_adam_dense_dev_pair(float *tab_a, float *exp_avg_a, float *exp_avg_sq_a, int64_t n_rows_a, const float *grad_a,
+                               float *tab_b, float *exp_avg_b, float *exp_avg_sq_b, int64_t n_rows_b, const float *grad_b,
+                               int32_t D, const float *consts, int64_t n_consts, const int32_t *step_dev, float l2,
+                               float beta1, float beta2, float eps, void *stream);
 int32_t wr_counter_add(int32_t *counter, int32_t delta, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -611,11 +611,16 @@ def test_pipelined_sgd_switches_to_the_bucket_map_on_skewed_ids(ops, dev):
     ops._FAST_BACKOFF.clear()
 
 
+@pytest.mark.parametrize("form", ["count", "bitonic"])
 @pytest.mark.parametrize("B,nbat,nU,nI,short", [(2048, 3, 900, 1500, 100), (4096, 2, 100000, 50, 0), (512, 5, 40, 30, 511), (1, 3, 5, 5, 0),
-                                                (3000, 2, 5000, 7000, 1), (2048, 1, 6040, 3706, 0)])
-def test_small_single_launch_builder_agrees_bitwise(ops, dev, B, nbat, nU, nI, short):
-    """one workgroup per batch, LDS bitonic sorts: the arrays of the radix-sort builder, bit for bit (duplicates, short last
-    batch, non-power-of-two batches, int64 and int32 inputs)"""
+                                                (3000, 2, 5000, 7000, 1), (2048, 1, 6040, 3706, 0), (4096, 2, 1, 1, 3),
+                                                (4096, 1, 8000, 8000, 0), (4096, 2, 3, 12000, 0)])
+def test_small_single_launch_builder_agrees_bitwise(ops, dev, monkeypatch, form, B, nbat, nU, nI, short):
+    """one workgroup per batch — LDS counting sort where a counter per row fits LDS (form "count"; tables too large for it
+    take the bitonic sorts either way), LDS bitonic sorts otherwise: the arrays of the radix-sort builder, bit for bit
+    (duplicates up to a batch of one single row, short last batch, non-power-of-two batches, int64 and int32 inputs)"""
+    if form == "bitonic":
+        monkeypatch.setenv("WR_PLAN_SMALL", "bitonic")
     rng = np.random.RandomState(B + nbat)
     N = nbat * B - short
     u, p, n = rng.randint(0, nU, N), rng.randint(0, nI, N), rng.randint(0, nI, N)

@@ -218,3 +218,23 @@ def test_captured_step_graph_equals_eager_loop():
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
     assert out[0][4] == out[1][4]
+
+
+@pytest.mark.gpu
+def test_pair_adam_launch_equals_two_single_launches():
+    """wr_adam_dense_dev_pair (both embedding tables in one launch) leaves the bits of two wr_adam_dense_dev launches"""
+    from whisprrec_amd import hip_ops as ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    consts = ops.adam_consts(64, 1e-3, device=dev)
+    step = torch.full((1,), 3, dtype=torch.int32, device=dev)
+    for rows_a, rows_b, D in ((6040, 3706, 64), (7, 300001, 32), (1, 1, 4)):
+        mk = lambda r: [torch.randn(r, D, device=dev, generator=g) for _ in range(2)] + \
+                       [torch.rand(r, D, device=dev, generator=g), torch.randn(r, D, device=dev, generator=g)]
+        a, b = mk(rows_a), mk(rows_b)
+        a1, b1 = [t.clone() for t in a], [t.clone() for t in b]
+        ops.adam_dense_dev_pair(a, b, consts, step, l2=1e-4)
+        for t in (a1, b1):
+            ops.adam_dense_dev(t[0], t[1], t[2], t[3], consts, step, l2=1e-4)
+        for x, y in zip(a + b, a1 + b1):
+            assert torch.equal(x, y)

@@ -90,6 +90,8 @@ SIGNATURES = {
     "wr_adam_dense": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32,
                               c_f32, c_vp]),
     "wr_adam_dense_dev": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "wr_adam_dense_dev_pair": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp,
+                                       c_f32, c_f32, c_f32, c_f32, c_vp]),
     "wr_counter_add": (c_i32, [c_vp, c_i32, c_vp]),
     "wr_adam_consts": (c_i32, [c_i64, c_i64, c_f32, c_f32, c_f32, c_vp]),
     "wr_adam_rows_lazy": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32,

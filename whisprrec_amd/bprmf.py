@@ -168,7 +168,7 @@ class _DenseGradBprLoss(torch.autograd.Function):
         plan = hip_ops.BatchPlan(u, p, n, u.numel(), m.user_num, m.item_num)
         gU = torch.zeros_like(tabs.U)
         gI = torch.zeros_like(tabs.I)
-        tabs.grads(plan, 0, gU, gI)
+        tabs.grads(plan, 0, gU, gI, stamps=False)
         return gU * grad_out, gI * grad_out, None, None, None, None
 
 

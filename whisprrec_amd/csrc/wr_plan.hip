@@ -10,6 +10,7 @@
 // One device-wide LSD radix sort per table over composite keys (batch << row_bits | row), restricted to the
 // bits that are actually used.  The radix sort itself is rocPRIM's (ROCm system library, stable); key
 // construction, range checks and unpacking are the kernels below.
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -212,6 +213,140 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(const Idx *__
         tn[lo + t] = sn[t];
     }
 }
+
+// Counting form of the same builder, for tables small enough that one counter per row fits LDS beside the batch (ml-scale:
+// 6,040 users / 3,706 items at the default batch): count the rows, exclusive scan, scatter the positions behind their row's
+// cursor, then put every row's segment in ascending position order (a position counts the smaller ones of its segment —
+// segments are a handful long; a batch of one single row costs B / 1,024 passes over it and stays correct).  A dozen
+// barriers instead of the 72 of the two bitonic sorts; the same arrays, bit for bit.
+constexpr int kCountPerThread = 2 * kSmallBatch / kSmallThreads;
+
+template <typename RowOf>
+__device__ __forceinline__ void count_sort_lds(int *__restrict__ cnt, int *__restrict__ cur, int *__restrict__ out,
+                                               int *__restrict__ wave_tot, int n_rows, int E, int total, RowOf row_of) {
+    for (int j = threadIdx.x; j < n_rows; j += kSmallThreads) cnt[j] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += kSmallThreads) {
+        const int r = row_of(e);
+        if (r >= 0) atomicAdd(&cnt[r], 1);                       // integer counts: order irrelevant
+    }
+    __syncthreads();
+    const int per = (n_rows + kSmallThreads - 1) / kSmallThreads;
+    const int c0 = threadIdx.x * per;
+    int local = 0;
+    for (int j = 0; j < per; ++j)
+        if (c0 + j < n_rows) local += cnt[c0 + j];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wave_tot[w];
+    for (int j = 0; j < per; ++j)
+        if (c0 + j < n_rows) {
+            cur[c0 + j] = run;
+            run += cnt[c0 + j];
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += kSmallThreads) {
+        const int r = row_of(e);
+        if (r >= 0) out[atomicAdd(&cur[r], 1)] = e;              // the cursors end at their segments' ends
+    }
+    __syncthreads();
+    int v[kCountPerThread], dst[kCountPerThread];
+#pragma unroll
+    for (int k = 0; k < kCountPerThread; ++k) {
+        const int q = threadIdx.x + k * kSmallThreads;
+        dst[k] = -1;
+        if (q < total) {
+            v[k] = out[q];
+            const int r = row_of(v[k]);
+            const int m = cnt[r];
+            dst[k] = q;
+            if (m > 1) {
+                const int s0 = cur[r] - m;
+                int rank = 0;
+                for (int x = 0; x < m; ++x) rank += out[s0 + x] < v[k] ? 1 : 0;
+                dst[k] = s0 + rank;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kCountPerThread; ++k)
+        if (dst[k] >= 0) out[dst[k]] = v[k];
+    __syncthreads();
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kSmallThreads) void plan_small_count_kernel(const Idx *__restrict__ u, const Idx *__restrict__ p,
+                                                                          const Idx *__restrict__ nn, int64_t n, int64_t B,
+                                                                          int64_t n_users, int64_t n_items, int *__restrict__ tu,
+                                                                          int *__restrict__ tp, int *__restrict__ tn,
+                                                                          int *__restrict__ torig, int *__restrict__ oc_item,
+                                                                          int *__restrict__ oc_src, int *__restrict__ err,
+                                                                          int nk, int P) {
+    extern __shared__ int lds_count[];                    // cnt[nk] | cur[nk] | out[2P] | sp[P] | sn[P]
+    __shared__ int wave_tot[kSmallThreads / 64];
+    int *cnt = lds_count, *cur = cnt + nk, *out = cur + nk, *sp = out + 2 * P, *sn = sp + P;
+    int *ur = out + P;                                    // the user side sorts P positions: its rows live in the upper half
+    const int64_t b = blockIdx.x, lo = b * B;
+    const int Bb = (int)((lo + B <= n) ? B : (n - lo));
+    for (int i = threadIdx.x; i < Bb; i += kSmallThreads) {
+        int64_t uu = (int64_t)u[lo + i];
+        if (uu < 0 || uu >= n_users) {
+            if (err) *err = 1;
+            uu = 0;
+        }
+        ur[i] = (int)uu;
+    }
+    __syncthreads();
+    count_sort_lds(cnt, cur, out, wave_tot, (int)n_users, Bb, Bb, [&](int e) { return ur[e]; });
+    for (int t = threadIdx.x; t < Bb; t += kSmallThreads) {
+        const int o = out[t];
+        int64_t pi = (int64_t)p[lo + o], ni = (int64_t)nn[lo + o];
+        if (pi < 0 || pi >= n_items || ni < 0 || ni >= n_items) {
+            if (err) *err = 1;
+            pi = (pi < 0 || pi >= n_items) ? 0 : pi;
+            ni = (ni < 0 || ni >= n_items) ? 0 : ni;
+        }
+        tu[lo + t] = ur[o];
+        if (torig) torig[lo + t] = (int)(lo + o);
+        sp[t] = (int)pi;
+        sn[t] = (int)ni;
+    }
+    __syncthreads();
+    // occurrences: element e = side * P + t, i.e. inside an item's segment the positive side first, each side by t
+    auto item_of = [&](int e) { const int t = e & (P - 1); return t < Bb ? ((e >= P ? sn[t] : sp[t]) & 0x7fffffff) : -1; };
+    count_sort_lds(cnt, cur, out, wave_tot, (int)n_items, 2 * P, 2 * Bb, item_of);
+    for (int q = threadIdx.x; q < 2 * Bb; q += kSmallThreads) {
+        const int e = out[q];
+        const int side = e >= P ? 1 : 0, t = e & (P - 1);
+        const int item = side ? sn[t] : sp[t];           // one reader and writer per (triplet, side): no flag set yet
+        oc_item[2 * lo + q] = item;
+        oc_src[2 * lo + q] = (t << 1) | side;
+        if (cnt[item] > 1) {
+            if (side) sn[t] = item | (int)0x80000000; else sp[t] = item | (int)0x80000000;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Bb; t += kSmallThreads) {
+        tp[lo + t] = sp[t];
+        tn[lo + t] = sn[t];
+    }
+}
+
+constexpr size_t kCountLdsMax = 128 * 1024;
+// WR_PLAN_SMALL=bitonic in the environment keeps the sorting form (A/B runs, and the tests that compare the two forms)
+static bool small_plan_force_bitonic() {
+    const char *e = getenv("WR_PLAN_SMALL");
+    return e && strcmp(e, "bitonic") == 0;
+}
+
 template <typename Idx>
 static int32_t plan_build_small(const Idx *u, const Idx *p, const Idx *nn, int64_t n, int64_t B, int64_t n_users,
                                 int64_t n_items, int32_t *tu, int32_t *tp, int32_t *tn, int32_t *torig, int32_t *oc_item,
@@ -226,6 +361,22 @@ static int32_t plan_build_small(const Idx *u, const Idx *p, const Idx *nn, int64
     int P = 1, pos_bits = 0;
     while (P < (B < n ? B : n)) { P <<= 1; ++pos_bits; }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    {   // small tables: one LDS counter per row (plan_small_count_kernel)
+        const int64_t nk = n_users > n_items ? n_users : n_items;
+        const size_t lds = (size_t)(2 * nk + 4 * (int64_t)P) * 4;
+        if (lds <= kCountLdsMax && !small_plan_force_bitonic()) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                WR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_count_kernel<Idx>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLdsMax));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((plan_small_count_kernel<Idx>), dim3((unsigned)nb), dim3(kSmallThreads), lds, stream, u, p, nn, n, B,
+                               n_users, n_items, tu, tp, tn, torig, oc_item, oc_src, err_flag, (int)nk, P);
+            WR_LAUNCH_CHECK("plan_small_count_kernel");
+            return WR_OK;
+        }
+    }
     // 32-bit composites when rows + side + positions fit 31 bits (the all-ones padding key stays above every real one)
     const bool narrow = (int)bits_for(n_users) + pos_bits <= 31 && (int)bits_for(n_items) + 1 + pos_bits <= 31;
     if (narrow) {

@@ -394,6 +394,33 @@ __global__ __launch_bounds__(kBlock) void adam_dense_dev_kernel(float4 *__restri
     }
 }
 
+// Two tables in one launch (a model's user and item embeddings): workgroups [0, blocks_a) take table a, the rest table b.
+struct AdamTab {
+    float4 *w, *m, *v;
+    const float4 *g;
+    int64_t n4;
+};
+
+__global__ __launch_bounds__(kBlock) void adam_dense_dev_pair_kernel(AdamTab a, AdamTab b, int blocks_a, float l2, float b1,
+                                                                      float b2, float eps, const float *__restrict__ consts,
+                                                                      const int *__restrict__ step_dev) {
+    const int t = step_dev[0];
+    const float step_size = consts[2 * t], inv_bc2 = consts[2 * t + 1];
+    const bool second = (int)blockIdx.x >= blocks_a;                 // workgroup-uniform
+    const AdamTab &tab = second ? b : a;
+    const int64_t first = (int64_t)((int)blockIdx.x - (second ? blocks_a : 0)) * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)(second ? (int)gridDim.x - blocks_a : blocks_a) * kBlock;
+    for (int64_t i = first; i < tab.n4; i += stride) {
+        float4 ww = tab.w[i], mm = tab.m[i], vv = tab.v[i];
+        const float4 gg = tab.g[i];
+        adam_elem(ww.x, mm.x, vv.x, gg.x, l2, b1, b2, eps, step_size, inv_bc2);
+        adam_elem(ww.y, mm.y, vv.y, gg.y, l2, b1, b2, eps, step_size, inv_bc2);
+        adam_elem(ww.z, mm.z, vv.z, gg.z, l2, b1, b2, eps, step_size, inv_bc2);
+        adam_elem(ww.w, mm.w, vv.w, gg.w, l2, b1, b2, eps, step_size, inv_bc2);
+        tab.w[i] = ww; tab.m[i] = mm; tab.v[i] = vv;
+    }
+}
+
 __global__ void counter_add_kernel(int *__restrict__ c, int delta) { c[0] += delta; }
 
 __global__ __launch_bounds__(kBlock) void axpy_kernel(float4 *__restrict__ y, const float4 *__restrict__ x, int64_t n4,
@@ -743,14 +770,24 @@ __global__ __launch_bounds__(kBlock) void lightgcn_tail_finish_kernel(const floa
 
 // Gradient of EmbLoss w.r.t. the gathered ego rows, accumulated per table row using a batch plan: every occurrence of row
 // r in block k contributes (reg_weight / (B * ||block_k||_F)) * row, so a run of m occurrences adds m times that.
-// side: 0 = user rows (runs of tu), 1 = item rows (runs of oc_item, positives and negatives have different norms).
+// Both tables in one launch: workgroups [0, user_blocks) take the user rows (runs of tu), the rest the item rows (runs of
+// oc_item; positives and negatives have different norms).
 template <int T, int NV, bool FULL>
-__global__ __launch_bounds__(kBlock) void embloss_grad_kernel(int side, const float *__restrict__ tab, float *__restrict__ grad,
-                                                               int D, const int *__restrict__ keys, const int *__restrict__ src,
-                                                               int n, const float *__restrict__ sq3, float reg_over_B) {
+__global__ __launch_bounds__(kBlock) void embloss_grad_kernel(const float *__restrict__ user_tab, float *__restrict__ grad_user,
+                                                               const int *__restrict__ tu, int n_user, int user_blocks,
+                                                               const float *__restrict__ item_tab, float *__restrict__ grad_item,
+                                                               const int *__restrict__ oc_item, const int *__restrict__ oc_src,
+                                                               int n_item, int D, const float *__restrict__ sq3,
+                                                               float reg_over_B) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
-    const int q0 = blockIdx.x * TEAMS + threadIdx.x / T;
+    const int side = (int)blockIdx.x >= user_blocks ? 1 : 0;              // workgroup-uniform
+    const float *__restrict__ tab = side ? item_tab : user_tab;
+    float *__restrict__ grad = side ? grad_item : grad_user;
+    const int *__restrict__ keys = side ? oc_item : tu;
+    const int *__restrict__ src = oc_src;
+    const int n = side ? n_item : n_user;
+    const int q0 = ((int)blockIdx.x - (side ? user_blocks : 0)) * TEAMS + threadIdx.x / T;
     if (q0 >= n) return;
     const int r = keys[q0];
     if (q0 > 0 && keys[q0 - 1] == r) return;  // not the head of its run
@@ -956,6 +993,29 @@ int32_t wr_adam_dense_dev(float *tab, float *exp_avg, float *exp_avg_sq, int64_t
     return WR_OK;
 }
 
+int32_t wr_adam_dense_dev_pair(float *tab_a, float *exp_avg_a, float *exp_avg_sq_a, int64_t n_rows_a, const float *grad_a,
+                               float *tab_b, float *exp_avg_b, float *exp_avg_sq_b, int64_t n_rows_b, const float *grad_b,
+                               int32_t D, const float *consts, int64_t n_consts, const int32_t *step_dev, float l2,
+                               float beta1, float beta2, float eps, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(tab_a, n_rows_a, D, "tab_a")) != WR_OK) return rc;
+    if ((rc = check_table(tab_b, n_rows_b, D, "tab_b")) != WR_OK) return rc;
+    WR_REQUIRE(exp_avg_a && exp_avg_sq_a && grad_a && exp_avg_b && exp_avg_sq_b && grad_b, WR_E_NULL, "NULL state or gradient");
+    WR_REQUIRE(aligned16(exp_avg_a) && aligned16(exp_avg_sq_a) && aligned16(grad_a) && aligned16(exp_avg_b) &&
+                   aligned16(exp_avg_sq_b) && aligned16(grad_b), WR_E_ALIGN, "state/gradient not 16-byte aligned");
+    WR_REQUIRE(consts != nullptr && step_dev != nullptr && n_consts >= 2, WR_E_NULL, "consts / step_dev is NULL");
+    const int64_t n4a = n_rows_a * (D / 4), n4b = n_rows_b * (D / 4);
+    const unsigned ga = stream_grid(n4a), gb = stream_grid(n4b);
+    const AdamTab a{reinterpret_cast<float4 *>(tab_a), reinterpret_cast<float4 *>(exp_avg_a), reinterpret_cast<float4 *>(exp_avg_sq_a),
+                    reinterpret_cast<const float4 *>(grad_a), n4a};
+    const AdamTab b{reinterpret_cast<float4 *>(tab_b), reinterpret_cast<float4 *>(exp_avg_b), reinterpret_cast<float4 *>(exp_avg_sq_b),
+                    reinterpret_cast<const float4 *>(grad_b), n4b};
+    hipLaunchKernelGGL(adam_dense_dev_pair_kernel, dim3(ga + gb), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream_), a, b,
+                       (int)ga, l2, beta1, beta2, eps, consts, step_dev);
+    WR_LAUNCH_CHECK("adam_dense_dev_pair_kernel");
+    return WR_OK;
+}
+
 int32_t wr_counter_add(int32_t *counter, int32_t delta, void *stream_) {
     WR_REQUIRE(counter != nullptr, WR_E_NULL, "counter is NULL");
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream_), counter, delta);
@@ -1125,13 +1185,10 @@ int32_t wr_embloss_grad(const float *user_tab, const float *item_tab, int32_t D,
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int tpb = teams_per_block_for(D);
     const float rob = reg_weight / (float)B;
+    const unsigned ub = (unsigned)((B + tpb - 1) / tpb), ib = (unsigned)((2 * B + tpb - 1) / tpb);
 #define WR_CALL_EG(T_, NV_, FULL_)                                                                                        \
-    do {                                                                                                                 \
-        hipLaunchKernelGGL((embloss_grad_kernel<T_, NV_, FULL_>), dim3((unsigned)((B + tpb - 1) / tpb)), dim3(kBlock), 0,  \
-                           stream, 0, user_tab, grad_user, D, tu, (const int *)nullptr, (int)B, sq3, rob);                \
-        hipLaunchKernelGGL((embloss_grad_kernel<T_, NV_, FULL_>), dim3((unsigned)((2 * B + tpb - 1) / tpb)), dim3(kBlock), \
-                           0, stream, 1, item_tab, grad_item, D, oc_item, oc_src, (int)(2 * B), sq3, rob);                \
-    } while (0)
+    hipLaunchKernelGGL((embloss_grad_kernel<T_, NV_, FULL_>), dim3(ub + ib), dim3(kBlock), 0, stream, user_tab, grad_user, \
+                       tu, (int)B, (int)ub, item_tab, grad_item, oc_item, oc_src, (int)(2 * B), D, sq3, rob)
     WR_DISPATCH_D(D, WR_CALL_EG);
 #undef WR_CALL_EG
     WR_LAUNCH_CHECK("embloss_grad_kernel");

@@ -782,13 +782,14 @@ class BprmfTables:
         self.step_id += count
         return losses
 
-    def grads(self, plan, k, grad_u, grad_i, loss_out=None):
+    def grads(self, plan, k, grad_u, grad_i, loss_out=None, stamps=True):
         """embedding_dense_backward of BaseRunner.py:198 for batch k: writes the gradient rows of the rows in the
-        batch into grad_u / grad_i and stamps them with the returned step id (other rows are not written)."""
+        batch into grad_u / grad_i and stamps them with the returned step id (other rows are not written).
+        stamps=False: no stamp arrays at all — for a caller that zero-filled grad_u / grad_i and reads them densely."""
         L = abi.lib()
         tu, tp, tn, oi, os_, B = self._plan_ptrs(plan, k)
         ws = self._ws(plan.batch_size)
-        su, si = self._stamps()
+        su, si = self._stamps() if stamps else (None, None)
         if loss_out is None:
             loss_out = torch.empty((), dtype=torch.float32, device=self.dev)
         self.step_id += 1
@@ -1535,6 +1536,18 @@ def adam_dense_dev(tab, exp_avg, exp_avg_sq, grad, consts, step_dev, l2=0.0, bet
     abi.check(abi.lib().wr_adam_dense_dev(_p(tab), _p(exp_avg), _p(exp_avg_sq), tab.shape[0], tab.shape[1], _p(grad),
                                           _p(consts), consts.numel() // 2, _p(step_dev), l2, beta1, beta2, eps, _stream()),
               "wr_adam_dense_dev")
+
+
+def adam_dense_dev_pair(a, b, consts, step_dev, l2=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """adam_dense_dev for two tables of the same width in one launch; a, b: (tab, exp_avg, exp_avg_sq, grad)"""
+    for grp in (a, b):
+        for t, nm in zip(grp, ("tab", "exp_avg", "exp_avg_sq", "grad")):
+            _req(t, torch.float32, nm, 2)
+    if a[0].shape[1] != b[0].shape[1]:
+        raise ValueError("adam_dense_dev_pair: tables of different width")
+    abi.check(abi.lib().wr_adam_dense_dev_pair(_p(a[0]), _p(a[1]), _p(a[2]), a[0].shape[0], _p(a[3]), _p(b[0]), _p(b[1]), _p(b[2]),
+                                               b[0].shape[0], _p(b[3]), a[0].shape[1], _p(consts), consts.numel() // 2,
+                                               _p(step_dev), l2, beta1, beta2, eps, _stream()), "wr_adam_dense_dev_pair")
 
 
 def counter_add(counter, delta=1):

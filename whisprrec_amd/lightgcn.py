@@ -99,9 +99,14 @@ class DenseHipOptimizer:
             if self.t >= self.MAX_STEPS:
                 raise RuntimeError("more than %d Adam steps" % self.MAX_STEPS)
             hip_ops.counter_add(self.step_dev, 1)
-        for p in self.params:
-            if p.grad is None:
-                continue
+        live = [p for p in self.params if p.grad is not None]
+        if self.name == "Adam" and len(live) == 2 and live[0].dim() == 2 and live[1].dim() == 2 and \
+                live[0].shape[1] == live[1].shape[1]:
+            # the two embedding tables of a model: one launch
+            a, b = ((p.data, *self.state[p], p.grad.contiguous()) for p in live)
+            hip_ops.adam_dense_dev_pair(a, b, self.consts, self.step_dev, self.l2)
+            return
+        for p in live:
             g = p.grad.contiguous()
             if self.name == "SGD":
                 hip_ops.sgd_dense(p.data, g, self.lr, self.l2)
@@ -121,8 +126,8 @@ class _LightGcnLoss(torch.autograd.Function):
     def backward(ctx, grad_out):
         gE = ctx.model._backward(ctx.idx, ctx.saved)
         nU = ctx.model.n_users
-        s = grad_out.reshape(-1)[0]
-        return gE[:nU] * s, gE[nU:] * s, None, None, None, None
+        gE.mul_(grad_out.reshape(-1)[0])             # gE is this call's own buffer: one pass for both tables
+        return gE[:nU], gE[nU:], None, None, None, None
 
 
 def make_lightgcn(general_model_cls):
@@ -230,7 +235,7 @@ def make_lightgcn(general_model_cls):
             plan = hip_ops.BatchPlan(u, p, n, B, nU, self.n_items, builder="small" if B <= 4096 else "generic", hot=False,
                                      validate=not getattr(self, "_trusted_indices", False))
             gOut = torch.zeros(nU + self.n_items, D, device=allE.device)
-            tabs.grads(plan, 0, gOut[:nU], gOut[nU:])
+            tabs.grads(plan, 0, gOut[:nU], gOut[nU:], stamps=False)     # gOut is zero-filled and read densely
             # back through the propagation: A is symmetric, d(mean_l A^l E0) = mean_l A^l gOut
             gE = self._propagate(gOut)
             # EmbLoss: d/dx ||X||_F = x/||X||_F per gathered row, duplicates add up (loss.py:94-98); the plan's runs give

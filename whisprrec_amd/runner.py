@@ -359,7 +359,9 @@ def make_hip_runner(base_runner_cls):
             torch.cuda.current_stream(dev).wait_stream(side)
             t_before = getattr(model.optimizer, "t", None)
             try:
-                static = [torch.empty(B, dtype=c.dtype, device=dev) for c in cols]
+                # one (3, B) buffer: a replay's indices arrive in one strided copy from the stacked epoch columns
+                static3 = torch.empty((3, B), dtype=cols[0].dtype, device=dev)
+                static = [static3[0], static3[1], static3[2]]
                 batch = {"user_id": static[0], "pos_item": static[1], "neg_items": static[2].unsqueeze(1), "batch_size": B,
                          "phase": "train"}
                 g = torch.cuda.CUDAGraph()
@@ -481,9 +483,11 @@ def make_hip_runner(base_runner_cls):
                 graph = self._step_graph(model, cols, B, n, eager_step) if self.hip_graphs else None
                 if graph is not None:
                     g, static, static_loss, lo = graph  # lo: first row not trained yet (a failed capture: g is None)
+                    if g is not None:
+                        static3 = static[0]._base           # the (3, B) buffer behind the three static index rows
+                        cols3 = torch.stack(cols)
                     while g is not None and lo + B <= n:    # full batches: copy the indices in, replay the captured step
-                        for dst, src in zip(static, cols):
-                            dst.copy_(src[lo:lo + B])
+                        static3.copy_(cols3[:, lo:lo + B])
                         g.replay()
                         losses.append(static_loss.detach().reshape(-1)[0].clone())
                         lo += B
