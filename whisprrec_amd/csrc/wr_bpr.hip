@@ -873,6 +873,41 @@ __device__ __forceinline__ void item_tile_block(float *__restrict__ I, int D, co
                     g.v[k].w = fmaf(g1, z1.v[k].w, fmaf(g0, z0.v[k].w, 0.f));
                 }
                 int j = j0 + 2;
+                if constexpr (MODE == 1) {
+                    // gradient mode (one small batch per call: LightGCN, the autograd path — popularity-skewed items, runs of
+                    // tens of occurrences, nothing else on the GPU to hide a serial walk): four stashed rows in flight
+                    for (;;) {
+                        int src[4];
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            const int q = tile0 + j + f;
+                            const bool in_lds = j + f < TILE + kAhead;
+                            src[f] = -1;
+                            if (q < B2 && (f == 0 || src[f - 1] >= 0)) {
+                                const int it = in_lds ? item_tile[j + f] : oc_item[q];
+                                if (it == r) src[f] = in_lds ? src_tile[j + f] : oc_src[q];
+                            }
+                        }
+                        Row<NV> z[4];
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            if (src[f] >= 0) z[f] = load_row<T, NV, FULL>(Z, src[f] >> 1, D, lane);
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            if (src[f] < 0) continue;
+                            const float sgn = (src[f] & 1) ? -1.0f : 1.0f;
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) {
+                                g.v[k].x = fmaf(sgn, z[f].v[k].x, g.v[k].x);
+                                g.v[k].y = fmaf(sgn, z[f].v[k].y, g.v[k].y);
+                                g.v[k].z = fmaf(sgn, z[f].v[k].z, g.v[k].z);
+                                g.v[k].w = fmaf(sgn, z[f].v[k].w, g.v[k].w);
+                            }
+                        }
+                        if (src[3] < 0) break;
+                        j += 4;
+                    }
+                } else
                 for (;;) {
                     const int q = tile0 + j;
                     if (q >= B2) break;

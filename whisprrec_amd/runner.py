@@ -364,11 +364,17 @@ def make_hip_runner(base_runner_cls):
                 static = [static3[0], static3[1], static3[2]]
                 batch = {"user_id": static[0], "pos_item": static[1], "neg_items": static[2].unsqueeze(1), "batch_size": B,
                          "phase": "train"}
+                # the root gradient of backward(): made once here (autograd would fill a fresh one inside every replay)
+                shape = getattr(self, "_loss_shape", None)
+                root = torch.ones(shape, dtype=torch.float32, device=dev) if shape is not None else None
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     model.optimizer.zero_grad()
                     static_loss = model.predict(batch)
-                    static_loss.backward()
+                    if root is not None and static_loss.shape == root.shape and static_loss.dtype == root.dtype:
+                        static_loss.backward(root)
+                    else:
+                        static_loss.backward()
                     model.optimizer.step()
             except (RuntimeError, abi.WhisprRecHipError) as e:
                 # capture is an optimisation: the epoch goes on eagerly FROM THE FIRST UNTRAINED ROW.  A capture that died
@@ -381,7 +387,7 @@ def make_hip_runner(base_runner_cls):
                 return None, None, None, 3 * B
             if hasattr(model.optimizer, "sync_step_count"):
                 model.optimizer.t -= 1               # the captured step() call itself trained nothing
-            self._graph_cache = (key, g, static, static_loss)
+            self._graph_cache = (key, g, static, static_loss, root)      # root: kept alive for the replays
             return g, static, static_loss, 3 * B
 
         def _epoch_columns(self, dataset, dev, epoch):
@@ -474,6 +480,7 @@ def make_hip_runner(base_runner_cls):
                     batch["history_items"], batch["lengths"] = hist[lo:lo + B], hlen[lo:lo + B]
                 model.optimizer.zero_grad()
                 loss = model.predict(batch)
+                self._loss_shape = tuple(loss.shape)
                 loss.backward()
                 model.optimizer.step()
                 losses.append(loss.detach().reshape(-1)[0])
