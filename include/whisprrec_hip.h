@@ -600,6 +600,17 @@ int32_t wr_spmm_csr_chunked_levels(int64_t n_rows, int64_t n_chunks, const int64
                                    const int32_t *col, const float *val, const float *X, int32_t D, float *Y, float *acc,
                                    float *partials, const int8_t *row_mode, int32_t levels, int32_t acc_from_x,
                                    float acc_scale, void *stream);
+
+/* The same product (one combine level) in ONE launch: the chunk of a cut row that finishes last adds the row's partials
+ * itself (in chunk order: the bits of the two-launch form) instead of a combine launch doing it.  row_span[2r], [2r + 1]:
+ * first chunk and number of chunks of row r; counters: n_rows words, zero before the first call (every call leaves them
+ * zero).  Rows must be whole 128-byte lines: wr_spmm_fused_supported(D, partials) != 0 (D % 32 == 0, partials 128-byte
+ * aligned); rows cut into more than a few dozen chunks are better served by the two-level form. */
+int32_t wr_spmm_fused_supported(int32_t D, const float *partials);
+int32_t wr_spmm_csr_chunked_fused(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                                  const int32_t *row_span, const int32_t *col, const float *val, const float *X, int32_t D,
+                                  float *Y, float *acc, float *partials, const int8_t *row_mode, int32_t acc_from_x,
+                                  float acc_scale, uint32_t *counters, void *stream);
 /* out = alpha * x  /  y += alpha * x  over numel floats (layer-mean scaling, gradient accumulation) */
 int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream);
 /* EmbLoss pieces (src/utils/loss.py:94-98): sq[0..2] = sum of squares of the gathered U[u], I[p], I[n] blocks */

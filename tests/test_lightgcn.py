@@ -238,3 +238,36 @@ def test_pair_adam_launch_equals_two_single_launches():
             ops.adam_dense_dev(t[0], t[1], t[2], t[3], consts, step, l2=1e-4)
         for x, y in zip(a + b, a1 + b1):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,L,N", [(64, 96, 9746), (32, 8, 3000), (128, 64, 3000), (96, 32, 2000)])
+def test_fused_combine_equals_two_launch_product(D, L, N, monkeypatch):
+    """wr_spmm_csr_chunked_fused (the last chunk of a cut row to finish adds the row's partials, one launch) leaves the bits
+    of the chunk + combine launches: products repeated on the same counters, with the layer sum started from the input
+    and scaled, hub rows of hundreds of chunks"""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(D + L)
+    deg = np.minimum((rng.pareto(0.8, N) * 20).astype(np.int64), N - 1)
+    deg[3] = 0; deg[4] = L; deg[9] = L + 1; deg[11] = N - 1
+    rp = np.zeros(N + 1, np.int64); np.cumsum(deg, out=rp[1:])
+    col = np.concatenate([np.sort(rng.choice(N, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.standard_normal(len(col)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    cptr, crow = hip_ops.spmm_chunks(rp, L)
+    cptr, crow, col, val = cptr.to(dev), crow.to(dev), t(col), t(val)
+    X = t(rng.standard_normal((N, D)).astype(np.float32))
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(hip_ops, "SPMM_FUSED_COMBINE", fused)
+        acc = torch.empty(N, D, device=dev)
+        cur, ys = X, []
+        for layer in range(3):                         # a propagation: the layer sum starts from the input, ends scaled
+            cur = hip_ops.spmm_csr_chunked(cptr, crow, col, val, cur, acc=acc, levels=1, acc_from_x=layer == 0,
+                                           acc_scale=0.25 if layer == 2 else 1.0)
+            ys.append(cur)
+        outs[fused] = ys + [acc, hip_ops.spmm_csr_chunked(cptr, crow, col, val, X, levels=1)]
+    assert hasattr(crow, "_wr_fuse") and not crow._wr_fuse[1].any()      # the counters are back at zero
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)

@@ -138,6 +138,9 @@ SIGNATURES = {
     "wr_spmm_dense_tiles": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "wr_spmm_csr_chunked_levels": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                            c_i32, c_f32, c_vp]),
+    "wr_spmm_fused_supported": (c_i32, [c_i32, c_vp]),
+    "wr_spmm_csr_chunked_fused": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                          c_f32, c_vp, c_vp]),
     "wr_spmm_csr_chunked_modes": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_axpy": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_i32, c_vp]),
     "wr_rank_eval": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),

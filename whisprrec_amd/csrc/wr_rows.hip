@@ -498,6 +498,41 @@ __device__ __forceinline__ void acc_update(float *__restrict__ acc, const float 
     store_row<T, NV, FULL>(acc, row, D, lane, a);
 }
 
+// Rows cut into several chunks are put together in two levels, so that a hub row with hundreds of chunks is not one team's
+// chain of hundreds of dependent adds.  Level 1: inside every aligned group of kGroup chunk slots, the first chunk of a row
+// adds that row's other chunks of the group into its own partial (in place; the groups' segments are disjoint).  Level 2: the
+// row's head adds the group leaders (its own partial, then the ones at the following group boundaries) and writes the row.
+// Fixed order, no atomics.
+constexpr int kGroup = 16;
+
+#ifndef WR_SPMM_COMBINE_FLY
+#define WR_SPMM_COMBINE_FLY 8
+#endif
+template <int T, int NV, bool FULL>
+__device__ __forceinline__ Row<NV> sum_partials(const float *__restrict__ partials, const int *__restrict__ chunk_row, int row,
+                                                int first, int next, int step, int end, int D, int lane) {
+    Row<NV> s = load_row<T, NV, FULL>(partials, first, D, lane);
+    constexpr int kFly = WR_SPMM_COMBINE_FLY;   // partial rows in flight per trip, added in order
+    for (int j = next; j < end && chunk_row[j] == row; j += kFly * step) {
+        Row<NV> x[kFly];
+        bool ok[kFly];
+#pragma unroll
+        for (int f = 0; f < kFly; ++f) ok[f] = j + f * step < end && chunk_row[j + f * step] == row;
+#pragma unroll
+        for (int f = 0; f < kFly; ++f)
+            if (ok[f]) x[f] = load_row<T, NV, FULL>(partials, j + f * step, D, lane);
+#pragma unroll
+        for (int f = 0; f < kFly; ++f) {
+            if (!ok[f]) continue;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                s.v[q].x += x[f].v[q].x; s.v[q].y += x[f].v[q].y; s.v[q].z += x[f].v[q].z; s.v[q].w += x[f].v[q].w;
+            }
+        }
+    }
+    return s;
+}
+
 #ifndef WR_SPMM_FLY
 #define WR_SPMM_FLY 8
 #endif
@@ -505,14 +540,21 @@ __device__ __forceinline__ void acc_update(float *__restrict__ acc, const float 
 // then one trip per round), not by L2 bandwidth: A/B on the ml-1m-shaped graph (scripts/ab_spmm.py), 4 -> 8 per round.
 constexpr int kSpmmFly = (WR_SPMM_FLY);
 
-template <int T, int NV, bool FULL>
+// FUSE: no combine launch.  A chunk of a row cut into several stores its partial write-through, waits for the store and
+// counts itself in at the row's counter; the team that arrives last (the count tells it) makes the other teams' partials
+// visible with one agent-scope acquire and adds all the row's partials in chunk order — the bits of spmm_combine_kernel<ONE>,
+// whoever does it — then zeroes the counter for the next product.  Needs rows of whole 128-byte lines (D % 32 == 0): a
+// partial row shares no line with another team's.  row_span[2r], row_span[2r + 1]: first chunk and number of chunks of row r.
+template <int T, int NV, bool FULL, bool FUSE = false>
 __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const int64_t *__restrict__ chunk_ptr,
                                                              const int *__restrict__ chunk_row, const int *__restrict__ col,
                                                              const float *__restrict__ val, const float *__restrict__ X, int D,
                                                              float *__restrict__ Y, float *__restrict__ acc,
                                                              float *__restrict__ partials,
                                                              const signed char *__restrict__ row_mode,
-                                                             const float *__restrict__ acc_src, float acc_scale) {
+                                                             const float *__restrict__ acc_src, float acc_scale,
+                                                             const int *__restrict__ row_span = nullptr,
+                                                             unsigned *__restrict__ counters = nullptr) {
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int c = blockIdx.x * TEAMS + threadIdx.x / T;
@@ -563,8 +605,22 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
         }
     }
     if (multi) {
-        store_row<T, NV, FULL>(partials, c, D, lane, s);
-        return;
+        if constexpr (FUSE) {
+            const int first = row_span[2 * row], cnt = row_span[2 * row + 1];
+            store_row_wt<T, NV, FULL>(partials, c, D, lane, s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through stores of this wave have left
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(counters + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __shfl(old, 0, T);
+            if ((int)old != cnt - 1) return;                     // every team of the row leaves here but the last to arrive
+            if (lane == 0) __hip_atomic_store(counters + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s = sum_partials<T, NV, FULL>(partials, chunk_row, row, first, first + 1, 1, n_chunks, D, lane);
+        } else {
+            store_row<T, NV, FULL>(partials, c, D, lane, s);
+            return;
+        }
     }
     if (mode == 1) {
         const Row<NV> y0 = load_row<T, NV, FULL>(Y, row, D, lane);
@@ -575,41 +631,6 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(int n_chunks, const 
     }
     store_row<T, NV, FULL>(Y, row, D, lane, s);
     if (acc != nullptr) acc_update<T, NV, FULL>(acc, acc_src, acc_scale, row, D, lane, s);
-}
-
-// Rows cut into several chunks are put together in two levels, so that a hub row with hundreds of chunks is not one team's
-// chain of hundreds of dependent adds.  Level 1: inside every aligned group of kGroup chunk slots, the first chunk of a row
-// adds that row's other chunks of the group into its own partial (in place; the groups' segments are disjoint).  Level 2: the
-// row's head adds the group leaders (its own partial, then the ones at the following group boundaries) and writes the row.
-// Fixed order, no atomics.
-constexpr int kGroup = 16;
-
-#ifndef WR_SPMM_COMBINE_FLY
-#define WR_SPMM_COMBINE_FLY 8
-#endif
-template <int T, int NV, bool FULL>
-__device__ __forceinline__ Row<NV> sum_partials(const float *__restrict__ partials, const int *__restrict__ chunk_row, int row,
-                                                int first, int next, int step, int end, int D, int lane) {
-    Row<NV> s = load_row<T, NV, FULL>(partials, first, D, lane);
-    constexpr int kFly = WR_SPMM_COMBINE_FLY;   // partial rows in flight per trip, added in order
-    for (int j = next; j < end && chunk_row[j] == row; j += kFly * step) {
-        Row<NV> x[kFly];
-        bool ok[kFly];
-#pragma unroll
-        for (int f = 0; f < kFly; ++f) ok[f] = j + f * step < end && chunk_row[j + f * step] == row;
-#pragma unroll
-        for (int f = 0; f < kFly; ++f)
-            if (ok[f]) x[f] = load_row<T, NV, FULL>(partials, j + f * step, D, lane);
-#pragma unroll
-        for (int f = 0; f < kFly; ++f) {
-            if (!ok[f]) continue;
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                s.v[q].x += x[f].v[q].x; s.v[q].y += x[f].v[q].y; s.v[q].z += x[f].v[q].z; s.v[q].w += x[f].v[q].w;
-            }
-        }
-    }
-    return s;
 }
 
 template <int T, int NV, bool FULL>
@@ -1100,6 +1121,39 @@ int32_t wr_spmm_csr_chunked_levels(int64_t n_rows, int64_t n_chunks, const int64
                                    float acc_scale, void *stream_) {
     return spmm_chunked_impl(n_rows, n_chunks, chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials,
                              reinterpret_cast<const signed char *>(row_mode), stream_, (int)levels, acc_from_x != 0, acc_scale);
+}
+
+int32_t wr_spmm_fused_supported(int32_t D, const float *partials) {
+    return (D >= 32 && D % 32 == 0 && partials != nullptr && (reinterpret_cast<uintptr_t>(partials) & 127) == 0) ? 1 : 0;
+}
+
+int32_t wr_spmm_csr_chunked_fused(int64_t n_rows, int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row,
+                                  const int32_t *row_span, const int32_t *col, const float *val, const float *X, int32_t D,
+                                  float *Y, float *acc, float *partials, const int8_t *row_mode, int32_t acc_from_x,
+                                  float acc_scale, uint32_t *counters, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(X, n_rows, D, "X")) != WR_OK) return rc;
+    if ((rc = check_table(Y, n_rows, D, "Y")) != WR_OK) return rc;
+    WR_REQUIRE(chunk_ptr && chunk_row && row_span && col && val && partials && counters, WR_E_NULL,
+               "chunked CSR arrays, row_span and counters must not be NULL");
+    WR_REQUIRE(n_chunks >= n_rows && n_chunks < (int64_t(1) << 31), WR_E_SHAPE, "every row needs at least one chunk");
+    WR_REQUIRE(X != Y, WR_E_SHAPE, "spmm: X and Y must not alias");
+    WR_REQUIRE(wr_spmm_fused_supported(D, partials), WR_E_SHAPE,
+               "fused combine: rows must be whole 128-byte lines (D %% 32 == 0, partials 128-byte aligned); D=%d", D);
+    WR_REQUIRE(acc == nullptr || aligned16(acc), WR_E_ALIGN, "acc not 16-byte aligned");
+    WR_REQUIRE(!acc_from_x || (acc != nullptr && acc != X), WR_E_SHAPE, "acc_from_x needs an acc buffer other than X");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int tpb = teams_per_block_for(D);
+    const unsigned grid = (unsigned)((n_chunks + tpb - 1) / tpb);
+    const float *acc_src = acc_from_x ? X : nullptr;
+    const signed char *rm = reinterpret_cast<const signed char *>(row_mode);
+#define WR_CALL_MF(T_, NV_, FULL_)                                                                                       \
+    hipLaunchKernelGGL((spmm_chunk_kernel<T_, NV_, FULL_, true>), dim3(grid), dim3(kBlock), 0, stream, (int)n_chunks,      \
+                       chunk_ptr, chunk_row, col, val, X, D, Y, acc, partials, rm, acc_src, acc_scale, row_span, counters)
+    WR_DISPATCH_D(D, WR_CALL_MF);
+#undef WR_CALL_MF
+    WR_LAUNCH_CHECK("spmm_chunk_kernel (fused combine)");
+    return WR_OK;
 }
 
 int32_t wr_axpy(float *y, const float *x, int64_t numel, float alpha, int32_t overwrite, void *stream_) {

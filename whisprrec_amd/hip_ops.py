@@ -1596,6 +1596,12 @@ def spmm_csr(row_ptr, col, val, X, Y=None, acc=None):
 
 SPMM_CHUNK_NNZ = 96              # non-zeros per chunk of the load-balanced CSR product
 SPMM_ONE_LEVEL_MAX_CHUNKS = 48   # one combine level while no row has more chunks than this
+SPMM_FUSED_COMBINE = False       # True: one-level products in ONE launch (wr_spmm_csr_chunked_fused: the last chunk of a cut
+                                 # row to finish combines; D % 32 == 0).  Same bits; measured, not adopted: every chunk of a cut
+                                 # row waits for its write-through store and for a returning atomic (~3 us of a wave's ~8 us
+                                 # life).  ml-1m-shaped graphs, us per product fused / two launches: 1.41 M non-zeros, chunks of
+                                 # 64 / 96 / 128 / 192: 63.4 / 38.7, 48.7 / 34.4, 43.2 / 37.7, 42.5 / 48.1; 0.71 M non-zeros
+                                 # (C3 epoch): 35.0 against 35.8 ms per epoch (scripts/exp/spmm_fused_ab.py)
 
 
 def spmm_chunks(row_ptr, max_nnz=SPMM_CHUNK_NNZ):
@@ -1648,10 +1654,22 @@ def spmm_csr_chunked(chunk_ptr, chunk_row, col, val, X, Y=None, acc=None, partia
         Y = torch.empty_like(X)
     if partials is None:
         partials = torch.empty((chunk_row.numel(), X.shape[1]), dtype=torch.float32, device=X.device)
+    lv = spmm_levels_of(chunk_row) if levels is None else int(levels)
+    if SPMM_FUSED_COMBINE and lv == 1 and X.shape[1] % 32 == 0 and partials.data_ptr() % 128 == 0:
+        # one launch: the last chunk of a cut row to finish adds the row's partials (wr_spmm_csr_chunked_fused)
+        st = getattr(chunk_row, "_wr_fuse", None)
+        if st is None:
+            per = torch.bincount(chunk_row.long(), minlength=X.shape[0])
+            span = torch.stack([torch.cumsum(per, 0) - per, per], dim=1).to(torch.int32).reshape(-1).contiguous()
+            st = chunk_row._wr_fuse = (span, torch.zeros(X.shape[0], dtype=torch.int32, device=X.device))
+        abi.check(abi.lib().wr_spmm_csr_chunked_fused(X.shape[0], chunk_row.numel(), _p(chunk_ptr), _p(chunk_row), _p(st[0]),
+                                                      _p(col), _p(val), _p(X), X.shape[1], _p(Y), _p(acc), _p(partials), None,
+                                                      1 if acc_from_x else 0, float(acc_scale), _p(st[1]), _stream()),
+                  "wr_spmm_csr_chunked_fused")
+        return Y
     abi.check(abi.lib().wr_spmm_csr_chunked_levels(X.shape[0], chunk_row.numel(), _p(chunk_ptr), _p(chunk_row), _p(col),
                                                    _p(val), _p(X), X.shape[1], _p(Y), _p(acc), _p(partials), None,
-                                                   spmm_levels_of(chunk_row) if levels is None else int(levels),
-                                                   1 if acc_from_x else 0, float(acc_scale), _stream()),
+                                                   lv, 1 if acc_from_x else 0, float(acc_scale), _stream()),
               "wr_spmm_csr_chunked_levels")
     return Y
 
