@@ -150,12 +150,32 @@ __device__ __forceinline__ void adam_load_caught_up(const float *__restrict__ W,
 // (constants through scalar loads), the wave spends sum(gaps) single-element iterations instead of 4 * max(gaps), and the
 // transpose back restores the team layout.  Every element goes through exactly the same operations in the same order:
 // the same bits.  Must be called by all 64 lanes (teams without a row pass from = t - 1: nothing to replay).
+#ifndef WR_TRANSPOSE_SHFL
+#define WR_TRANSPOSE_SHFL 0     // 1: the butterfly through ds_bpermute (the form before the gfx950 lane swaps; A/B runs)
+#endif
 __device__ __forceinline__ void wave_transpose4(float4 &x, bool a0, bool a1) {
+#if WR_TRANSPOSE_SHFL
     float s, r;
     s = a0 ? x.x : x.y; r = __shfl_xor(s, 16, 64); if (a0) x.x = r; else x.y = r;
     s = a0 ? x.z : x.w; r = __shfl_xor(s, 16, 64); if (a0) x.z = r; else x.w = r;
     s = a1 ? x.x : x.z; r = __shfl_xor(s, 32, 64); if (a1) x.x = r; else x.z = r;
     s = a1 ? x.y : x.w; r = __shfl_xor(s, 32, 64); if (a1) x.y = r; else x.w = r;
+#else
+    // gfx950 lane swaps, one VALU instruction per exchange and no LDS crossbar: v_permlane16_swap(a, b) swaps the odd
+    // 16-lane rows of a with the even rows of b, v_permlane32_swap(a, b) the upper 32 lanes of a with the lower 32 of b —
+    // exactly the two butterfly stages (scripts/exp/permlane_probe.hip prints what they do)
+    (void)a0; (void)a1;
+    auto swap16 = [](float &a, float &b) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+    };
+    auto swap32 = [](float &a, float &b) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+    };
+    swap16(x.x, x.y); swap16(x.z, x.w);
+    swap32(x.x, x.z); swap32(x.y, x.w);
+#endif
 }
 
 template <int NV>
