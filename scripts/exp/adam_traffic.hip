@@ -6,6 +6,8 @@
 extern "C" __global__ __launch_bounds__(256) void adam_traffic(float4 *Wu, float4 *Mu, float4 *Vu, float4 *Wi, float4 *Mi, float4 *Vi,
                                                                int *lastU, int *lastI, const int *u, const int *p, const int *n,
                                                                int B, int stamps, int t) {
+    extern __shared__ int occupancy_limiter[];      // dynamic LDS only limits the workgroups per CU
+    if (B < 0) occupancy_limiter[threadIdx.x] = 1;
     const int lane = threadIdx.x & 15, team = (blockIdx.x * 256 + threadIdx.x) >> 4;
     if (team >= B) return;
     const int64_t ru = (int64_t)u[team] * 16 + lane, rp = (int64_t)p[team] * 16 + lane, rn = (int64_t)n[team] * 16 + lane;
@@ -18,8 +20,8 @@ extern "C" __global__ __launch_bounds__(256) void adam_traffic(float4 *Wu, float
     if (stamps && lane == 0) { lastU[u[team]] = t; lastI[p[team]] = t; lastI[n[team]] = t; }
 }
 extern "C" void run(void *Wu, void *Mu, void *Vu, void *Wi, void *Mi, void *Vi, void *lastU, void *lastI, const void *u,
-                    const void *p, const void *n, int B, int stamps, int t, void *stream) {
-    hipLaunchKernelGGL(adam_traffic, dim3((B * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)Wu, (float4 *)Mu,
+                    const void *p, const void *n, int B, int stamps, int t, int lds_bytes, void *stream) {
+    hipLaunchKernelGGL(adam_traffic, dim3((B * 16 + 255) / 256), dim3(256), lds_bytes, (hipStream_t)stream, (float4 *)Wu, (float4 *)Mu,
                        (float4 *)Vu, (float4 *)Wi, (float4 *)Mi, (float4 *)Vi, (int *)lastU, (int *)lastI, (const int *)u,
                        (const int *)p, (const int *)n, B, stamps, t);
 }

@@ -18,9 +18,9 @@ for k in range(NL):
     u = np.sort(rng.permutation(nU)[:B]).astype(np.int32)
     items = rng.permutation(nI)[:2 * B].astype(np.int32)
     batches.append(tuple(torch.from_numpy(x).to(dev) for x in (u, items[:B], items[B:])))
-for stamps in (0, 1):
+for stamps, lds in ((0, 0), (1, 0), (1, 20 * 1024), (1, 32 * 1024), (1, 40 * 1024)):   # LDS per workgroup limits the waves per SIMD: 8 / 8 / 8 / 5 / 4
     def launch(b, t):
-        lib.run(*[P(x) for x in tabs], P(lastU), P(lastI), P(b[0]), P(b[1]), P(b[2]), B, stamps, t, st)
+        lib.run(*[P(x) for x in tabs], P(lastU), P(lastI), P(b[0]), P(b[1]), P(b[2]), B, stamps, t, lds, st)
     for b in batches[:4]: launch(b, 1)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,4 +31,4 @@ for stamps in (0, 1):
     t = e0.elapsed_time(e1) / (3 * NL) * 1e-3
     byts = B * (18 * 256 + (24 if stamps else 0) + 12)
     print(json.dumps({"case": "traffic-only: 9 random 256-B rows in + 9 out per triplet over six 1M-row tables%s" % (", + 3 stamps read and written" if stamps else ""),
-                      "us_per_launch": round(t * 1e6, 2), "GBs": round(byts / t / 1e9, 1), "frac_of_8TBs": round(byts / t / 8e12, 3)}))
+                      "lds_per_workgroup": lds, "us_per_launch": round(t * 1e6, 2), "GBs": round(byts / t / 1e9, 1), "frac_of_8TBs": round(byts / t / 8e12, 3)}))

@@ -30,6 +30,9 @@
 #ifndef WR_USER_WAVES
 #define WR_USER_WAVES 8      // waves per SIMD the headline instantiation of the user phase is held to (64 VGPRs)
 #endif
+#ifndef WR_ADAM_DBG
+#define WR_ADAM_DBG 0        // timing-only variants of the folded Adam step (A/B builds): 1 no replay, 2 transposes but no replay loops
+#endif
 #ifndef WR_ADAM_WAVES
 #define WR_ADAM_WAVES 5      // the same for the folded-Adam instantiation (MODE 4): 96 VGPRs + 8 spilled; A/B on MI355X, us per
                              // step at 1M x 1M x 64, B = 65,536: unconstrained (103 VGPRs, 4 waves) 107-111, 5 waves 104-106,
@@ -185,6 +188,9 @@ __device__ __forceinline__ void adam_replay_balanced(Row<NV> &w, Row<NV> &m, Row
     const int f0 = __builtin_amdgcn_readlane(from, 0), f1 = __builtin_amdgcn_readlane(from, 16),
               f2 = __builtin_amdgcn_readlane(from, 32), f3 = __builtin_amdgcn_readlane(from, 48);
     if (f0 + 1 >= a.t && f1 + 1 >= a.t && f2 + 1 >= a.t && f3 + 1 >= a.t) return;   // uniform: nothing missed anywhere
+#if WR_ADAM_DBG & 1
+    return;                                 // timing only: no replay at all (wrong tables; no index depends on the replay)
+#endif
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         wave_transpose4(w.v[q], a0, a1);
@@ -207,10 +213,12 @@ __device__ __forceinline__ void adam_replay_balanced(Row<NV> &w, Row<NV> &m, Row
         }
         for (; s < a.t; ++s) replay(c2[s]);
     };
+#if !(WR_ADAM_DBG & 2)
     run(f0, [](float4 &x) -> float & { return x.x; });
     run(f1, [](float4 &x) -> float & { return x.y; });
     run(f2, [](float4 &x) -> float & { return x.z; });
     run(f3, [](float4 &x) -> float & { return x.w; });
+#endif
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         wave_transpose4(w.v[q], a0, a1);
