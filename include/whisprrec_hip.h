@@ -84,9 +84,12 @@ int32_t wr_bprmf_plan_build_i32(const int32_t *u, const int32_t *p, const int32_
                                 void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Small batches (batch_size <= wr_bprmf_plan_small_max_batch() = 4,096; the reference's default is 2,048): the plan of a
- * batch is built by ONE workgroup in LDS (two bitonic sorts of unique composites), one launch for all batches, no workspace,
- * nothing to read back but err_flag — the builder of the LightGCN step (a plan per optimizer step, hipGraph-capturable).
- * Arrays identical to wr_bprmf_plan_build_*'s, bit for bit. */
+ * batch is built by ONE workgroup in LDS, one launch for all batches, no workspace, nothing to read back but err_flag — the
+ * builder of the LightGCN step (a plan per optimizer step, hipGraph-capturable).  Tables small enough for one LDS counter
+ * per row (8 * max(n_users, n_items) + 16 * P bytes <= 128 KB, P = batch size rounded up to a power of two: ml-scale) take a
+ * counting sort (count, scan, scatter, order every row's segment by position); the others two bitonic sorts of unique
+ * composites.  Either way the arrays are wr_bprmf_plan_build_*'s, bit for bit.  WR_PLAN_SMALL=bitonic in the environment
+ * keeps the sorting form (A/B runs). */
 int64_t wr_bprmf_plan_small_max_batch(void);
 int32_t wr_bprmf_plan_build_small_i64(const int64_t *u, const int64_t *p, const int64_t *n, int64_t n_triplets,
                                       int64_t batch_size, int64_t n_users, int64_t n_items, int32_t *tu, int32_t *tp,
