@@ -215,6 +215,18 @@ int32_t wr_epoch_prepare_range_set_i32(const int32_t *users, const int32_t *item
                                        int64_t first, int64_t count, int32_t *out_users, int32_t *out_pos, int32_t *out_neg,
                                        int64_t *order_out, int32_t *err_flag, void *stream);
 
+/* wr_epoch_prepare_range_set_* with the source rows PACKED, one 8-byte word (user << 32) | item per interaction (built once
+ * per training frame): one random memory sector per output row for the source instead of two — the kernel is bound by its
+ * random sectors (source row + membership probe).  Same columns, bit for bit. */
+int32_t wr_epoch_prepare_range_packed_i64(const uint64_t *packed_rows, int64_t n, int64_t n_users, int64_t n_items,
+                                          const uint64_t *pair_table, int64_t pair_capacity, uint64_t seed, uint64_t epoch,
+                                          int64_t first, int64_t count, int64_t *out_users, int64_t *out_pos, int64_t *out_neg,
+                                          int64_t *order_out, int32_t *err_flag, void *stream);
+int32_t wr_epoch_prepare_range_packed_i32(const uint64_t *packed_rows, int64_t n, int64_t n_users, int64_t n_items,
+                                          const uint64_t *pair_table, int64_t pair_capacity, uint64_t seed, uint64_t epoch,
+                                          int64_t first, int64_t count, int32_t *out_users, int32_t *out_pos, int32_t *out_neg,
+                                          int64_t *order_out, int32_t *err_flag, void *stream);
+
 /* Epoch shuffle on the device — the row order DataLoader(shuffle=True) gives an epoch (src/helpers/BaseRunner.py:188-193):
  * out_k[i] = col_k[perm(i)] for up to three index columns (NULL pairs are skipped), order_out[i] = perm(i) if not NULL.
  * perm is a keyed bijection of [0, n) evaluated per row (alternating Feistel network on ceil(log2 n) bits, splitmix64

@@ -27,19 +27,30 @@ for epoch in (1, 2):            # the preparation alone: lists against the hash 
         prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch, pairs=pr)
         prep.fill(0, n_inter)
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        print(json.dumps({"membership": name, "sample_negatives_ms": (t1 - t0) * 1e3, "fused_prepare_ms": (t2 - t1) * 1e3}))
+        res = {"membership": name, "sample_negatives_ms": (t1 - t0) * 1e3, "fused_prepare_ms": (t2 - t1) * 1e3}
+        if pr is not None:                                       # source rows as one word each
+            packed = hip_ops.pack_rows(users, items)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            prep2 = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch, pairs=pr, packed=packed)
+            prep2.fill(0, n_inter)
+            torch.cuda.synchronize(); t4 = time.perf_counter()
+            res["fused_prepare_packed_rows_ms"] = (t4 - t3) * 1e3
+            del prep2, packed
+        print(json.dumps(res))
         del prep, neg
-for mode in ("upfront", "pipelined", "upfront+set", "pipelined+set"):
+packed_rows = hip_ops.pack_rows(users, items)
+for mode in ("upfront", "pipelined", "upfront+set", "pipelined+set", "pipelined+set+packed"):
     for epoch in (1, 2, 3):
         losses = torch.empty(nb, dtype=torch.float32, device=dev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        pr = pairs if mode.endswith("+set") else None
+        pr = pairs if "+set" in mode else None
         if mode.startswith("upfront"):
             neg, err = hip_ops.sample_negatives(users, nU, nI, ptr, idx, 3407, epoch, pairs=pr)
             u, p, n = hip_ops.epoch_shuffle([users, items, neg], 3407, epoch)
             pipe.run(pipe.plan(U, [(I, u, p, n)], B, lr=0.05), 0, 0.05, losses)
         else:
-            prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch, pairs=pr)
+            prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch, pairs=pr,
+                                     packed=packed_rows if mode.endswith("+packed") else None)
             pipe.run(pipe.plan(U, [(I, prep.cols[0], prep.cols[1], prep.cols[2])], B, lr=0.05, prep=prep), 0, 0.05, losses)
             prep.check()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -104,6 +104,19 @@ def c2_epoch_case(n_inter=100_000_000, nU=1_000_000, nI=1_000_000, D=64, B=65536
         res = dict(sample_ms=(t1 - t0) * 1e3, shuffle_ms=(t2 - t1) * 1e3, plan_and_steps_ms=(t3 - t2) * 1e3,
                    epoch_ms=(t3 - t0) * 1e3, loss_mean=float(losses.mean()))
         del u, p, n, neg
+    # the product's form (HipRunner --device_epoch_prep 1): sampler + shuffle fused, produced chunk by chunk beside the steps,
+    # membership through the pair set, source rows packed into one word each
+    packed = hip_ops.pack_rows(users, items)
+    for epoch in (4, 5, 6):
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        prep = hip_ops.EpochPrep(users, items, nU, nI, ptr, idx, 3407, epoch, pairs=pairs, packed=packed)
+        pipe.run(pipe.plan(U, [(I, prep.cols[0], prep.cols[1], prep.cols[2])], B, prep=prep), 0, 0.05, losses)
+        prep.check()
+        torch.cuda.synchronize()
+        res["epoch_ms_fused_pipelined"] = (time.perf_counter() - t0) * 1e3
+        del prep
+    res["triplets_per_s_epoch_fused_pipelined"] = n_inter / (res["epoch_ms_fused_pipelined"] * 1e-3)
     emit(case="C2 whole epoch on the device: sampler + shuffle + plans + %d steps (1Mx1M, D=64, B=65536, %d interactions)" % (nb, n_inter),
          clicked_csr_build_once_ms=t_csr * 1e3, pair_set_build_once_ms=t_set * 1e3, triplets_per_s_epoch=n_inter / (res["epoch_ms"] * 1e-3), **res)
 

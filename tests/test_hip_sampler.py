@@ -164,9 +164,16 @@ def test_fused_range_preparation_equals_sampler_then_shuffle(dtype):
         neg_set, _ = hip_ops.sample_negatives(tu, nU, nI, None, None, 3407, epoch, pairs=pairs)
         prep_set = hip_ops.EpochPrep(tu, ti, nU, nI, None, None, 3407, epoch, want_order=True, pairs=pairs)
         prep_set.fill(0, n)
+        # ... and with the source rows packed into one word each (wr_epoch_prepare_range_packed): the same columns again
+        prep_pk = hip_ops.EpochPrep(tu, ti, nU, nI, None, None, 3407, epoch, want_order=True, pairs=pairs,
+                                    packed=hip_ops.pack_rows(tu, ti))
+        for lo, hi in ((100, n), (0, 100)):
+            prep_pk.fill(lo, hi)
         torch.cuda.synchronize()
         assert torch.equal(neg_set, neg)
         assert all(torch.equal(a, b) for a, b in zip(prep_set.cols, prep.cols)) and torch.equal(prep_set.order, prep.order)
+        assert prep_pk.packed is not None
+        assert all(torch.equal(a, b) for a, b in zip(prep_pk.cols, prep.cols)) and torch.equal(prep_pk.order, prep.order)
         assert torch.equal(prep.cols[0], su) and torch.equal(prep.cols[1], si) and torch.equal(prep.cols[2], sn)
         assert torch.equal(prep.order, order)
         prep.check()

@@ -57,6 +57,10 @@ SIGNATURES = {
                                                c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_epoch_prepare_range_set_i32": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64, c_i64,
                                                c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "wr_epoch_prepare_range_packed_i64": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64, c_i64,
+                                                  c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "wr_epoch_prepare_range_packed_i32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64, c_i64,
+                                                  c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_epoch_shuffle_i64": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_epoch_shuffle_i32": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wr_bprmf_step_workspace_bytes": (c_i64, [c_i64, c_i32]),

@@ -174,7 +174,10 @@ static int32_t epoch_shuffle(const Idx *c0, const Idx *c1, const Idx *c2, int64_
 // negative wr_sample_negatives would have drawn for row j (the generator is keyed by the source row) — bit for bit the
 // columns of wr_sample_negatives followed by wr_epoch_shuffle, without the intermediate negatives array, and chunk by
 // chunk: the step stream prepares the rows of plan chunk c+1 on the plan stream while chunk c trains.
-template <typename Idx, typename Clicked>
+// PACKED: the source rows as ONE 8-byte word each, (user << 32) | item — one random memory sector per output row where the
+// two columns cost two (the kernel is bound by its random sectors: source row(s) + the membership probe); `users` then
+// points to the packed words and `items` is not read.
+template <typename Idx, typename Clicked, bool PACKED = false>
 __global__ __launch_bounds__(kBlock) void epoch_prepare_range_kernel(const Idx *__restrict__ users, const Idx *__restrict__ items,
                                                                       int64_t n, int64_t n_users, uint32_t n_items, Clicked cl,
                                                                       uint64_t seed, uint64_t epoch, unsigned bits, uint64_t key,
@@ -184,7 +187,15 @@ __global__ __launch_bounds__(kBlock) void epoch_prepare_range_kernel(const Idx *
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= count) return;
     const int64_t j = (int64_t)shuffle_index((uint64_t)(first + k), (uint64_t)n, bits, key);
-    const Idx uj = users[j];
+    Idx uj, ij;
+    if constexpr (PACKED) {
+        const unsigned long long w = reinterpret_cast<const unsigned long long *>(users)[j];
+        uj = (Idx)(int32_t)(uint32_t)(w >> 32);
+        ij = (Idx)(int32_t)(uint32_t)w;
+    } else {
+        uj = users[j];
+        ij = items[j];
+    }
     int64_t u = (int64_t)uj;
     if (u < 0 || u >= n_users) {
         if (err) *err = 1;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void epoch_prepare_range_kernel(const Idx *
     }
     const uint32_t cand = draw_negative(cl, u, seed, epoch, (uint64_t)j, n_items, err);
     out_u[k] = uj;
-    out_p[k] = items[j];
+    out_p[k] = ij;
     out_n[k] = (Idx)cand;
     if (order) order[k] = j;
 }
@@ -206,8 +217,9 @@ static int32_t epoch_prepare_range(const Idx *users, const Idx *items, int64_t n
                                    const int64_t *clicked_ptr, const int32_t *clicked_idx, uint64_t seed, uint64_t epoch,
                                    int64_t first, int64_t count, Idx *out_u, Idx *out_p, Idx *out_n, int64_t *order,
                                    int32_t *err_flag, void *stream, const uint64_t *pair_table = nullptr,
-                                   int64_t pair_capacity = 0) {
-    WR_REQUIRE(users && items && out_u && out_p && out_n, WR_E_NULL, "epoch prepare: NULL argument");
+                                   int64_t pair_capacity = 0, bool packed = false) {
+    WR_REQUIRE(users && (items || packed) && out_u && out_p && out_n, WR_E_NULL, "epoch prepare: NULL argument");
+    WR_REQUIRE(!packed || pair_table != nullptr, WR_E_NULL, "epoch prepare: packed source rows go with a pair set");
     WR_REQUIRE((clicked_ptr && clicked_idx) || pairset_ok(pair_table, pair_capacity), WR_E_NULL,
                "epoch prepare: needs the clicked lists or a pair set (capacity a power of two)");
     WR_REQUIRE(n > 0 && n < (int64_t(1) << 62) && n_users > 0 && n_items >= 2 && n_items < (int64_t(1) << 31), WR_E_SHAPE,
@@ -217,7 +229,12 @@ static int32_t epoch_prepare_range(const Idx *users, const Idx *items, int64_t n
     if (count == 0) return WR_OK;
     const uint64_t key = mix64(mix64(seed ^ (epoch * 0x9E3779B97F4A7C15ull)) ^ 0x5DEECE66Dull);
     const dim3 grid((unsigned)((count + kBlock - 1) / kBlock));
-    if (pair_table != nullptr)
+    if (packed)
+        hipLaunchKernelGGL((epoch_prepare_range_kernel<Idx, ClickedPairs, true>), grid, dim3(kBlock), 0,
+                           reinterpret_cast<hipStream_t>(stream), users, items, n, n_users, (uint32_t)n_items,
+                           ClickedPairs{reinterpret_cast<const unsigned long long *>(pair_table), (uint64_t)pair_capacity - 1},
+                           seed, epoch, shuffle_bits(n), key, first, count, out_u, out_p, out_n, order, err_flag);
+    else if (pair_table != nullptr)
         hipLaunchKernelGGL((epoch_prepare_range_kernel<Idx, ClickedPairs>), grid, dim3(kBlock), 0,
                            reinterpret_cast<hipStream_t>(stream), users, items, n, n_users, (uint32_t)n_items,
                            ClickedPairs{reinterpret_cast<const unsigned long long *>(pair_table), (uint64_t)pair_capacity - 1},
@@ -349,6 +366,26 @@ int32_t wr_epoch_prepare_range_set_i32(const int32_t *users, const int32_t *item
     WR_REQUIRE(pair_table != nullptr, WR_E_NULL, "epoch prepare: pair set is NULL");
     return epoch_prepare_range<int32_t>(users, items, n, n_users, n_items, nullptr, nullptr, seed, epoch, first, count, out_users,
                                         out_pos, out_neg, order_out, err_flag, stream, pair_table, pair_capacity);
+}
+
+int32_t wr_epoch_prepare_range_packed_i64(const uint64_t *packed_rows, int64_t n, int64_t n_users, int64_t n_items,
+                                          const uint64_t *pair_table, int64_t pair_capacity, uint64_t seed, uint64_t epoch,
+                                          int64_t first, int64_t count, int64_t *out_users, int64_t *out_pos, int64_t *out_neg,
+                                          int64_t *order_out, int32_t *err_flag, void *stream) {
+    WR_REQUIRE(packed_rows != nullptr && pair_table != nullptr, WR_E_NULL, "epoch prepare: packed rows / pair set is NULL");
+    return epoch_prepare_range<int64_t>(reinterpret_cast<const int64_t *>(packed_rows), nullptr, n, n_users, n_items, nullptr,
+                                        nullptr, seed, epoch, first, count, out_users, out_pos, out_neg, order_out, err_flag,
+                                        stream, pair_table, pair_capacity, true);
+}
+
+int32_t wr_epoch_prepare_range_packed_i32(const uint64_t *packed_rows, int64_t n, int64_t n_users, int64_t n_items,
+                                          const uint64_t *pair_table, int64_t pair_capacity, uint64_t seed, uint64_t epoch,
+                                          int64_t first, int64_t count, int32_t *out_users, int32_t *out_pos, int32_t *out_neg,
+                                          int64_t *order_out, int32_t *err_flag, void *stream) {
+    WR_REQUIRE(packed_rows != nullptr && pair_table != nullptr, WR_E_NULL, "epoch prepare: packed rows / pair set is NULL");
+    return epoch_prepare_range<int32_t>(reinterpret_cast<const int32_t *>(packed_rows), nullptr, n, n_users, n_items, nullptr,
+                                        nullptr, seed, epoch, first, count, out_users, out_pos, out_neg, order_out, err_flag,
+                                        stream, pair_table, pair_capacity, true);
 }
 
 int32_t wr_epoch_prepare_range_i64(const int64_t *users, const int64_t *items, int64_t n, int64_t n_users, int64_t n_items,

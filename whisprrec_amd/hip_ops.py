@@ -874,7 +874,10 @@ class EpochPrep:
     calls it for each plan chunk right before that chunk's plan build, on the plan stream: the preparation of chunk c+1 runs
     beside the steps of chunk c."""
 
-    def __init__(self, users, items, n_users, n_items, clicked_ptr, clicked_idx, seed, epoch, want_order=False, pairs=None):
+    def __init__(self, users, items, n_users, n_items, clicked_ptr, clicked_idx, seed, epoch, want_order=False, pairs=None,
+                 packed=None):
+        """pairs: pair_set(...) — membership through the hash set; packed: pack_rows(users, items) — with a pair set, the
+        source rows are read as one 8-byte word each (one random sector per output row instead of two; same columns)"""
         if users.dtype not in (torch.int64, torch.int32) or items.dtype != users.dtype:
             raise TypeError("users / items must both be int64 or int32")
         self.users = _req(users.contiguous(), users.dtype, "users", 1)
@@ -886,6 +889,11 @@ class EpochPrep:
             _req(clicked_idx, torch.int32, "clicked_idx", 1)
         self.ptr, self.idx = clicked_ptr, clicked_idx
         self.pairs = None if pairs is None else _req(pairs, torch.int64, "pairs", 1)     # pair_set(...): hash-set membership
+        self.packed = None
+        if packed is not None and pairs is not None:
+            self.packed = _req(packed, torch.int64, "packed", 1)
+            if self.packed.numel() != self.users.numel():
+                raise ValueError("packed rows: one word per interaction")
         self.n, self.n_users, self.n_items = users.numel(), int(n_users), int(n_items)
         self.seed, self.epoch = int(seed), int(epoch)
         self.cols = [torch.empty_like(self.users) for _ in range(3)]
@@ -902,7 +910,11 @@ class EpochPrep:
         tail = (self.seed, self.epoch, lo, hi - lo, self.cols[0].data_ptr() + es * lo, self.cols[1].data_ptr() + es * lo,
                 self.cols[2].data_ptr() + es * lo, None if self.order is None else self.order.data_ptr() + 8 * lo,
                 _p(self.err), _stream())
-        if self.pairs is not None:
+        if self.packed is not None:
+            fn = L.wr_epoch_prepare_range_packed_i64 if self.users.dtype == torch.int64 else L.wr_epoch_prepare_range_packed_i32
+            abi.check(fn(_p(self.packed), self.n, self.n_users, self.n_items, _p(self.pairs), self.pairs.numel(), *tail),
+                      "wr_epoch_prepare_range_packed")
+        elif self.pairs is not None:
             fn = L.wr_epoch_prepare_range_set_i64 if self.users.dtype == torch.int64 else L.wr_epoch_prepare_range_set_i32
             abi.check(fn(_p(self.users), _p(self.items), self.n, self.n_users, self.n_items, _p(self.pairs), self.pairs.numel(),
                          *tail), "wr_epoch_prepare_range_set")
@@ -916,6 +928,11 @@ class EpochPrep:
         """after the epoch (one read-back): nn.Embedding would have raised IndexError for an out-of-range user id"""
         if int(self.err.item()) == 1:
             raise IndexError("user id out of range in the training frame")
+
+
+def pack_rows(users, items):
+    """the training frame's (user, item) rows as one int64 word each, (user << 32) | item (EpochPrep(packed=...)); ids < 2^31"""
+    return ((users.to(torch.int64) << 32) | items.to(torch.int64)).contiguous()
 
 
 def clicked_csr_from_pairs(users, items, n_users, n_items):

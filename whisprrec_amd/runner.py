@@ -289,14 +289,16 @@ def make_hip_runner(base_runner_cls):
                 ptr, idx = hip_ops.clicked_csr(corpus.train_clicked_set, model.user_num, dev)
                 # big frames: membership tests through a hash set of the pairs (one sector per test instead of a binary search)
                 pairs = hip_ops.pair_set(ptr, idx, model.user_num) if idx.numel() >= hip_ops.PAIR_SET_MIN_PAIRS else None
-                self._epoch_cache = (dataset, users, items, ptr, idx, pairs)
-            _, users, items, ptr, idx, pairs = self._epoch_cache
+                # ... and the source rows as one word each: one random sector per output row instead of two
+                packed = hip_ops.pack_rows(users, items) if pairs is not None else None
+                self._epoch_cache = (dataset, users, items, ptr, idx, pairs, packed)
+            _, users, items, ptr, idx, pairs, packed = self._epoch_cache
             # the epoch's rows in batch order: a keyed bijection of the rows (no 100 M-key sort as in torch.randperm) and the
             # negative of every row, fused and produced range by range (wr_epoch_prepare_range) — a model with a native epoch
             # loop gets the EpochPrep itself and fills each plan chunk's rows beside the previous chunk's steps
             sequential = "position" in dataset.data
             prep = hip_ops.EpochPrep(users, items, model.user_num, model.item_num, ptr, idx, self.seed, max(epoch, 0),
-                                     want_order=sequential, pairs=pairs)
+                                     want_order=sequential, pairs=pairs, packed=packed)
             self._epoch_prep = prep
             if pipelined:
                 return prep
