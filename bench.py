@@ -57,6 +57,10 @@ def parse(argv=None):
                          "step stream between the halves of the current chunk (measured slower; kept for the A/B)")
     ap.add_argument("--no-adam", action="store_true",
                     help="N=1: skip the Adam figure reported under `extra` (the reference's default optimizer on the same shape)")
+    ap.add_argument("--no-epoch", action="store_true",
+                    help="N=1: skip the whole-epoch figure reported under `extra` (negative sampling + shuffle + plans + steps)")
+    ap.add_argument("--epoch-interactions", type=int, default=100_000_000,
+                    help="N=1: interactions of the synthetic training frame of the whole-epoch figure")
     ap.add_argument("--no-chain", action="store_true",
                     help="N=1: two launches per step (user phase, item phase) instead of the chained step launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -362,6 +366,9 @@ def single_gpu(args, local_rank):
            "roofline": roofline}
     if not args.no_adam:
         out["extra"] = {"adam": adam_extra(args, hip_ops, U, I, u, p, n, dev)}
+    if not args.no_epoch and not args.overlap:
+        del u, p, n
+        out.setdefault("extra", {})["epoch"] = epoch_extra(args, hip_ops, U, I, dev)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         out["cpu_baseline_torch"] = cpu_torch_sequence(args, max(4.0, args.cpu_seconds / 2))
@@ -401,6 +408,39 @@ def adam_extra(args, hip_ops, U, I, u, p, n, dev):
             "how": "exact lazy rows, catch-up %s; plan builds inside the timed region" %
                    ("folded into the step kernels' row loads" if st._folds(handle["cur"][1]) else "in a pass of its own"),
             "loss_last": float(lt[-1])}
+
+
+def epoch_extra(args, hip_ops, U, I, dev):
+    """SURVEY 8(d)'s epoch-level figure on the same tables: one WHOLE epoch of a synthetic training frame with everything
+    the reference does per epoch on the device — a negative per interaction that the user has not clicked
+    (BaseModel.py:167-177), the epoch's shuffle (BaseRunner.py:188-193), batch plans, SGD steps — as HipRunner
+    --device_epoch_prep 1 runs it: sampler + shuffle fused and produced chunk by chunk beside the steps (hip_ops.EpochPrep),
+    membership through the pair set, source rows packed.  The clicked lists / pair set / packed rows are per-frame setup
+    (built once, reported); the third epoch is the one timed."""
+    import torch
+    n_inter, B = int(args.epoch_interactions), args.batch
+    g = torch.Generator(device=dev); g.manual_seed(3409)
+    users = torch.randint(0, args.users, (n_inter,), generator=g, device=dev, dtype=torch.int32)
+    items = torch.randint(0, args.items, (n_inter,), generator=g, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ptr, idx = hip_ops.clicked_csr_from_pairs(users, items, args.users, args.items)
+    pairs = hip_ops.pair_set(ptr, idx, args.users)
+    packed = hip_ops.pack_rows(users, items)
+    torch.cuda.synchronize(); setup = time.perf_counter() - t0
+    pipe = hip_ops.PipelinedSgd(chunk=64)
+    nb = (n_inter + B - 1) // B
+    dt = 0.0
+    for epoch in (1, 2, 3):
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        prep = hip_ops.EpochPrep(users, items, args.users, args.items, ptr, idx, 3407, epoch, pairs=pairs, packed=packed)
+        pipe.run(pipe.plan(U, [(I, prep.cols[0], prep.cols[1], prep.cols[2])], B, prep=prep), 0, args.lr, losses)
+        prep.check()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        del prep
+    return {"metric": "BPR training triplets/sec over a whole epoch (negative sampling + shuffle + plans + steps on the device)",
+            "value": n_inter / dt, "unit": "triplets/s", "epoch_ms": dt * 1e3, "interactions": n_inter, "steps": nb,
+            "per_frame_setup_ms": setup * 1e3, "loss_mean": float(losses.mean())}
 
 
 # --------------------------------------------------------------------------------------------------- N > 1
