@@ -306,11 +306,15 @@ class BatchPlan:
             self.meta = arena.meta
             self.meta.zero_()
             self._pinned = arena.meta_host
+            self._unchecked = False
         else:
             self.tu, self.tp, self.tn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
             self.oc_item, self.oc_src = torch.empty(2 * N, **i32), torch.empty(2 * N, **i32)
             self._cap_batches = self.n_batches
-            self.meta = torch.zeros(self.meta_len(self.n_batches), **i32)
+            # a single-workgroup plan nobody will ask for its flags (indices range-checked by the caller, no hot-run scan):
+            # no flag words to clear — one launch less in a step that builds a plan of its own (LightGCN)
+            self._unchecked = builder == "small" and not validate and not hot and not overlap
+            self.meta = (torch.empty if self._unchecked else torch.zeros)(self.meta_len(self.n_batches), **i32)
             self._pinned = None
         self.torig = torch.empty(N, **i32) if keep_orig else None
         self.flags = self.meta[:2]
@@ -403,8 +407,8 @@ class BatchPlan:
                                                                                     L.wr_bprmf_plan_small_max_batch()))
         fn = L.wr_bprmf_plan_build_small_i64 if u.dtype == torch.int64 else L.wr_bprmf_plan_build_small_i32
         abi.check(fn(_p(u), _p(p), _p(n), self.n_triplets, self.batch_size, self.n_users, self.n_items, _p(self.tu), _p(self.tp),
-                     _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), _p(self.err), _stream()),
-                  "wr_bprmf_plan_build_small")
+                     _p(self.tn), _p(self.torig), _p(self.oc_item), _p(self.oc_src), None if self._unchecked else _p(self.err),
+                     _stream()), "wr_bprmf_plan_build_small")
         self.builder = self._tried = "small"
         self._bitmap_ready = False
         if self._want_hot:
@@ -555,6 +559,8 @@ class BatchPlan:
 
     def validate(self):
         """nn.Embedding raises IndexError for out-of-range ids; so does the plan."""
+        if self._unchecked:
+            raise abi.WhisprRecHipError("this plan was built with validate=False and keeps no index-range flag")
         self.finish()
         if self.meta_host is None:
             self.meta_host = self._read_meta()

@@ -370,14 +370,18 @@ def make_hip_runner(base_runner_cls):
                 shape = getattr(self, "_loss_shape", None)
                 root = torch.ones(shape, dtype=torch.float32, device=dev) if shape is not None else None
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    model.optimizer.zero_grad()
-                    static_loss = model.predict(batch)
-                    if root is not None and static_loss.shape == root.shape and static_loss.dtype == root.dtype:
-                        static_loss.backward(root)
-                    else:
-                        static_loss.backward()
-                    model.optimizer.step()
+                try:
+                    with torch.cuda.graph(g):
+                        model.optimizer.zero_grad()
+                        static_loss = model.predict(batch)
+                        if root is not None and static_loss.shape == root.shape and static_loss.dtype == root.dtype:
+                            model._unit_root = True      # the model's backward may skip its scale by the root gradient (ones)
+                            static_loss.backward(root)
+                        else:
+                            static_loss.backward()
+                        model.optimizer.step()
+                finally:
+                    model._unit_root = False
             except (RuntimeError, abi.WhisprRecHipError) as e:
                 # capture is an optimisation: the epoch goes on eagerly FROM THE FIRST UNTRAINED ROW.  A capture that died
                 # after the captured optimizer.step() call has bumped the host-side step count without training anything.
