@@ -72,6 +72,23 @@ def test_hip_runner_device_epoch_prep(g2):
     assert losses[-1] < losses[0] - 1e-4 and all(np.isfinite(losses))
 
 
+def test_hip_runner_device_epoch_prep_with_pair_set_and_packed_rows(g2, monkeypatch):
+    """big training frames take the hash set of the pairs and the packed source rows (hip_ops.PAIR_SET_MIN_PAIRS): the same
+    epochs, bit for bit, as the clicked lists and the two index columns give"""
+    from whisprrec_amd import runner, hip_ops
+    res = []
+    for min_pairs in (1, 1 << 40):
+        monkeypatch.setattr(hip_ops, "PAIR_SET_MIN_PAIRS", min_pairs)
+        args, corpus, model, ds = _setup(g2, device_epoch_prep=1, random_seed=3407, lr=2.0)
+        r = runner.HipRunner(args)
+        losses = [r.fit(ds, epoch=e) for e in range(1, 4)]
+        cache = r._epoch_cache
+        assert (cache[5] is not None and cache[6] is not None) == (min_pairs == 1)       # pair set, packed rows
+        res.append((losses, model.user_embeddings.weight.detach().clone(), model.item_embeddings.weight.detach().clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 @pytest.mark.parametrize("lazy", [0, 1])
 def test_hip_runner_adam_default_optimizer(g2, lazy):
     """reference default optimizer (BaseRunner.py:36), README learning rate; --lazy_optimizer 1 = exact lazy rows, read
