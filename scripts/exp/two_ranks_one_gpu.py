@@ -37,6 +37,7 @@ def worker(rank, world, port, argv):
 if __name__ == "__main__":
     import torch.multiprocessing as mp
     import bench
-    argv = ["--gpus", "2", "--steps", "20", "--warmup", "5", "--users", "200000", "--items", "200000", "--no-cpu-baseline"] + sys.argv[1:]
-    mp.spawn(worker, args=(2, bench.free_port(), argv), nprocs=2, join=True)
-    print("two ranks on one GPU: ok")
+    world = int(os.environ.get("WR_RANKS", "2"))          # at most 6 processes may share the card on the GPU pool
+    argv = ["--gpus", str(world), "--steps", "20", "--warmup", "5", "--users", "200000", "--items", "200000", "--no-cpu-baseline"] + sys.argv[1:]
+    mp.spawn(worker, args=(world, bench.free_port(), argv), nprocs=world, join=True)
+    print("%d ranks on one GPU: ok" % world)
