@@ -1,6 +1,8 @@
 """Rehearsal of bench.py's N > 1 path with TWO ranks on ONE GPU: the same bench_run functions of both sharding modes, real
 kernels, torch.distributed over gloo (RCCL refuses two ranks on one device).  Checks that every rank gets through and that
-rank 0 can build the N > 1 JSON line; the numbers mean nothing (two processes share the card, gloo stages through the host)."""
+rank 0 can build the N > 1 JSON line; the numbers mean nothing (two processes share the card) and neither do the tables: gloo's
+point-to-point calls read device memory from the host, unordered with the streams (tests/test_hip_rotating_two_ranks.py stages
+them through the host and checks the result)."""
 import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
