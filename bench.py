@@ -246,6 +246,12 @@ def single_gpu(args, local_rank):
         pipe.run_steps(prime, 2 * C, args.lr, torch.empty(2 * C, dtype=torch.float32, device=dev))
         torch.cuda.synchronize()
     # the warm-up is two plans long when it can be, so that every host path of the pipeline has run twice before the clock starts
+    # No cyclic-GC pass of the interpreter between here and the end of the timed region, which can be as short as 0.6 ms: a
+    # pass costs milliseconds and leaves the host path behind it slower (a gc.collect() right before the clock: host time to
+    # queue the 20 steps 0.33 -> 0.85 ms, 33 -> 47 us/step, three A/B pairs on one box); one run in ~20 of the driver's
+    # command came out at 122 us/step.  A training loop amortises such a pass over its thousands of steps.
+    import gc
+    gc.disable()
     handle = pipe.plan(U, [(I, u, p, n)], B, first_chunk=[W - W // 2, W // 2] if W > 0 else None, lr=args.lr)
     if W > 0:
         pipe.run_steps(handle, W, args.lr, losses_w)
@@ -253,8 +259,12 @@ def single_gpu(args, local_rank):
 
     t0 = time.perf_counter()
     pipe.run_steps(handle, K, args.lr, losses)
+    t_queued = time.perf_counter()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
+    host_queue_ms = (t_queued - t0) * 1e3   # host time to queue the K steps + the next plan's build (a diagnostic: a host stall
+                                            # inside a 20-step region — scheduler, allocator — shows here)
 
     plan = handle["cur"][1]            # the plan of the last timed chunk: row statistics and the per-kernel timing pass
     tabs = handle["segs"][0]["tabs"]
@@ -361,7 +371,8 @@ def single_gpu(args, local_rank):
                       "step_stream_calls": dict(pipe.stats),
                       "plan_build": "on the step stream, between the halves of the chunk before" if handle["inline"]
                                     else "on a side stream, beside the steps of the chunk before",
-                      "untimed_priming_steps": 2 * C if args.overlap else 0},
+                      "untimed_priming_steps": 2 * C if args.overlap else 0,
+                      "host_queue_ms_of_timed_region": host_queue_ms},
            "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
            "roofline": roofline}
     if not args.no_adam:

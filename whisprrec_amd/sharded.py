@@ -274,10 +274,13 @@ def bench_run(args, rank, world, dev):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    import gc
+    gc.disable()            # no cyclic-GC pass of the interpreter inside a sub-millisecond timed region (see bench.py)
     t0 = time.perf_counter()
     res = run_range(W, K)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    gc.enable()
     # every rank started behind the same barrier; the job's time is the MAX over ranks of (own completion - start), which is
     # what a closing barrier would measure without that barrier's own launch + rendezvous latency (~0.1 ms of a 0.7 ms region)
     dist.barrier()
