@@ -19,6 +19,8 @@ for rep in range(4):
     pipe.run_steps(h, W, 0.05, lw)
     torch.cuda.synchronize()
     main = torch.cuda.current_stream(dev)
+    if os.environ.get("WR_GC_COLLECT"):
+        import gc; gc.collect()
     t0 = T()
     cur = h["next"]; plan = cur[1]
     t1 = T(); plan.ready.synchronize()
