@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void overlap_mark_deferred(const int *__res
 // global version is bound by its two random 4-byte L2 requests per triplet (4.2 M triplets per 64-batch plan: 38-41 us);
 // here a workgroup of 1,024 threads copies the bitmap once (coalesced) and looks up kLdsTile triplets in LDS.
 constexpr int kLdsThreads = 1024;
-constexpr int kLdsTile = 8192;
+constexpr int kLdsTile = 16384;
 constexpr size_t kLdsBitmapMax = 144 * 1024;
 
 __global__ __launch_bounds__(kLdsThreads) void overlap_mark_deferred_lds(const int *__restrict__ tu, const int *__restrict__ tp,
