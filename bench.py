@@ -6,8 +6,9 @@
 N=1 workload = BASELINE.json configs[1]: BPRMF, emb_size=64, synthetic 1M users x 1M items (uniform ids from the
 100M-interaction generator, seed 3407), batch 65,536 triplets, SGD, l2=0.  A "step" is one BaseRunner.fit iteration
 (zero_grad / predict / backward / optimizer.step, reference src/helpers/BaseRunner.py:196-199) over one batch: raw
-(u, p, n) int32 triplets resident in HBM -> sorted batch plan -> user-phase kernel -> item-phase kernel -> updated
-tables + loss.  The step stream is the product's own pipeline (whisprrec_amd.hip_ops.PipelinedSgd): plans are built a
+(u, p, n) int32 triplets resident in HBM -> group plan (flags + lists of the rows that recur in the batch; no sort) -> one
+step launch (wr_bprmf_run_sgd_group) -> updated tables + loss; `--no-group`: sorted batch plan -> user-phase / item-phase
+kernels.  The step stream is the product's own pipeline (whisprrec_amd.hip_ops.PipelinedSgd): plans are built a
 chunk ahead on a side stream, INSIDE the timed region (K steps' worth of plan builds run between the two timestamps).
 
 N>1 (`python bench.py --gpus N` starts its own N ranks; under `torch.distributed.run` it uses the ranks it is given):
@@ -61,6 +62,9 @@ def parse(argv=None):
                     help="N=1: skip the whole-epoch figure reported under `extra` (negative sampling + shuffle + plans + steps)")
     ap.add_argument("--epoch-interactions", type=int, default=100_000_000,
                     help="N=1: interactions of the synthetic training frame of the whole-epoch figure")
+    ap.add_argument("--no-group", action="store_true",
+                    help="N=1: sorted batch plans (two bucket scatters + two LDS sorts per batch) instead of group plans "
+                         "(no per-batch sort, whisprrec_amd/csrc/wr_group.hip)")
     ap.add_argument("--no-chain", action="store_true",
                     help="N=1: two launches per step (user phase, item phase) instead of the chained step launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,9 +209,10 @@ def synth_triplets(n, n_users, n_items, dev, seed, zipf=0.0):
 
 
 def csrc_sha():
-    """hash of the step kernels' sources: a committed PMC traffic figure is only quoted for the kernels it was taken on"""
+    """hash of the sources of every kernel that runs in the timed region (step kernels and plan builders): a committed PMC
+    traffic figure is only quoted for the kernels it was taken on"""
     h = hashlib.sha256()
-    for f in ("wr_bpr.hip", "wr_common.h"):
+    for f in ("wr_group.hip", "wr_bpr.hip", "wr_common.h", "wr_plan_fast.hip", "wr_plan.hip", "wr_overlap.hip"):
         with open(os.path.join(ROOT, "whisprrec_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -234,7 +239,7 @@ def single_gpu(args, local_rank):
     # one: K batches' worth of plan builds between the two timestamps, K steps trained.
     u, p, n = synth_triplets((K + W + C) * B, args.users, args.items, dev, 3407, args.zipf)
     pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=args.overlap, chain=not args.no_chain,
-                                inline_plan=args.plan_stream == "inline")
+                                inline_plan=args.plan_stream == "inline", group=not args.no_group)
     losses_w = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
     losses = torch.empty(K, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -252,64 +257,83 @@ def single_gpu(args, local_rank):
     # command came out at 122 us/step.  A training loop amortises such a pass over its thousands of steps.
     import gc
     gc.disable()
-    handle = pipe.plan(U, [(I, u, p, n)], B, first_chunk=[W - W // 2, W // 2] if W > 0 else None, lr=args.lr)
-    if W > 0:
-        pipe.run_steps(handle, W, args.lr, losses_w)
-    torch.cuda.synchronize()
+    try:
+        handle = pipe.plan(U, [(I, u, p, n)], B, first_chunk=[W - W // 2, W // 2] if W > 0 else None, lr=args.lr)
+        if W > 0:
+            pipe.run_steps(handle, W, args.lr, losses_w)
+        torch.cuda.synchronize()
 
-    t0 = time.perf_counter()
-    pipe.run_steps(handle, K, args.lr, losses)
-    t_queued = time.perf_counter()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gc.enable()
+        t0 = time.perf_counter()
+        pipe.run_steps(handle, K, args.lr, losses)
+        t_queued = time.perf_counter()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     host_queue_ms = (t_queued - t0) * 1e3   # host time to queue the K steps + the next plan's build (a diagnostic: a host stall
                                             # inside a 20-step region — scheduler, allocator — shows here)
 
-    plan = handle["cur"][1]            # the plan of the last timed chunk: row statistics and the per-kernel timing pass
+    plan = handle["cur"][1]            # the plan of the last timed chunk: the per-kernel timing pass runs on it
     tabs = handle["segs"][0]["tabs"]
-    # per-kernel timing: HIP events that the library attaches to the dispatches of the two kernels of each step (the
-    # kernels' own start / end timestamps), on a second pass over already planned batches — outside the throughput
-    # measurement, so nothing extra sits in the timed region.
-    events, KP, chain_ev, chained = None, 0, None, []
+    grouped = isinstance(plan, hip_ops.GroupPlan)
+    # per-kernel timing: HIP events that the library attaches to the dispatches of the step kernels (the kernels' own start /
+    # end timestamps), on a second pass over already planned batches — outside the throughput measurement, so nothing extra
+    # sits in the timed region.
+    events, KP, chain_ev, chained, group_ev = None, 0, None, [], None
     if not args.no_phase_events:
         KP = min(K, 64, plan.n_batches)
 
-        def fresh_events():
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4 * KP)]
+        def fresh_events(per_step=4):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(per_step * KP)]
             for e in evs:
                 e.record()
             torch.cuda.synchronize()
             return evs
-        if handle["chain"] and plan.overlap is not None and KP >= 2:
-            # the chained form first (what the timed region ran): per step ONE launch that carries the user phase of the
-            # step and the item phase of the step before (the first step of a call and steps with too many deferred runs go
-            # out as two launches)
-            chain_ev = fresh_events()
-            tabs.run_sgd_chain(plan, 0, KP, args.lr, phase_events=chain_ev)
+        if grouped:
+            # what the timed region ran: ONE launch per step (the triplets of batch k + the tiles of batch k-1)
+            group_ev = fresh_events(2)
+            tabs.run_sgd_group(plan, 0, KP, args.lr, events=group_ev)
             torch.cuda.synchronize()
-            dc = plan.overlap["def_count_np"]
-            chained = [k for k in range(1, KP) if 0 <= int(dc[k]) <= plan.overlap["cap"]]
+            lo_p = handle["cur"][0] * B
+            sorted_plan = hip_ops.BatchPlan(u[lo_p:lo_p + plan.n_triplets], p[lo_p:lo_p + plan.n_triplets],
+                                            n[lo_p:lo_p + plan.n_triplets], B, args.users, args.items)
+        else:
+            sorted_plan = plan
+            if handle["chain"] and plan.overlap is not None and KP >= 2:
+                # the chained form first (what the timed region ran): per step ONE launch that carries the user phase of the
+                # step and the item phase of the step before (the first step of a call and steps with too many deferred runs
+                # go out as two launches)
+                chain_ev = fresh_events()
+                tabs.run_sgd_chain(plan, 0, KP, args.lr, phase_events=chain_ev)
+                torch.cuda.synchronize()
+                dc = plan.overlap["def_count_np"]
+                chained = [k for k in range(1, KP) if 0 <= int(dc[k]) <= plan.overlap["cap"]]
         events = fresh_events()
-        tabs.run_sgd(plan, 0, KP, args.lr, phase_events=events)
+        tabs.run_sgd(sorted_plan, 0, KP, args.lr, phase_events=events)     # the two-launch form of the same steps
         torch.cuda.synchronize()
-        tabs.check_chain()
+    else:
+        sorted_plan = plan if not grouped else None
+    tabs.check_chain()                 # a bounded wait inside a launch expired: the run is invalid — always checked
 
     lv = losses.cpu().numpy()
     assert np.all(np.isfinite(lv)), "non-finite loss"
     value = K * B / dt
 
-    # unique rows per step (for algorithmic bytes with in-batch duplicates counted once)
-    nb = plan.n_triplets // B          # whole batches of the plan
-    tu = plan.tu[:nb * B].view(nb, B)
-    oi = plan.oc_item[:2 * nb * B].view(nb, 2 * B)
-    uniq_u = (int((tu[:, 1:] != tu[:, :-1]).sum().item()) + nb) / nb
-    uniq_i = (int((oi[:, 1:] != oi[:, :-1]).sum().item()) + nb) / nb
-    single_i = (int((plan.tp[:nb * B] >= 0).sum().item()) + int((plan.tn[:nb * B] >= 0).sum().item())) / nb
+    # unique rows per step (for algorithmic bytes with in-batch duplicates counted once): from the ids of up
+    # to 8 batches of the last timed chunk
+    lo_p = handle["cur"][0] * B
+    nbs = max(1, min(8, plan.n_triplets // B))
+    uniq_u = uniq_i = single_i = 0.0
+    for k in range(nbs):
+        sl = slice(lo_p + k * B, lo_p + (k + 1) * B)
+        uniq_u += torch.unique(u[sl]).numel() / nbs
+        _, ci = torch.unique(torch.cat([p[sl], n[sl]]), return_counts=True)
+        uniq_i += ci.numel() / nbs
+        single_i += int((ci == 1).sum().item()) / nbs
     row = D * 4
     # Algorithmic bytes: every unique row of the batch read once and written once + 12 B of indices
-    # per triplet.  Split by who does it: the user phase reads all of them, writes the user rows and the
-    # single-occurrence item rows; the item phase writes the item rows that have several occurrences (its re-read of
+    # per triplet.  Split by who does it in the two-launch form: the user phase reads all of them, writes the user rows and
+    # the single-occurrence item rows; the item phase writes the item rows that have several occurrences (its re-read of
     # those rows and the stash traffic are overhead, not algorithmic).
     bytes_user = row * (2 * uniq_u + uniq_i + single_i) + 12 * B
     bytes_item = row * (uniq_i - single_i)
@@ -324,7 +348,11 @@ def single_gpu(args, local_rank):
         else:
             name, tk, bk = "bprmf_user_phase", t_user, bytes_user
         t_chain = None
-        if chained:
+        if group_ev is not None and KP >= 2:
+            # the launch of step k: the triplets of batch k + the tiles of batch k-1 = one step's algorithmic bytes
+            t_chain = np.mean([group_ev[2 * k].elapsed_time(group_ev[2 * k + 1]) for k in range(1, KP)]) * 1e-3
+            name, tk, bk = "bprmf_group_step", t_chain, bytes_step
+        elif chained:
             # the launch of step k: user phase of batch k + item phase of batch k-1 = one step's algorithmic bytes
             t_chain = np.mean([chain_ev[4 * k].elapsed_time(chain_ev[4 * k + 1]) for k in chained]) * 1e-3
             name, tk, bk = "bprmf_chain_step", t_chain, bytes_step
@@ -333,7 +361,7 @@ def single_gpu(args, local_rank):
                     "traffic": None, "kernel": name, "kernel_us": tk * 1e6, "algorithmic_bytes_per_launch": bk,
                     "kernel_us_method": "start/stop events attached to the dispatch (hipExtLaunchKernelGGL)",
                     "chain_step_us": None if t_chain is None else t_chain * 1e6,
-                    "chained_steps_of_timing_pass": "%d of %d" % (len(chained), KP),
+                    "chained_steps_of_timing_pass": "%d of %d" % (KP - 1 if group_ev is not None else len(chained), KP),
                     # the two-launch form of the same steps (a second pass; what --no-chain runs)
                     "user_phase_us": t_user * 1e6, "item_phase_us": t_item * 1e6,
                     "user_phase_GBs": bytes_user / t_user / 1e9, "item_phase_GBs": bytes_item / t_item / 1e9,
@@ -349,14 +377,14 @@ def single_gpu(args, local_rank):
         # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
         # passes: scripts/pmc_passes.sh) cannot run inside this process, so the figure comes from the committed summary — and
         # only when that summary was taken on THESE kernel sources and this configuration; otherwise null.
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_configs1.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic_configs1.json")
         if os.path.exists(pmc) and (B, D, args.users, args.items, args.zipf) == (65536, 64, 1_000_000, 1_000_000, 0.0):
             rec = json.load(open(pmc))
             if rec.get("csrc_sha") == csrc_sha():
                 for k, v in rec.get("kernels", {}).items():
                     if k.startswith(name):
                         roofline["traffic"] = v["hbm_bytes"]
-                        roofline["traffic_source"] = "profiles/r02_pmc_traffic_configs1.json (rocprofv3 --pmc FETCH_SIZE / " \
+                        roofline["traffic_source"] = "profiles/r03_pmc_traffic_configs1.json (rocprofv3 --pmc FETCH_SIZE / " \
                                                      "WRITE_SIZE on kernel sources %s)" % rec["csrc_sha"]
     out = {"metric": "BPR training triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": 1, "steps": K,
            "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -366,8 +394,10 @@ def single_gpu(args, local_rank):
                                                                   "uniform" if args.zipf == 0 else "zipf(%.2f) item" % args.zipf, B),
                       "batch": B, "emb_size": D, "optimizer": "SGD", "l2": 0.0, "lr": args.lr,
                       "plan_chunk_batches": C, "tables": "single GPU", "step_stream": "whisprrec_amd.hip_ops.PipelinedSgd",
-                      "overlapped_item_phase": bool(plan.overlap is not None and handle["overlap"]),
-                      "chained_step_launch": bool(plan.overlap is not None and handle["chain"]),
+                      "plan": "group plan (no per-batch sort: flags + lists of the shared rows, wr_group.hip)" if grouped
+                              else "sorted batch plan (bucket scatter + LDS sort per table)",
+                      "overlapped_item_phase": bool(not grouped and plan.overlap is not None and handle["overlap"]),
+                      "chained_step_launch": bool(grouped or (plan.overlap is not None and handle["chain"])),
                       "step_stream_calls": dict(pipe.stats),
                       "plan_build": "on the step stream, between the halves of the chunk before" if handle["inline"]
                                     else "on a side stream, beside the steps of the chunk before",

@@ -343,6 +343,43 @@ int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab
                                const int32_t *def_count_host, int64_t def_cap, int64_t def_limit, void *const *phase_events,
                                void *workspace, int64_t workspace_bytes, int32_t *sync, int64_t sync_words, void *stream);
 
+/* Step stream WITHOUT a per-batch sort (wr_group.hip) — the same consecutive steps as wr_bprmf_run_sgd
+ * (src/helpers/BaseRunner.py:194-200: zero_grad / predict / backward / SGD.step per batch, l2 = 0), one launch per step.
+ * The reference loop does no per-batch index work; neither does this path beyond GROUPING what recurs in a batch:
+ *   wr_group_plan_build    leaves the triplets (u, p, n: int32, batch order) where they are and writes, per batch, four
+ *       flag bits per triplet (user shared in the batch / positive item shared / negative item shared / an item row is
+ *       rewritten by the batch before) and the shared occurrences only, sorted by (row, position), as lists.  `plan` holds
+ *       wr_group_plan_words(...) int32 words (0: shape not supported — batch_size > 131,072), 16-byte aligned, caller-owned.
+ *       plan[0] != 0: an id was out of range (nn.Embedding would raise IndexError); plan[1] != 0: a list overflowed
+ *       (tables small against the batch, or popularity-skewed ids) — the plan is NOT usable, build a sorted plan instead;
+ *       plan[2] != 0: some row has more than 32 occurrences in a batch (usable, but slow: prefer the sorted plan's hot-row
+ *       path).  Tables beyond 2^21 rows are hashed into 2^21 bits: a collision makes a row look shared, never the reverse.
+ *   wr_bprmf_run_sgd_group  the steps of batches [first_batch, first_batch + n_batches) of that plan; `u, p, n` are the
+ *       arrays the plan was built from.  The item rows with several occurrences in batch k are rewritten by workgroups
+ *       that ride in the launch of step k+1 (write-through stores + an in-launch counter hand-off, as wr_bprmf_run_sgd_chain);
+ *       the call ends with a launch of its own for the last batch's, so the stream holds complete steps on return.
+ *       Every table row has one writer per step and a fixed summation order (bitwise reproducible); the order differs from
+ *       the sorted plan's, so tables agree with wr_bprmf_run_sgd to rounding (1e-7 relative), not bit for bit.
+ *       events (may be NULL): 2 handles per step, start / stop of the launch that carries step k's triplets.
+ *       workspace >= wr_bprmf_group_workspace_bytes(batch_size, D); sync: wr_bprmf_group_sync_words(n_batches) int32 words,
+ *       16-byte aligned; word sync_words - 4 is the sticky "a bounded wait expired" word (zero it once when allocating).
+ *       Rows must be whole 128-byte lines (wr_bprmf_group_supported; WR_E_ALIGN otherwise). */
+int64_t wr_group_plan_words(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items);
+/* out[16] = {n_batches, flag words per batch, user ranges, item ranges, user hash mask, item hash mask, and the offsets (in
+ * int32 words from `plan`) of: flags [nb][fw][4], user list lengths [nb][R_u], item list lengths [nb][R_i], user list rows,
+ * user list positions, item list rows, item list sources [nb][R][cap]; total words; cap; meta words} — for tools and tests */
+int32_t wr_group_plan_layout(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items, int64_t *out);
+int32_t wr_group_plan_build(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets, int64_t batch_size,
+                            int64_t n_users, int64_t n_items, int32_t *plan, int64_t plan_words, void *stream);
+int64_t wr_bprmf_group_workspace_bytes(int64_t batch_size, int32_t D);
+int64_t wr_bprmf_group_sync_words(int64_t n_batches);
+int32_t wr_bprmf_group_supported(const float *user_tab, const float *item_tab, int32_t D);
+int32_t wr_bprmf_run_sgd_group(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                               const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets, int64_t batch_size,
+                               const int32_t *plan, int64_t plan_words, int64_t first_batch, int64_t n_batches, float lr,
+                               float *loss_out, void *const *events, void *workspace, int64_t workspace_bytes, int32_t *sync,
+                               int64_t sync_words, void *stream);
+
 /* Plan-time marks for wr_bprmf_run_sgd_overlap (index work only; call after the plan build, on the same stream).
  *   bitmap [n_batches * ceil(n_items/32)] (out): per batch, bit r = item row r has several occurrences in the batch;
  *   prev_bitmap: that bitmap of the batch BEFORE this plan's first batch, or NULL (then the first batch defers nothing);

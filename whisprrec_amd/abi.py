@@ -78,6 +78,14 @@ SIGNATURES = {
     "wr_bprmf_run_sgd_chain": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                        c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
                                        c_vp]),
+    "wr_group_plan_words": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    "wr_group_plan_layout": (c_i32, [c_i64, c_i64, c_i64, c_i64, c_vp]),
+    "wr_group_plan_build": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "wr_bprmf_group_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "wr_bprmf_group_sync_words": (c_i64, [c_i64]),
+    "wr_bprmf_group_supported": (c_i32, [c_vp, c_vp, c_i32]),
+    "wr_bprmf_run_sgd_group": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
+                                       c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "wr_bprmf_plan_overlap_deferred": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
                                                c_vp]),
     "wr_bprmf_plan_fast_marks_supported": (c_i32, [c_i64, c_i64, c_i64, c_i64]),

@@ -586,6 +586,123 @@ class BatchPlan:
             t.record_stream(stream)
 
 
+class GroupArena:
+    """Pre-sized home of ONE group plan (GroupPlan): the plan words and the pinned mirror of its meta words.  Like
+    PlanArena: nothing is allocated while steps run, the read-back is an asynchronous copy consumed at first use."""
+
+    def __init__(self, device, max_triplets, batch_size, n_users, n_items):
+        words = int(abi.lib().wr_group_plan_words(int(max_triplets), int(batch_size), int(n_users), int(n_items)))
+        if words <= 0:
+            raise abi.WhisprRecHipError("group plan: shape not supported (batch size %d)" % batch_size)
+        self.device, self.max_triplets, self.batch_size = device, int(max_triplets), int(batch_size)
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self.buf = torch.empty(words, dtype=torch.int32, device=device)
+        self.meta_host = torch.zeros(GroupPlan.META, dtype=torch.int32, pin_memory=True)
+        self.meta_np = self.meta_host.numpy()
+        self.free = None
+
+    def release_after(self, stream):
+        self.free = torch.cuda.Event()
+        self.free.record(stream)
+
+
+class GroupPlan:
+    """Batches for the step stream WITHOUT a per-batch sort (include/whisprrec_hip.h, wr_group_plan_build): the triplets stay
+    where they are (``u, p, n`` int32, batch order — kept by the plan, the step kernels read them); per batch the plan holds
+    four flag bits per triplet and the shared occurrences only, as sorted lists.  One launch per build, ~0.1 B of plan per
+    triplet.  ``finish()`` publishes ``bad_index`` / ``overflow`` (the plan is unusable: fall back to BatchPlan) /
+    ``long_run`` (usable, but a row has more than 32 occurrences in a batch)."""
+
+    META = 16
+
+    def __init__(self, u, p, n, batch_size, n_users, n_items, arena=None, defer=False):
+        u, p, n = (_req(t, torch.int32, nm, 1) for t, nm in ((u, "u"), (p, "p"), (n, "n")))
+        N = u.numel()
+        if not (p.numel() == N and n.numel() == N) or N == 0:
+            raise ValueError("u/p/n must have the same non-zero length")
+        L = abi.lib()
+        self.u, self.p, self.n = u, p, n
+        self.n_triplets, self.batch_size = N, int(batch_size)
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self.n_batches = (N + self.batch_size - 1) // self.batch_size
+        self.words = int(L.wr_group_plan_words(N, self.batch_size, self.n_users, self.n_items))
+        if self.words <= 0:
+            raise abi.WhisprRecHipError("group plan: shape not supported (batch size %d)" % self.batch_size)
+        self.arena = arena
+        self._stream = torch.cuda.current_stream(u.device)
+        if arena is not None:
+            if arena.buf.numel() < self.words or arena.batch_size != self.batch_size or \
+                    (arena.n_users, arena.n_items) != (self.n_users, self.n_items):
+                raise ValueError("plan does not fit its arena")
+            if arena.free is not None:
+                self._stream.wait_event(arena.free)
+                arena.free = None
+            self.buf = arena.buf
+            self._pinned = arena.meta_host
+        else:
+            self.buf = torch.empty(self.words, dtype=torch.int32, device=u.device)
+            self._pinned = None
+        abi.check(L.wr_group_plan_build(_p(u), _p(p), _p(n), N, self.batch_size, self.n_users, self.n_items, _p(self.buf),
+                                        self.buf.numel(), _stream()), "wr_group_plan_build")
+        self.ready = None
+        if self._pinned is not None:
+            self._pinned.copy_(self.buf[:self.META], non_blocking=True)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self._stream)
+        self._finished = False
+        self.bad_index = self.overflow = self.long_run = False
+        if not defer:
+            self.finish()
+
+    def finish(self):
+        if self._finished:
+            return self
+        if self._pinned is not None:
+            self.ready.synchronize()
+            m = self.arena.meta_np
+        else:
+            m = self.buf[:self.META].cpu().numpy()
+        self.bad_index, self.overflow, self.long_run = bool(m[0]), bool(m[1]), bool(m[2])
+        self._finished = True
+        return self
+
+    def validate(self):
+        """nn.Embedding raises IndexError for out-of-range ids; so does the plan."""
+        self.finish()
+        if self.bad_index:
+            raise IndexError("index out of range in batch (user_id >= n_users or item id >= n_items)")
+
+    def batch_len(self, k):
+        return min(self.batch_size, self.n_triplets - k * self.batch_size)
+
+    def layout(self):
+        out = (ctypes.c_int64 * 16)()
+        abi.check(abi.lib().wr_group_plan_layout(self.n_triplets, self.batch_size, self.n_users, self.n_items,
+                                                 ctypes.addressof(out)), "wr_group_plan_layout")
+        keys = ("nb", "fw", "R_u", "R_i", "mask_u", "mask_i", "flags", "ucnt", "icnt", "ul_row", "ul_src", "il_row", "il_src",
+                "total", "cap", "meta")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def decode(self):
+        """the plan as NumPy arrays (tests, statistics): flags [nb, fw, 4] uint32 and, per (batch, range), the user and item
+        lists as (rows, sources)"""
+        import numpy as np
+        self.finish()
+        Ly = self.layout()
+        w = self.buf[:Ly["total"]].cpu().numpy()
+        nb, fw, cap = Ly["nb"], Ly["fw"], Ly["cap"]
+        flags = w[Ly["flags"]:Ly["flags"] + nb * fw * 4].view(np.uint32).reshape(nb, fw, 4).copy()
+        out = {"flags": flags, "users": {}, "items": {}, "R_u": Ly["R_u"], "R_i": Ly["R_i"], "meta": w[:self.META].copy()}
+        for side, R, co, ro, so in (("users", Ly["R_u"], "ucnt", "ul_row", "ul_src"), ("items", Ly["R_i"], "icnt", "il_row", "il_src")):
+            for b in range(nb):
+                for r in range(R):
+                    c = int(w[Ly[co] + b * R + r])
+                    at = (b * R + r) * cap
+                    out[side][(b, r)] = (w[Ly[ro] + at:Ly[ro] + at + c].astype(np.int64),
+                                         w[Ly[so] + at:Ly[so] + at + c].astype(np.int64))
+        return out
+
+
 class OverlapEvents:
     """the ring of hipEvent_t handles wr_bprmf_run_sgd_overlap orders its two streams with (caller-owned, like every other
     resource of the C-ABI)"""
@@ -746,8 +863,8 @@ class BprmfTables:
     def check_chain(self):
         """raises if a bounded wait inside a chained step launch ever expired on this device (synchronises; call it where
         the caller waits for the device anyway: end of an epoch, end of a benchmark)"""
-        for (dev, _), bufs in _CHAIN_SYNC.items():
-            if dev != str(self.dev):
+        for key, bufs in _CHAIN_SYNC.items():
+            if key[0] != str(self.dev):
                 continue
             for buf in bufs:
                 if int(buf[-4].item()) != 0:
@@ -785,6 +902,48 @@ class BprmfTables:
                                            o["cap"] if def_limit is None else int(def_limit),
                                            ctypes.addressof(ev) if ev is not None else None, _p(ws), ws.numel(), _p(sync),
                                            sync.numel(), _stream()), "wr_bprmf_run_sgd_chain")
+        self.step_id += count
+        return losses
+
+    def group_supported(self):
+        """rows are whole 128-byte lines: the step stream without a per-batch sort applies (wr_bprmf_run_sgd_group)"""
+        return bool(abi.lib().wr_bprmf_group_supported(_p(self.U), _p(self.I), self.D))
+
+    def _group_sync(self, count):
+        """hand-off counters + sticky timeout word of wr_bprmf_run_sgd_group: kept with the chained launches' (check_chain
+        reads both)"""
+        key = (str(self.dev), torch.cuda.current_stream(self.dev).cuda_stream, "group")
+        bufs = _CHAIN_SYNC.setdefault(key, [])
+        need = int(abi.lib().wr_bprmf_group_sync_words(count))
+        if not bufs or bufs[-1].numel() < need:
+            words = int(abi.lib().wr_bprmf_group_sync_words(max(count, self.CHAIN_SYNC_STEPS)))
+            bufs.append(torch.zeros(words, dtype=torch.int32, device=self.dev))
+        return bufs[-1]
+
+    def run_sgd_group(self, gplan, first, count, lr, losses=None, events=None):
+        """`count` consecutive steps of a GroupPlan from batch `first` (wr_bprmf_run_sgd_group): one launch per step, no
+        sorted plan.  events: optional 2 * count ``torch.cuda.Event(enable_timing=True)`` — start / stop of each step's launch."""
+        L = abi.lib()
+        nbytes = abi.check_size(L.wr_bprmf_group_workspace_bytes(gplan.batch_size, self.D), "wr_bprmf_group_workspace_bytes")
+        ws = workspace(self.dev, "group_step").get(nbytes)
+        if losses is None:
+            losses = torch.empty(count, dtype=torch.float32, device=self.dev)
+        ev = None
+        if events is not None:
+            if len(events) != 2 * count:
+                raise ValueError("events must hold 2 events per step")
+            handles = []
+            for e in events:
+                if not e.cuda_event:
+                    e.record()
+                handles.append(e.cuda_event)
+            ev = (ctypes.c_void_p * len(handles))(*handles)
+        sync = self._group_sync(count)
+        abi.check(L.wr_bprmf_run_sgd_group(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(gplan.u),
+                                           _p(gplan.p), _p(gplan.n), gplan.n_triplets, gplan.batch_size, _p(gplan.buf),
+                                           gplan.buf.numel(), first, count, lr, _p(losses),
+                                           ctypes.addressof(ev) if ev is not None else None, _p(ws), ws.numel(), _p(sync),
+                                           sync.numel(), _stream()), "wr_bprmf_run_sgd_group")
         self.step_id += count
         return losses
 
@@ -1050,12 +1209,22 @@ class PipelinedSgd:
     PLAN_TRIPLETS = 1 << 22
     OVERLAP_MIN_BATCH = 8192      # below this a step is launch-bound and a third launch per step costs more than it hides
 
+    GROUP_MIN_ROWS_PER_TRIPLET = 12   # group plans (no per-batch sort): both tables hold at least this many rows per triplet of a
+                                      # batch — with fewer, the lists of shared rows outgrow their capacity (uniform ids: a
+                                      # share 1 - exp(-2 B / rows) of the item occurrences is shared: 15 % at 12 rows per triplet)
+    GROUP_MIN_BATCH = 4096            # below this the step is launch-bound either way and the sorted plan's two tiny launches win
+
     CHAIN_MIN_BATCH = 8192        # below this the step is launch-bound: nothing to hide the item phase behind
     CHAIN_MIN_ITEMS_PER_TRIPLET = 6   # item rows per triplet of a batch: with fewer, too many runs are deferred (uniform ids:
                                       # 2 * (1 - exp(-x)(1 + x)), x = 2 B / rows, of the runs: 1/20 at 6 rows per triplet)
 
-    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True, inline_plan=False):
-        """chain (default): steps of plans that qualify (no hot rows; B >= CHAIN_MIN_BATCH; rows = whole 128-B lines; item
+    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True, inline_plan=False, group=True):
+        """group (default): batches that qualify (int32 ids; 4,096 <= B <= 131,072; rows = whole 128-B lines; both tables large
+        against the batch; no popularity-skewed ids) are NOT sorted at all: the plan only groups the rows that recur in a batch
+        (GroupPlan, wr_group_plan_build: one launch per chunk, LDS bitmaps, ~0.1 B of plan per triplet) and the step is one
+        launch (wr_bprmf_run_sgd_group).  A chunk whose lists overflow is re-planned with the sorted builder, and the stream
+        stays with sorted plans from there on; so it does after a chunk that reports a long run.
+        chain: steps of plans that qualify (no hot rows; B >= CHAIN_MIN_BATCH; rows = whole 128-B lines; item
         table large against the batch) go out as ONE launch per step — the item phase of step k-1 inside the launch of step
         k's user phase (wr_bprmf_run_sgd_chain; same tables bit for bit; MI355X, 1M x 1M x 64, B = 65,536, steps only:
         27.3 -> 24.7 us/step).
@@ -1074,11 +1243,13 @@ class PipelinedSgd:
         self.chunk = int(chunk)
         self.overlap = bool(overlap)
         self.chain = bool(chain)
+        self.group = bool(group)
         self.inline_plan = inline_plan
         self.item_stream = None
         self._ovl_events = None
         self._graphs = {}
-        self.stats = {"graph_replays": 0, "plain_calls": 0, "chain_calls": 0}
+        self.stats = {"graph_replays": 0, "plain_calls": 0, "chain_calls": 0, "group_calls": 0, "group_fallbacks": 0}
+        self._garenas = {}
         if min_triplets is not None:
             self.PLAN_TRIPLETS = int(min_triplets)
         self.plan_stream = None
@@ -1096,6 +1267,15 @@ class PipelinedSgd:
         if pair is None or pair[0].max_triplets < cap:
             pair = [self.ops.PlanArena(device, cap, B, overlap_items=overlap_items) for _ in range(2)]
             self._arenas[key] = pair
+        return pair
+
+    def _garena_pair(self, device, B, nb_total, n_users, n_items):
+        cap = min(self.chunk_batches(B), max(int(nb_total), 1)) * B
+        key = (str(device), B, int(n_users), int(n_items))
+        pair = self._garenas.get(key)
+        if pair is None or pair[0].max_triplets < cap:
+            pair = [self.ops.GroupArena(device, cap, B, n_users, n_items) for _ in range(2)]
+            self._garenas[key] = pair
         return pair
 
     def plan(self, U, segments, batch, first_chunk=None, lr=None, prep=None, runner=None):
@@ -1135,11 +1315,19 @@ class PipelinedSgd:
         use_chain = self.chain and runner is None and not use_overlap and B >= self.CHAIN_MIN_BATCH and first >= 2 and \
             min([s[0].shape[0] for s in live] or [0]) >= self.CHAIN_MIN_ITEMS_PER_TRIPLET * B and \
             all(sg["tabs"].chain_supported() for sg in segs if sg["tabs"] is not None)
-        arenas = self._arena_pair(U.device, B, first, n_items if (use_overlap or use_chain) else 0)
-        for a in arenas:                     # a previous handle may have left steps queued that read these arrays
+        min_rows = min([U.shape[0]] + [s[0].shape[0] for s in live])
+        use_group = self.group and runner is None and not use_overlap and len(live) == 1 and first >= 2 and \
+            self.GROUP_MIN_BATCH <= B <= 131072 and u_all.dtype == torch.int32 and \
+            min_rows >= self.GROUP_MIN_ROWS_PER_TRIPLET * B and \
+            all(sg["tabs"].group_supported() for sg in segs if sg["tabs"] is not None)
+        garenas = self._garena_pair(U.device, B, first, U.shape[0], n_items) if use_group else None
+        # the sorted plans' arenas are made on demand when a group-plan stream has to fall back (skewed ids)
+        arenas = None if use_group else self._arena_pair(U.device, B, first, n_items if (use_overlap or use_chain) else 0)
+        for a in (arenas or []) + (garenas or []):     # a previous handle may have left steps queued that read these arrays
             a.release_after(main)
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
+             "group": use_group, "garenas": garenas, "device": U.device,
              "overlap": use_overlap, "chain": use_chain, "prep": prep, "runner": runner,
              "inline": (not use_overlap) and bool(self.inline_plan),
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
@@ -1217,6 +1405,14 @@ class PipelinedSgd:
             bmap = h["map"] if h["map"] else None
             if h["prep"] is not None:
                 h["prep"].fill(lo, hi)       # this chunk's rows: shuffle + negatives, on the plan stream, before its plan
+            if h["group"]:
+                plan = self.ops.GroupPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
+                                          arena=h["garenas"][h["tag"]], defer=True)
+                h["tag"] ^= 1
+                h["next"] = (first, plan)
+                return
+            if h["arenas"] is None:          # first sorted plan of a stream that started with group plans
+                h["arenas"] = self._arena_pair(h["device"], B, h["nb"], h["n_items"] if h["chain"] else 0)
             plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
                                       validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap, arena=h["arenas"][h["tag"]],
                                       defer=True, overlap=h["overlap"] or h["chain"])
@@ -1231,6 +1427,30 @@ class PipelinedSgd:
         assert cur is not None and cur[0] == pos, "steps must be run in order"
         plan = cur[1]
         plan.validate()                      # finish(): waits for the build's event only if the build has not run yet
+        if isinstance(plan, GroupPlan):
+            if plan.overflow or plan.long_run:
+                # ids the group plan is not made for (tables small against the batch, popularity skew): sorted plans from
+                # here on; after an overflow this chunk is re-planned too (its lists are incomplete)
+                h["group"] = False
+                self.stats["group_fallbacks"] += 1
+                if h["next"] is not None and h["next"][0] != cur[0]:
+                    raise AssertionError("plan pipeline out of step")
+                if plan.overflow:
+                    first, B = cur[0], h["B"]
+                    lo, hi = first * B, first * B + plan.n_triplets
+                    plan.arena.release_after(main)
+                    if h["arenas"] is None:
+                        h["arenas"] = self._arena_pair(h["device"], B, h["nb"], h["n_items"] if h["chain"] else 0)
+                    with torch.cuda.stream(self._build_stream(h)):
+                        plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
+                                                  validate=False, ws_tag="rot%d" % h["tag"], arena=h["arenas"][h["tag"]],
+                                                  defer=True, overlap=h["chain"])
+                    h["tag"] ^= 1
+                    plan.validate()
+                    cur = (first, plan)
+            main.wait_event(plan.ready)
+            h["cur"], h["next"] = cur, None
+            return cur
         main.wait_event(plan.ready)
         if plan.fast_overflowed:
             # skewed ids: equal-width buckets overflow chunk after chunk.  Balance the buckets by the rows' share of
@@ -1279,6 +1499,9 @@ class PipelinedSgd:
                 self.stats["graph_replays"] += 1
                 losses[loss_off:loss_off + c].copy_(graph[1])
                 sg["tabs"].step_id += c
+            elif isinstance(plan, GroupPlan):
+                sg["tabs"].run_sgd_group(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
+                self.stats["group_calls"] += 1
             elif h["runner"] is not None:
                 h["runner"](plan, pos - base, c, losses[loss_off:loss_off + c])
                 self.stats["plain_calls"] += 1
