@@ -367,7 +367,8 @@ int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab
 int64_t wr_group_plan_words(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items);
 /* out[16] = {n_batches, flag words per batch, user ranges, item ranges, user hash mask, item hash mask, and the offsets (in
  * int32 words from `plan`) of: flags [nb][fw][4], user list lengths [nb][R_u], item list lengths [nb][R_i], user list rows,
- * user list positions, item list rows, item list sources [nb][R][cap]; total words; cap; meta words} — for tools and tests */
+ * user list sources, item list rows, item list sources [nb][R][cap]; total words; cap of a user segment; cap of an item
+ * segment} — for tools and tests */
 int32_t wr_group_plan_layout(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items, int64_t *out);
 int32_t wr_group_plan_build(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets, int64_t batch_size,
                             int64_t n_users, int64_t n_items, int32_t *plan, int64_t plan_words, void *stream);

@@ -113,18 +113,20 @@ def test_steps_match_oracle_and_are_reproducible(ops, nU, nI, D, B):
     assert rel_err(outs[0][1].cpu().numpy(), ref.I.cpu().numpy()) < 1e-6
 
 
-def test_hot_row_and_single_user_batches(ops):
-    """degenerate batches: one user for every triplet (a single run of B entries, far beyond the staged window), one item
-    row with 300 occurrences — slow paths, same results"""
+def test_hot_rows_take_the_slow_paths(ops):
+    """degenerate batches: a user with 150 triplets in one batch and an item row with 200 occurrences — runs far beyond the
+    tiles' staged window (slow paths, same results; the plan says `long_run`).  More than 256 occurrences of one row are
+    beyond what the plan orders: `overflow`, and the caller takes the sorted plan."""
     dev = torch.device("cuda:0")
     nU, nI, D, B, nb, lr = 40_000, 50_000, 64, 2048, 3, 0.05
     u, p, n = _epoch(9, nU, nI, nb * B)
-    u[B:2 * B] = 123
-    p[:300] = 77
+    u[B:B + 150] = 123
+    p[:200] = 77
     n[2 * B:2 * B + 40] = 77
     U, I = _tables(4, nU, nI, D)
     plan = ops.GroupPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI)
     assert plan.long_run and not plan.overflow
+    _same_plan(plan.decode(), oracle.group_plan(u, p, n, B, nU, nI))
     tabs = ops.BprmfTables(T(U, dev), T(I, dev))
     losses = tabs.run_sgd_group(plan, 0, nb, lr)
     torch.cuda.synchronize()
@@ -134,6 +136,8 @@ def test_hot_row_and_single_user_batches(ops):
               for k in range(nb)]
     assert rel_err(losses.cpu().numpy(), np.asarray(lo_ref)) < TOL
     assert rel_err(tabs.U.cpu().numpy(), Uo) < TOL and rel_err(tabs.I.cpu().numpy(), Io) < TOL
+    u[B:2 * B] = 123                                                # one user for a whole batch
+    assert ops.GroupPlan(T(u, dev), T(p, dev), T(n, dev), B, nU, nI).overflow
 
 
 def test_headline_shape_rows_outside_the_batch_untouched(ops):

@@ -40,27 +40,33 @@ constexpr int kGpThreads = 1024;
 constexpr unsigned kGpRangeBits = 18;                 // hashed rows per range workgroup: 2^18
 constexpr int kGpWords = 1 << (kGpRangeBits - 5);     // words of one bitmap (32 KiB)
 constexpr int kGpCap = 8192;                          // list entries per (batch, side, range): 64 KiB of 8-byte keys in LDS
-constexpr int kGpMaxRanges = 8;                       // hashed space <= 2^21 rows
+constexpr int kGpBins = 4096;                         // counting-sort bins of a range: 64 hashed rows each
+constexpr int kGpMaxBin = 256;                        // longest bin ordered by ranking (else: overflow)
+constexpr int kGpMaxRanges = 8;                       // hashed space <= 2^21 rows (gs_tile_of loads 8 lengths)
 constexpr int64_t kGpMaxBatch = 1 << 17;              // three flag arrays of B / 32 words in LDS
-constexpr int kGpLongRun = 32;                        // a run longer than this sets meta[2] (the caller goes back to the sorted plan)
+constexpr int kGpLongRun = 32;                        // a bin with more entries than this sets meta[2] (a hot row: the caller goes
+                                                      // back to the sorted plan, whose hot-row path is made for it)
 constexpr int kGpMetaWords = 16;
 #ifndef WR_GP_DBG
-#define WR_GP_DBG 0      // timing-only variants (A/B builds, never shipped; all stay inside the arrays): 1 no sort, 2 no second scan,
-#endif                 // 4 no flag words out, 8 no first scan, 16 no deferral scan
+#define WR_GP_DBG 0      // timing-only variants (A/B builds, never shipped; all stay inside the arrays): 1 no ordering, 2 no second
+#endif                 // scan, 4 no flag words out, 8 no first scan, 16 no deferral scan
 
 struct GroupLayout {
     int64_t nb, B, fw;
-    int R_u, R_i;
-    unsigned mask_u, mask_i;
+    int R_u, R_i, cap_u, cap_i;     // ranges per batch and side; entries a range's list segment holds in the plan
+    unsigned mask_u, mask_i, hbits_u, hbits_i;
     int64_t flags, ucnt, icnt, ul_row, ul_src, il_row, il_src, total;   // offsets in int32 words; meta at 0
     int64_t zero_words;                                                  // meta + flags + counts: cleared before a build
 };
 
-static inline int ranges_for(int64_t n_rows, unsigned *mask) {
+static inline int ranges_for(int64_t n_rows, unsigned *mask, unsigned *hbits, int *cap) {
     unsigned bits = kGpRangeBits;
     while (bits < kGpRangeBits + 3 && (int64_t(1) << bits) < n_rows) ++bits;
     *mask = (1u << bits) - 1u;
-    return 1 << (bits - kGpRangeBits);
+    *hbits = bits;
+    const int R = 1 << (bits - kGpRangeBits);
+    *cap = kGpCap;
+    return R;
 }
 
 static bool group_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items, GroupLayout &L) {
@@ -69,33 +75,34 @@ static bool group_layout(int64_t n, int64_t B, int64_t n_users, int64_t n_items,
     L.nb = (n + B - 1) / B;
     L.B = B;
     L.fw = (B + 31) / 32;
-    L.R_u = ranges_for(n_users, &L.mask_u);
-    L.R_i = ranges_for(n_items, &L.mask_i);
+    L.R_u = ranges_for(n_users, &L.mask_u, &L.hbits_u, &L.cap_u);
+    L.R_i = ranges_for(n_items, &L.mask_i, &L.hbits_i, &L.cap_i);
     L.flags = kGpMetaWords;
     L.ucnt = L.flags + L.nb * L.fw * 4;
     L.icnt = L.ucnt + align_up(L.nb * L.R_u, 4);
     L.zero_words = L.icnt + align_up(L.nb * L.R_i, 4);
     L.ul_row = L.zero_words;
-    L.ul_src = L.ul_row + L.nb * L.R_u * (int64_t)kGpCap;
-    L.il_row = L.ul_src + L.nb * L.R_u * (int64_t)kGpCap;
-    L.il_src = L.il_row + L.nb * L.R_i * (int64_t)kGpCap;
-    L.total = L.il_src + L.nb * L.R_i * (int64_t)kGpCap;
+    L.ul_src = L.ul_row + L.nb * L.R_u * (int64_t)L.cap_u;
+    L.il_row = L.ul_src + L.nb * L.R_u * (int64_t)L.cap_u;
+    L.il_src = L.il_row + L.nb * L.R_i * (int64_t)L.cap_i;
+    L.total = L.il_src + L.nb * L.R_i * (int64_t)L.cap_i;
     return true;
 }
 
 struct GpDev {
-    int *meta;            // [0] id out of range, [1] a list overflowed, [2] a run longer than kGpLongRun
+    int *meta;            // [0] id out of range, [1] a list overflowed, [2] a row with more than kGpLongRun occurrences
     unsigned *flags;      // [nb][fw][4] = {US, PS, NS, DF}
     int *ucnt, *icnt;     // [nb][R]
-    int *ul_row, *ul_src, *il_row, *il_src;   // [nb][R][kGpCap]
-    int R_u, R_i;
-    unsigned mask_u, mask_i;
+    int *ul_row, *ul_src, *il_row, *il_src;   // [nb][R][cap]
+    int R_u, R_i, cap_u, cap_i;
+    unsigned mask_u, mask_i, hbits_u, hbits_i;
     int fw;
 };
 
 static inline GpDev group_dev(int32_t *plan, const GroupLayout &L) {
     return GpDev{plan, reinterpret_cast<unsigned *>(plan + L.flags), plan + L.ucnt, plan + L.icnt, plan + L.ul_row,
-                 plan + L.ul_src, plan + L.il_row, plan + L.il_src, L.R_u, L.R_i, L.mask_u, L.mask_i, (int)L.fw};
+                 plan + L.ul_src, plan + L.il_row, plan + L.il_src, L.R_u, L.R_i, L.cap_u, L.cap_i, L.mask_u, L.mask_i,
+                 L.hbits_u, L.hbits_i, (int)L.fw};
 }
 
 // f(value, position) over a[0 .. cnt): 16-byte loads when the array is aligned (batch starts are, for batch sizes that are
@@ -133,15 +140,17 @@ __device__ __forceinline__ void gp_scan(const int *__restrict__ a, int cnt, F f)
     }
 }
 
+// One workgroup = (batch, side, range of 2^18 hashed rows).  LDS: region X (64 KiB: the "seen" bitmap in its first half, then
+// the list of shared (row, source) keys), region M (32 KiB: the "several" bitmap, then the bins' counters and the keys'
+// indices grouped by bin), three flag arrays of B / 32 words.
 __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__restrict__ u, const int *__restrict__ p,
                                                                  const int *__restrict__ n, int64_t n_total, int B, int nb,
                                                                  int n_users, int n_items, GpDev L) {
-    // every LDS word lives in the dynamic region (a static __shared__ in front of it would shift its base off the 8-byte
-    // alignment the keys need: a misaligned ds_read_b64 is replayed at 64 cycles — the sort ran 8x slower)
+    // every LDS word lives in the dynamic region, 16-byte aligned (cdna_hip_programming.md, Guideline 17)
     extern __shared__ __attribute__((aligned(16))) unsigned gp_lds[];
-    unsigned *seen = gp_lds;                                                  // words [0, kGpWords) of the first region
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(gp_lds);   // the same region later: kGpCap keys
-    unsigned *multi = gp_lds + 2 * kGpCap;
+    unsigned *seen = gp_lds;                                                       // words [0, kGpWords) of region X
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(gp_lds);     // region X later: kGpCap 8-byte keys
+    unsigned *multi = gp_lds + 2 * kGpCap;                                         // region M
     unsigned *f0 = multi + kGpWords, *f1 = f0 + L.fw, *f2 = f1 + L.fw;
     int &n_list = *reinterpret_cast<int *>(f2 + L.fw);
     const int per = L.R_u + L.R_i;
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
     const int Bb = (int)((base + B <= n_total) ? B : (n_total - base));
     const unsigned n_rows = (unsigned)(item ? n_items : n_users);
     const unsigned mask = item ? L.mask_i : L.mask_u;
+    constexpr unsigned rmask = (1u << kGpRangeBits) - 1u;
     for (int i = threadIdx.x; i < kGpWords; i += kGpThreads) {
         seen[i] = 0u;
         multi[i] = 0u;
@@ -169,33 +179,25 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
         }
         const unsigned h = (unsigned)row & mask;
         if ((h >> kGpRangeBits) != r) return;
-        const unsigned bit = h & ((1u << kGpRangeBits) - 1u), m = 1u << (bit & 31u);
-#if WR_GP_DBG & 32
-        const unsigned old = seen[bit >> 5];        // timing only: no atomics (racy, wrong bits)
-        seen[bit >> 5] = old | m;
-        if (old & m) multi[bit >> 5] |= m;
-#elif WR_GP_DBG & 64
-        atomicOr(&seen[bit >> 5], m);               // timing only: no returned value
-#else
+        const unsigned bit = h & rmask, m = 1u << (bit & 31u);
         const unsigned old = atomicOr(&seen[bit >> 5], m);
         if (old & m) atomicOr(&multi[bit >> 5], m);
-#endif
     };
     if (!(WR_GP_DBG & 8)) {
-    if (item) {
-        gp_scan(p + base, Bb, mark);
-        gp_scan(n + base, Bb, mark);
-    } else {
-        gp_scan(u + base, Bb, mark);
-    }
+        if (item) {
+            gp_scan(p + base, Bb, mark);
+            gp_scan(n + base, Bb, mark);
+        } else {
+            gp_scan(u + base, Bb, mark);
+        }
     }
     __syncthreads();
-    // scan B: flag the shared occurrences and collect them (the list takes over the "seen" region)
+    // scan B: flag the shared occurrences and collect their sources (the list takes over the "seen" region); an id out of
+    // range was reported by scan A and its hashed bit is inside the bitmap anyway
     auto several = [&](int row) -> bool {
-        if ((unsigned)row >= n_rows) return false;
         const unsigned h = (unsigned)row & mask;
         if ((h >> kGpRangeBits) != r) return false;
-        const unsigned bit = h & ((1u << kGpRangeBits) - 1u);
+        const unsigned bit = h & rmask;
         return (multi[bit >> 5] >> (bit & 31u)) & 1u;
     };
     auto append = [&](int row, unsigned src) {
@@ -203,43 +205,37 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
         if (pos < kGpCap) keys[pos] = ((unsigned long long)(unsigned)row << 32) | src;
     };
     if (!(WR_GP_DBG & 2)) {
-    if (item) {
-        gp_scan(p + base, Bb, [&](int row, int t) {
-            if (several(row)) {
-                atomicOr(&f0[t >> 5], 1u << (t & 31));
-                append(row, (unsigned)t << 1);
-            }
-        });
-        gp_scan(n + base, Bb, [&](int row, int t) {
-            if (several(row)) {
-                atomicOr(&f1[t >> 5], 1u << (t & 31));
-                append(row, ((unsigned)t << 1) | 1u);
-            }
-        });
-        if (b + 1 < nb && !(WR_GP_DBG & 16)) {   // the next batch's triplets that read a row this batch's item tiles rewrite
-            const int64_t nbase = base + B;
-            const int Bn = (int)((nbase + B <= n_total) ? B : (n_total - nbase));
-            auto defer = [&](int row, int t) {
-                if (several(row)) atomicOr(&f2[t >> 5], 1u << (t & 31));
-            };
+        const bool next = b + 1 < nb && !(WR_GP_DBG & 16);
+        const int64_t nbase = base + B;
+        const int Bn = next ? (int)((nbase + B <= n_total) ? B : (n_total - nbase)) : 0;
+        // the next batch's triplets that read a row this batch's tiles rewrite
+        auto defer = [&](int row, int t) {
+            if (several(row)) atomicOr(&f2[t >> 5], 1u << (t & 31));
+        };
+        if (item) {
+            gp_scan(p + base, Bb, [&](int row, int t) {
+                if (several(row)) {
+                    atomicOr(&f0[t >> 5], 1u << (t & 31));
+                    append(row, (unsigned)t << 1);
+                }
+            });
+            gp_scan(n + base, Bb, [&](int row, int t) {
+                if (several(row)) {
+                    atomicOr(&f1[t >> 5], 1u << (t & 31));
+                    append(row, ((unsigned)t << 1) | 1u);
+                }
+            });
             gp_scan(p + nbase, Bn, defer);
             gp_scan(n + nbase, Bn, defer);
-        }
-    } else {
-        gp_scan(u + base, Bb, [&](int row, int t) {
-            if (several(row)) {
-                atomicOr(&f0[t >> 5], 1u << (t & 31));
-                append(row, (unsigned)t << 1);
-            }
-        });
-        if (b + 1 < nb && !(WR_GP_DBG & 16)) {   // the next batch's triplets whose user row this batch's user tiles rewrite
-            const int64_t nbase = base + B;
-            const int Bn = (int)((nbase + B <= n_total) ? B : (n_total - nbase));
-            gp_scan(u + nbase, Bn, [&](int row, int t) {
-                if (several(row)) atomicOr(&f2[t >> 5], 1u << (t & 31));
+        } else {
+            gp_scan(u + base, Bb, [&](int row, int t) {
+                if (several(row)) {
+                    atomicOr(&f0[t >> 5], 1u << (t & 31));
+                    append(row, (unsigned)t << 1);
+                }
             });
+            gp_scan(u + nbase, Bn, defer);
         }
-    }
     }
     __syncthreads();
     // flags out: the ranges of a batch OR their words together (agent-scope, no return value)
@@ -252,38 +248,72 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
                 __hip_atomic_fetch_or(fb + 4 * (L.fw + w) + 3, f2[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    const int cap = item ? L.cap_i : L.cap_u, R = item ? L.R_i : L.R_u;
     int m = n_list;
-    if (m > kGpCap) {
+    if (m > cap) {
         if (threadIdx.x == 0) L.meta[1] = 1;
-        m = kGpCap;
+        m = cap;
     }
-    // bitonic sort of the m keys (unique: (row, position)), padded to a power of two with ~0
-    int P = 2;
-    while (P < m) P <<= 1;
-    for (int i = m + threadIdx.x; i < P; i += kGpThreads) keys[i] = ~0ull;
+    // Order the m keys by (hashed row, row, source) without a comparison sort: a counting sort over bins of 64 hashed rows
+    // places the keys' INDICES (16 bits each) grouped by bin, and a key's final position is its bin's start + the number of
+    // smaller keys in its bin (keys are unique; a bin holds ~1 key).  Equal rows end up adjacent, in source order: what the
+    // tiles need.  (A bitonic sort of the same keys took 2.1 of the 4.7 us per batch of the first version.)
+    int *cnt = reinterpret_cast<int *>(multi);                                      // the "several" bitmap is done with
+    unsigned short *out16 = reinterpret_cast<unsigned short *>(multi + kGpBins);
+    int *wave_tot = reinterpret_cast<int *>(f0);                                    // the flag arrays have been written out
+    auto bin_of = [&](unsigned long long k) -> int { return (int)((((unsigned)(k >> 32) & mask) & rmask) >> 6); };
+    int *lrow = (item ? L.il_row : L.ul_row) + ((int64_t)b * R + r) * cap, *lsrc = (item ? L.il_src : L.ul_src) + ((int64_t)b * R + r) * cap;
+    __syncthreads();      // every thread has read n_list and written its flag words out
+    for (int i = threadIdx.x; i < kGpBins; i += kGpThreads) cnt[i] = 0;
     __syncthreads();
-    for (int k = 2; k <= P && !(WR_GP_DBG & 1); k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < (P >> 1); i += kGpThreads) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
-                const unsigned long long x = keys[lo], y = keys[hi];
-                const bool up = (lo & k) == 0;
-                if ((x > y) == up) {
-                    keys[lo] = y;
-                    keys[hi] = x;
-                }
-            }
-            __syncthreads();
+    if (!(WR_GP_DBG & 1)) {
+        for (int j = threadIdx.x; j < m; j += kGpThreads) atomicAdd(&cnt[bin_of(keys[j])], 1);
+        __syncthreads();
+        // exclusive scan of the kGpBins counters: thread t owns counters [4 t, 4 t + 4)
+        constexpr int kOwn = kGpBins / kGpThreads;
+        const int c0 = (int)threadIdx.x * kOwn;
+        int local = 0;
+#pragma unroll
+        for (int j = 0; j < kOwn; ++j) local += cnt[c0 + j];
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) incl += v;
         }
-    }
-    const int R = item ? L.R_i : L.R_u;
-    const int64_t seg = ((int64_t)b * R + r) * kGpCap;
-    int *lrow = (item ? L.il_row : L.ul_row) + seg, *lsrc = (item ? L.il_src : L.ul_src) + seg;
-    for (int i = threadIdx.x; i < m; i += kGpThreads) {
-        const unsigned long long k = keys[i];
-        lrow[i] = (int)(k >> 32);
-        lsrc[i] = (int)(unsigned)k;
-        if (i + kGpLongRun < m && (keys[i + kGpLongRun] >> 32) == (k >> 32)) L.meta[2] = 1;
+        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wave_tot[w];
+#pragma unroll
+        for (int j = 0; j < kOwn; ++j) {
+            const int c = cnt[c0 + j];
+            cnt[c0 + j] = run;
+            run += c;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < m; j += kGpThreads) out16[atomicAdd(&cnt[bin_of(keys[j])], 1)] = (unsigned short)j;
+        __syncthreads();
+        // cnt[bin] is now the END of the bin; its start is the end of the bin before
+        for (int j = threadIdx.x; j < m; j += kGpThreads) {
+            const unsigned long long k = keys[j];
+            const int bin = bin_of(k);
+            const int lo = bin ? cnt[bin - 1] : 0, hi = cnt[bin];
+            if (hi - lo > kGpLongRun) L.meta[2] = 1;
+            if (hi - lo > kGpMaxBin) {
+                L.meta[1] = 1;
+                continue;
+            }
+            int pos = lo;
+            for (int jj = lo; jj < hi; ++jj) pos += keys[out16[jj]] < k ? 1 : 0;
+            lrow[pos] = (int)(k >> 32);
+            lsrc[pos] = (int)(unsigned)k;
+        }
+    } else {
+        for (int j = threadIdx.x; j < m; j += kGpThreads) {
+            lrow[j] = (int)(keys[j] >> 32);
+            lsrc[j] = (int)(unsigned)keys[j];
+        }
     }
     if (threadIdx.x == 0) (item ? L.icnt : L.ucnt)[(int64_t)b * R + r] = m;
 }
@@ -302,7 +332,7 @@ struct GsBatch {
     const int *u, *p, *n;
     const uint4 *flags;
     const int *ul_row, *ul_src, *ul_cnt, *il_row, *il_src, *il_cnt;
-    int B, R_u, R_i;
+    int B, R_u, R_i, cap_u, cap_i;
 };
 
 struct GsArgs {
@@ -408,7 +438,7 @@ __device__ __forceinline__ void gs_wait_tiles(const GsArgs &a) {
 
 // tile q of a batch side's lists -> (segment, first entry, entries of the segment); false when q is beyond the last tile.
 // All segment lengths are fetched together (one round trip, not one per segment).
-__device__ __forceinline__ bool gs_tile_of(const int *__restrict__ cnt, int R, int q, int &seg, int &e0, int &len) {
+__device__ __forceinline__ bool gs_tile_of(const int *__restrict__ cnt, int R, int cap, int q, int &seg, int &e0, int &len) {
     int c[kGpMaxRanges];
 #pragma unroll
     for (int s = 0; s < kGpMaxRanges; ++s) c[s] = cnt[s < R ? s : 0];      // unconditional loads, one wait for all of them
@@ -419,7 +449,7 @@ __device__ __forceinline__ bool gs_tile_of(const int *__restrict__ cnt, int R, i
     bool found = false;
 #pragma unroll
     for (int s = 0; s < kGpMaxRanges; ++s) {
-        const int cs = min(c[s], kGpCap);
+        const int cs = min(c[s], cap);
         const int nt = (cs + kGsTile - 1) / kGsTile;
         if (!found && q < nt) {
             seg = s;
@@ -444,9 +474,9 @@ struct GsTile {
 };
 
 __device__ __forceinline__ void gs_tile_fetch(GsTile &tl, const int *__restrict__ l_row, const int *__restrict__ l_src, int seg,
-                                              int e0, int len, int B) {
-    tl.lrow = l_row + (int64_t)seg * kGpCap;
-    tl.lsrc = l_src + (int64_t)seg * kGpCap;
+                                              int cap, int e0, int len, int B) {
+    tl.lrow = l_row + (int64_t)seg * cap;
+    tl.lsrc = l_src + (int64_t)seg * cap;
     tl.e0 = e0;
     tl.len = len;
     tl.er = -1;
@@ -545,13 +575,13 @@ __device__ __forceinline__ void gs_tile_finish(float *__restrict__ W, int D, flo
 
 template <int T, int NV, bool FULL, bool WT>
 __device__ __forceinline__ void gs_list_tiles(float *__restrict__ W, int D, float lr, const int *__restrict__ l_row,
-                                              const int *__restrict__ l_src, const int *__restrict__ l_cnt, int R, int B,
-                                              const float *__restrict__ Z, int w, int nw, int *__restrict__ lds) {
+                                              const int *__restrict__ l_src, const int *__restrict__ l_cnt, int R, int cap,
+                                              int B, const float *__restrict__ Z, int w, int nw, int *__restrict__ lds) {
     for (int q = w;; q += nw) {      // workgroup `w` of `nw` takes tiles w, w + nw, ...
         int seg, e0, len;
-        if (!gs_tile_of(l_cnt, R, q, seg, e0, len)) break;
+        if (!gs_tile_of(l_cnt, R, cap, q, seg, e0, len)) break;
         GsTile tl;
-        gs_tile_fetch(tl, l_row, l_src, seg, e0, len, B);
+        gs_tile_fetch(tl, l_row, l_src, seg, cap, e0, len, B);
         gs_tile_finish<T, NV, FULL, WT>(W, D, lr, B, Z, tl, lds);
     }
 }
@@ -573,14 +603,14 @@ __global__ __launch_bounds__(kBlock, NV == 1 ? WR_GS_WAVES : 1) void bprmf_group
         const bool wt = a.nA > 0;      // tiles that ride beside the next batch's triplets hand their rows over
         if (!(WR_GS_DBG & 1)) {
             if (w < a.nIT) {
-                if (wt) gs_list_tiles<T, NV, FULL, true>(a.I, a.D, a.lr, a.prev.il_row, a.prev.il_src, a.prev.il_cnt, a.prev.R_i,
+                if (wt) gs_list_tiles<T, NV, FULL, true>(a.I, a.D, a.lr, a.prev.il_row, a.prev.il_src, a.prev.il_cnt, a.prev.R_i, a.prev.cap_i,
                                                          a.prev.B, a.Zp, w, a.nIT, lds);
-                else gs_list_tiles<T, NV, FULL, false>(a.I, a.D, a.lr, a.prev.il_row, a.prev.il_src, a.prev.il_cnt, a.prev.R_i,
+                else gs_list_tiles<T, NV, FULL, false>(a.I, a.D, a.lr, a.prev.il_row, a.prev.il_src, a.prev.il_cnt, a.prev.R_i, a.prev.cap_i,
                                                        a.prev.B, a.Zp, w, a.nIT, lds);
             } else {
-                if (wt) gs_list_tiles<T, NV, FULL, true>(a.U, a.D, a.lr, a.prev.ul_row, a.prev.ul_src, a.prev.ul_cnt, a.prev.R_u,
+                if (wt) gs_list_tiles<T, NV, FULL, true>(a.U, a.D, a.lr, a.prev.ul_row, a.prev.ul_src, a.prev.ul_cnt, a.prev.R_u, a.prev.cap_u,
                                                          a.prev.B, a.ZUp, w - a.nIT, a.nUT, lds);
-                else gs_list_tiles<T, NV, FULL, false>(a.U, a.D, a.lr, a.prev.ul_row, a.prev.ul_src, a.prev.ul_cnt, a.prev.R_u,
+                else gs_list_tiles<T, NV, FULL, false>(a.U, a.D, a.lr, a.prev.ul_row, a.prev.ul_src, a.prev.ul_cnt, a.prev.R_u, a.prev.cap_u,
                                                        a.prev.B, a.ZUp, w - a.nIT, a.nUT, lds);
             }
         }
@@ -702,8 +732,10 @@ static inline bool gs_shape_ok(const float *U, const float *I, int32_t D) {
 #define WR_GS_TILES_AT 0     // where the tile workgroups sit among the main ones (in 1/16 of the main grid)
 #endif
 #ifndef WR_GS_SIDE_AT
-#define WR_GS_SIDE_AT 2      // where the deferred workgroups sit among the main ones (in 1/16 of the main grid)
-#endif
+#define WR_GS_SIDE_AT 12     // where the deferred workgroups sit among the main ones (in 1/16 of the main grid).  They poll from
+#endif                       // the moment they are dispatched: A/B on MI355X, 1M x 1M x 64, B = 65,536, us per launch at 2 / 6 / 8 /
+                             // 10 / 12 / 14 sixteenths: 25.2 / 23.8 / 23.2 / 22.5 / 22.3 / 21.7-21.9 (12-14 tie within noise; the
+                             // ~1,150 deferred triplets of a batch take 64 workgroups two rounds of teams, ~4 us)
 #ifndef WR_GS_NUT
 #define WR_GS_NUT 256
 #endif
@@ -711,7 +743,7 @@ static inline bool gs_shape_ok(const float *U, const float *I, int32_t D) {
 #define WR_GS_NDS 64
 #endif
 #ifndef WR_GS_NIT
-#define WR_GS_NIT 768
+#define WR_GS_NIT 1024
 #endif
 
 template <int T, int NV, bool FULL>
@@ -736,9 +768,9 @@ static int32_t launch_group_steps(float *U, float *I, int32_t D, const int32_t *
         const int64_t off = b * B;
         const int Bk = (int)((off + B <= n_triplets) ? B : (n_triplets - off));
         return GsBatch{u + off, p + off, n + off, reinterpret_cast<const uint4 *>(G.flags + b * L.fw * 4),
-                       G.ul_row + b * L.R_u * (int64_t)kGpCap, G.ul_src + b * L.R_u * (int64_t)kGpCap, G.ucnt + b * L.R_u,
-                       G.il_row + b * L.R_i * (int64_t)kGpCap, G.il_src + b * L.R_i * (int64_t)kGpCap, G.icnt + b * L.R_i,
-                       Bk, L.R_u, L.R_i};
+                       G.ul_row + b * L.R_u * (int64_t)L.cap_u, G.ul_src + b * L.R_u * (int64_t)L.cap_u, G.ucnt + b * L.R_u,
+                       G.il_row + b * L.R_i * (int64_t)L.cap_i, G.il_src + b * L.R_i * (int64_t)L.cap_i, G.icnt + b * L.R_i,
+                       Bk, L.R_u, L.R_i, L.cap_u, L.cap_i};
     };
     auto ev = [&](int64_t k, int j) { return events ? reinterpret_cast<hipEvent_t>(events[2 * k + j]) : (hipEvent_t) nullptr; };
     int n_partials_prev = 0;
@@ -806,7 +838,7 @@ int32_t wr_group_plan_layout(int64_t n_triplets, int64_t batch_size, int64_t n_u
     WR_REQUIRE(group_layout(n_triplets, batch_size, n_users, n_items, L), WR_E_RANGE,
                "group plan not applicable to n=%lld, batch=%lld", (long long)n_triplets, (long long)batch_size);
     const int64_t v[16] = {L.nb, L.fw, L.R_u, L.R_i, (int64_t)L.mask_u, (int64_t)L.mask_i, L.flags, L.ucnt, L.icnt, L.ul_row,
-                           L.ul_src, L.il_row, L.il_src, L.total, kGpCap, kGpMetaWords};
+                           L.ul_src, L.il_row, L.il_src, L.total, L.cap_u, L.cap_i};
     for (int i = 0; i < 16; ++i) out[i] = v[i];
     return WR_OK;
 }

@@ -680,7 +680,7 @@ class GroupPlan:
         abi.check(abi.lib().wr_group_plan_layout(self.n_triplets, self.batch_size, self.n_users, self.n_items,
                                                  ctypes.addressof(out)), "wr_group_plan_layout")
         keys = ("nb", "fw", "R_u", "R_i", "mask_u", "mask_i", "flags", "ucnt", "icnt", "ul_row", "ul_src", "il_row", "il_src",
-                "total", "cap", "meta")
+                "total", "cap_u", "cap_i")
         return dict(zip(keys, [int(v) for v in out]))
 
     def decode(self):
@@ -690,10 +690,11 @@ class GroupPlan:
         self.finish()
         Ly = self.layout()
         w = self.buf[:Ly["total"]].cpu().numpy()
-        nb, fw, cap = Ly["nb"], Ly["fw"], Ly["cap"]
+        nb, fw = Ly["nb"], Ly["fw"]
         flags = w[Ly["flags"]:Ly["flags"] + nb * fw * 4].view(np.uint32).reshape(nb, fw, 4).copy()
         out = {"flags": flags, "users": {}, "items": {}, "R_u": Ly["R_u"], "R_i": Ly["R_i"], "meta": w[:self.META].copy()}
-        for side, R, co, ro, so in (("users", Ly["R_u"], "ucnt", "ul_row", "ul_src"), ("items", Ly["R_i"], "icnt", "il_row", "il_src")):
+        for side, R, cap, co, ro, so in (("users", Ly["R_u"], Ly["cap_u"], "ucnt", "ul_row", "ul_src"),
+                                         ("items", Ly["R_i"], Ly["cap_i"], "icnt", "il_row", "il_src")):
             for b in range(nb):
                 for r in range(R):
                     c = int(w[Ly[co] + b * R + r])
