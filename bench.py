@@ -50,9 +50,6 @@ def parse(argv=None):
     ap.add_argument("--lr", type=float, default=0.05)
     ap.add_argument("--chunk", type=int, default=0, help="batches per plan build (0: min(64, steps))")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent over items (0 = uniform, headline)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="A/B: overlapped step stream (item phase of step k beside the user phase of step k+1, hipGraph replays); "
-                         "slower than the ordinary stream on this stack, see DESIGN.md section 4")
     ap.add_argument("--plan-stream", choices=["side", "inline"], default="side",
                     help="N=1: where the next chunk's plan is built: on a side stream beside the steps (default), or on the "
                          "step stream between the halves of the current chunk (measured slower; kept for the A/B)")
@@ -238,18 +235,11 @@ def single_gpu(args, local_rank):
     # steps — and the timed region builds the plans of the chunks that FOLLOW its own chunks, the last of which is the spare
     # one: K batches' worth of plan builds between the two timestamps, K steps trained.
     u, p, n = synth_triplets((K + W + C) * B, args.users, args.items, dev, 3407, args.zipf)
-    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, overlap=args.overlap, chain=not args.no_chain,
+    pipe = hip_ops.PipelinedSgd(chunk=C, min_triplets=1, chain=not args.no_chain,
                                 inline_plan=args.plan_stream == "inline", group=not args.no_group)
     losses_w = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
     losses = torch.empty(K, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    if args.overlap:
-        # Untimed priming of the overlapped stream, before the warm-up: its two hipGraphs (one per plan arena) are captured
-        # and each is replayed once, on the first 2 C batches of the data.  These are ordinary training steps; they are
-        # neither part of the W warm-up steps nor of the K timed ones.
-        prime = pipe.plan(U, [(I, u[:2 * C * B], p[:2 * C * B], n[:2 * C * B])], B, lr=args.lr)
-        pipe.run_steps(prime, 2 * C, args.lr, torch.empty(2 * C, dtype=torch.float32, device=dev))
-        torch.cuda.synchronize()
     # the warm-up is two plans long when it can be, so that every host path of the pipeline has run twice before the clock starts
     # No cyclic-GC pass of the interpreter between here and the end of the timed region, which can be as short as 0.6 ms: a
     # pass costs milliseconds and leaves the host path behind it slower (a gc.collect() right before the clock: host time to
@@ -396,18 +386,16 @@ def single_gpu(args, local_rank):
                       "plan_chunk_batches": C, "tables": "single GPU", "step_stream": "whisprrec_amd.hip_ops.PipelinedSgd",
                       "plan": "group plan (no per-batch sort: flags + lists of the shared rows, wr_group.hip)" if grouped
                               else "sorted batch plan (bucket scatter + LDS sort per table)",
-                      "overlapped_item_phase": bool(not grouped and plan.overlap is not None and handle["overlap"]),
                       "chained_step_launch": bool(grouped or (plan.overlap is not None and handle["chain"])),
                       "step_stream_calls": dict(pipe.stats),
                       "plan_build": "on the step stream, between the halves of the chunk before" if handle["inline"]
                                     else "on a side stream, beside the steps of the chunk before",
-                      "untimed_priming_steps": 2 * C if args.overlap else 0,
                       "host_queue_ms_of_timed_region": host_queue_ms},
            "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
            "roofline": roofline}
     if not args.no_adam:
         out["extra"] = {"adam": adam_extra(args, hip_ops, U, I, u, p, n, dev)}
-    if not args.no_epoch and not args.overlap:
+    if not args.no_epoch:
         del u, p, n
         out.setdefault("extra", {})["epoch"] = epoch_extra(args, hip_ops, U, I, dev)
     if not args.no_cpu_baseline:

@@ -289,33 +289,6 @@ int32_t wr_bprmf_run_sgd(float *user_tab, int64_t n_users, float *item_tab, int6
                          int64_t n_batches, float lr, float *loss_out, void *const *phase_events, const wr_hot_runs *hot,
                          void *workspace, int64_t workspace_bytes, void *stream);
 
-/* Overlapped step stream — the same consecutive steps as wr_bprmf_run_sgd (BaseRunner.py:194-200, l2 = 0, no hot rows),
- * with the item phase of step k running on `stream_side` BESIDE the user phase of step k+1 on `stream_main`.  Legal only for
- * the user runs of batch k+1 that read no item row the item phase of step k rewrites; the plan marks the others
- * (wr_bprmf_plan_overlap_marks) and they run, behind that item phase, as a small launch of their own.  Every table row keeps
- * one writer per step and its summation order: tables bit-identical to wr_bprmf_run_sgd's; the loss of a step differs by
- * the association of its partial sums only (fixed order, bitwise reproducible).
- *   tdef  [n_batches_of_plan * ceil(batch_size/32)] : per batch, bit t%32 of word t/32 = the run headed at sorted position
- *         t is deferred;  def_q [n_batches_of_plan * def_cap] : those positions, ascending;
- *   def_count_host (HOST memory, one int32 per batch of the plan) : their number — every value for batches
- *         (first_batch, first_batch + n_batches) must be in [0, def_cap] (WR_E_RANGE otherwise; the first batch of a call
- *         follows a join of the two streams and defers nothing).
- *   def_count_dev (device memory, may be NULL): the same counts where the kernels can read them.  When given, nothing in
- *         the call depends on host-side counts (the deferred launch is sized for def_cap and reads its length on the
- *         device; def_count_host may then be NULL): the call can be captured into a hipGraph ONCE and replayed for every
- *         plan that is built into the same arrays — one graph launch per plan instead of seven runtime calls per step.
- *   workspace >= 2 * wr_bprmf_step_workspace_bytes(batch_size, D) (stash and loss partials double-buffered by step parity).
- *   events: n_events >= 5 hipEvent_t handles created by the caller (hipEventDisableTiming is fine), used as a ring.
- * On entry the side stream is made to wait for everything queued on stream_main; on return stream_main is ordered behind
- * the last item phase: to the caller it behaves like a call on stream_main alone. */
-int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
-                                 const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
-                                 const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
-                                 int64_t n_batches, float lr, float *loss_out, const int32_t *tdef, const int32_t *def_q,
-                                 const int32_t *def_count_host, const int32_t *def_count_dev, int64_t def_cap, void *workspace,
-                                 int64_t workspace_bytes, void *stream_main, void *stream_side, void *const *events,
-                                 int32_t n_events);
-
 /* Chained step stream — the same consecutive steps as wr_bprmf_run_sgd (BaseRunner.py:194-200, l2 = 0, no hot rows) with
  * ONE launch per step on ONE stream: the item phase of step k-1 rides, as extra workgroups, in the launch that carries the
  * user phase of step k.  The runs of batch k that read an item row that item phase rewrites (the plan's deferred runs,
@@ -323,7 +296,9 @@ int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_t
  * workgroups add to after their (write-through) row stores; every other run needs no ordering.  Every table row keeps one
  * writer per step and its summation order: tables bit-identical to wr_bprmf_run_sgd's; the loss of a step differs by the
  * association of its partial sums only (fixed by the plan, bitwise reproducible).
- *   tdef, def_q, def_count_host, def_cap as for wr_bprmf_run_sgd_overlap.  A step whose batch has more than
+ *   tdef  [n_batches_of_plan * ceil(batch_size/32)] : per batch, bit t%32 of word t/32 = the run headed at sorted position
+ *         t is deferred;  def_q [n_batches_of_plan * def_cap] : those positions, ascending;
+ *   def_count_host (HOST memory, one int32 per batch of the plan) : their number.  A step whose batch has more than
  *         min(def_cap, def_limit) deferred runs (small item tables: almost every run) is issued as the two ordinary
  *         launches; the first step of a call always is, and the call ends with an ordinary item-phase launch — on return
  *         the stream holds complete steps only.
@@ -381,7 +356,7 @@ int32_t wr_bprmf_run_sgd_group(float *user_tab, int64_t n_users, float *item_tab
                                float *loss_out, void *const *events, void *workspace, int64_t workspace_bytes, int32_t *sync,
                                int64_t sync_words, void *stream);
 
-/* Plan-time marks for wr_bprmf_run_sgd_overlap (index work only; call after the plan build, on the same stream).
+/* Plan-time marks for wr_bprmf_run_sgd_chain (index work only; call after the plan build, on the same stream).
  *   bitmap [n_batches * ceil(n_items/32)] (out): per batch, bit r = item row r has several occurrences in the batch;
  *   prev_bitmap: that bitmap of the batch BEFORE this plan's first batch, or NULL (then the first batch defers nothing);
  *   tdef, def_q as above (out); def_count [n_batches] (out, device): deferred runs per batch — may exceed def_cap, in which

@@ -174,3 +174,40 @@ def test_headline_shape_rows_outside_the_batch_untouched(ops):
     l2 = again.run_sgd_group(plan, 0, nb, lr)
     torch.cuda.synchronize()
     assert torch.equal(again.U, tabs.U) and torch.equal(again.I, tabs.I) and torch.equal(l2, losses)
+
+
+def test_expired_wait_is_raised_within_one_chunk(ops, g2):
+    """The only failure of the product whose detection could lag its damage: a bounded wait inside a step launch that
+    expires sets a sticky word.  The step stream copies that word to pinned memory behind every chunk and reads it when the
+    next chunk starts (and when a run ends): with the word set by hand, the stream raises one chunk later — not at the end of
+    the epoch — and HipRunner.fit raises before anything could save or evaluate the tables."""
+    from whisprrec_amd import abi
+    dev = torch.device("cuda:0")
+    nU, nI, D, B, nb, lr = 120_000, 150_000, 64, 8192, 16, 0.05
+    u, p, n = _epoch(31, nU, nI, nb * B)
+    U, I = _tables(5, nU, nI, D)
+    pipe = ops.PipelinedSgd(chunk=4, min_triplets=1)
+    Ud, Id = T(U, dev), T(I, dev)
+    handle = pipe.plan(Ud, [(Id, T(u, dev), T(p, dev), T(n, dev))], B)
+    assert handle["group"]
+    losses = torch.empty(nb, dtype=torch.float32, device=dev)
+    pipe.run_steps(handle, 4, lr, losses[:4])                       # one chunk: nothing wrong
+    tabs = handle["segs"][0]["tabs"]
+    words = tabs.sticky_words()
+    assert words
+    try:
+        for w in words:
+            w.fill_(1)
+        with pytest.raises(abi.WhisprRecHipError, match="expired"):
+            pipe.run_steps(handle, 12, lr, losses[4:])              # raised when the chunk after the next one starts
+        assert handle["pos"] <= 12                                   # ... not after all 16 steps
+        # the model path HipRunner.fit takes (BPRMF.train_epoch -> PipelinedSgd.run): raises before fit returns
+        from test_hip_integration import _setup
+        from whisprrec_amd import runner
+        args, corpus, model, ds = _setup(g2)
+        with pytest.raises(abi.WhisprRecHipError):
+            runner.HipRunner(args).fit(ds, epoch=1)
+    finally:
+        for w in words:
+            w.zero_()
+        torch.cuda.synchronize()

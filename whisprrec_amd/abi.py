@@ -70,9 +70,6 @@ SIGNATURES = {
                                   c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_bprmf_run_sgd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                  c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
-    "wr_bprmf_run_sgd_overlap": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
-                                         c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
-                                         c_i32]),
     "wr_bprmf_chain_supported": (c_i32, [c_vp, c_vp, c_i32]),
     "wr_bprmf_chain_sync_words": (c_i64, [c_i64]),
     "wr_bprmf_run_sgd_chain": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,

@@ -24,9 +24,6 @@
 #include "wr_common.h"
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: stop events attached to a dispatch (timing hooks of launch_step)
 
-#ifndef WR_USER_TWO
-#define WR_USER_TWO 0
-#endif
 #ifndef WR_USER_WAVES
 #define WR_USER_WAVES 8      // waves per SIMD the headline instantiation of the user phase is held to (64 VGPRs)
 #endif
@@ -440,7 +437,7 @@ __device__ __forceinline__ void finish_user_row(float *__restrict__ U, float *__
 
 // Each team works on SLOTS positions (t, t + seg, ...): the index loads of all slots are issued together, then the row
 // loads of all slots, then the slots are finished one after the other.  (Launched with SLOTS = 1; see launch_step.)
-// DEF selects which run heads a launch works on (overlapped step stream, wr_bprmf_run_sgd_overlap):
+// DEF selects which run heads a launch works on (the chained step launch, bprmf_chain_step):
 //   0  every head (the ordinary step);
 //   1  every head whose bit in `dmask` is clear — the runs that read no item row the PREVIOUS batch's item phase is still
 //      rewriting, so this launch may run beside that item phase;
@@ -467,11 +464,6 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
     // trips in a row before the first row load is issued, and a workgroup's lifetime is what bounds the bytes in flight.
     int t0[SLOTS], uu[SLOTS], unext[SLOTS], praw0[SLOTS], nraw0[SLOTS];
     bool head[SLOTS];
-#if WR_USER_TWO
-    // second triplet of the run (97 % of the multi-triplet runs have exactly two): its indices come with the first batch of
-    // index loads and its rows with the first batch of row loads, instead of two more dependent round trips behind the first body
-    int praw1[SLOTS], nraw1[SLOTS], unext2[SLOTS];
-#endif
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         t0[s] = team + s * seg;
@@ -486,12 +478,6 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
                 const int t = dlist[team];
                 t0[s] = t;
                 const int u = tu[t], un = tu[min(t + 1, B - 1)];
-#if WR_USER_TWO
-                const int un2 = tu[min(t + 2, B - 1)];
-                praw1[s] = tp[min(t + 1, B - 1)];
-                nraw1[s] = tn[min(t + 1, B - 1)];
-                unext2[s] = (t + 2 < B) ? un2 : ~u;
-#endif
                 praw0[s] = tp[t];
                 nraw0[s] = tn[t];
                 uu[s] = u;
@@ -503,12 +489,6 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
             const int u = tu[t], uprev = tu[max(t - 1, 0)], un = tu[min(t + 1, B - 1)];
             const int uhot = SKIP_HOT ? tu[min(t + kHotRun, B - 1)] : 0;
             const int dm = DEF == 1 ? dmask[t >> 5] : 0;
-#if WR_USER_TWO
-            const int un2 = tu[min(t + 2, B - 1)];
-            praw1[s] = tp[min(t + 1, B - 1)];
-            nraw1[s] = tn[min(t + 1, B - 1)];
-            unext2[s] = (t + 2 < B) ? un2 : ~u;
-#endif
             praw0[s] = tp[t];
             nraw0[s] = tn[t];
             uu[s] = u;
@@ -520,9 +500,6 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
         }
     }
     Row<NV> ur[SLOTS], pr0[SLOTS], nr0[SLOTS];
-#if WR_USER_TWO
-    Row<NV> pr1[SLOTS], nr1[SLOTS];
-#endif
     Moments<NV, MODE == 4> umv[SLOTS], pmv0[SLOTS], nmv0[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -562,12 +539,6 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
                 ur[s] = load_row<T, NV, FULL>(U, uu[s], D, lane);
                 pr0[s] = load_row<T, NV, FULL>(I, praw0[s] & 0x7fffffff, D, lane);
                 nr0[s] = load_row<T, NV, FULL>(I, nraw0[s] & 0x7fffffff, D, lane);
-#if WR_USER_TWO
-                if (unext[s] == uu[s]) {
-                    pr1[s] = load_row<T, NV, FULL>(I, praw1[s] & 0x7fffffff, D, lane);
-                    nr1[s] = load_row<T, NV, FULL>(I, nraw1[s] & 0x7fffffff, D, lane);
-                }
-#endif
             }
         }
     }
@@ -588,16 +559,6 @@ __device__ __forceinline__ void user_phase_block(float *__restrict__ U, float *I
                                             term_acc, ad, pmv, nmv);
             if (!more) break;
             ++t;   // next triplet of this user (nothing is kept live across the body: 8 waves per SIMD, no spill)
-#if WR_USER_TWO
-            if (MODE != 4 && t == t0[s] + 1) {   // the run's second triplet: indices and rows are already here
-                praw = praw1[s];
-                nraw = nraw1[s];
-                more = unext2[s] == u;
-                pr = pr1[s];
-                nr = nr1[s];
-                continue;
-            }
-#endif
             praw = tp[t];
             nraw = tn[t];
             more = (t + 1 < B) && (tu[t + 1] == u);
@@ -1204,83 +1165,6 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
     return WR_OK;
 }
 
-// ----------------------------------------------------------------------------------------------- overlapped step stream
-// The item phase of step k is ~5 us of latency on ~8 K rows (two dependent round trips), serialised behind the user phase
-// by the kernel boundary.  Here it runs on a second stream BESIDE the user phase of step k+1: the plan marks the user runs
-// of batch k+1 that read an item row the item phase of step k rewrites (rows with several occurrences in batch k: ~1.6 % of
-// the triplets at the headline shape) — those "deferred" runs wait for that item phase (DEF = 2 launch on the second
-// stream), every other run of batch k+1 touches none of its rows (DEF = 1 launch).  Per step:
-//     main stream :  [wait D(k-1)]  user phase of the undeferred runs of batch k                          -> event A(k)
-//     side stream :  user phase of the deferred runs of batch k  -> event D(k);  [wait A(k)]  item phase of batch k
-// D(k-1) lies behind the item phase of step k-2 and the deferred runs of step k-1 on the side stream, so the main launch of
-// step k starts once everything it may read is final; the stash / loss partials are double-buffered by step parity (the
-// item phase of step k reads buffer k % 2 while the user phase of step k+1 fills the other).  Every table row still has
-// exactly one writer per step and the same summation order: the tables come out bit-identical to the ordinary step's.
-template <int T, int NV, bool FULL>
-static int32_t launch_overlap_steps(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
-                                    const int32_t *oc_item, const int32_t *oc_src, int64_t n_triplets, int64_t batch_size,
-                                    int64_t first_batch, int64_t n_batches, float lr, float *loss_out, const int32_t *tdef,
-                                    const int32_t *def_q, const int32_t *def_count_host, const int32_t *def_count_dev,
-                                    int64_t def_cap, void *workspace, hipStream_t sa, hipStream_t sb, hipEvent_t *ev, int n_ev) {
-    const int64_t ws_one = step_ws_bytes(batch_size, D);
-    const StepWs w2[2] = {carve_step_ws(workspace, batch_size, D),
-                          carve_step_ws(reinterpret_cast<char *>(workspace) + ws_one, batch_size, D)};
-    const int64_t dwords = (batch_size + 31) / 32;
-    const dim3 block(kBlock);
-    const AdamArgs ad{};
-    // events: ev[0] = entry / exit join, then R slots of (A, D)
-    const int R = (n_ev - 1) / 2;
-    hipEvent_t ev_join = ev[0];
-    WR_HIP(hipEventRecord(ev_join, sa));            // the side stream starts behind everything queued on the main stream
-    WR_HIP(hipStreamWaitEvent(sb, ev_join, 0));
-    for (int64_t k = 0; k < n_batches; ++k) {
-        const int64_t b = first_batch + k;
-        const int64_t off = b * batch_size;
-        const int64_t Bk = (off + batch_size <= n_triplets) ? batch_size : (n_triplets - off);
-        const StepWs &w = w2[k & 1];
-        hipEvent_t evA = ev[1 + 2 * (k % R)], evD = ev[2 + 2 * (k % R)];
-        // the first batch of a call follows a join: nothing to defer.  Static form (def_count_dev: the counts are read on
-        // the device, the deferred launch is sized for the list's capacity): nothing here depends on host-side counts, so
-        // the whole call can be captured into a hipGraph once and replayed for every plan built into the same arrays.
-        const bool is_static = def_count_dev != nullptr;
-        const int n_def = (k == 0) ? 0 : (is_static ? (int)def_cap : def_count_host[b]);
-        const dim3 gridA((unsigned)n_blocks_for(Bk, D));
-        const dim3 gridD((unsigned)n_blocks_for(n_def, D));
-        const dim3 gridB((unsigned)((2 * Bk + kItemTile - 1) / kItemTile));
-        if (k > 0) WR_HIP(hipStreamWaitEvent(sa, ev[2 + 2 * ((k - 1) % R)], 0));   // D(k-1)
-        if (n_def > 0)
-            hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 1>), gridA, block, 0, sa, U, I, D, tu + off, tp + off,
-                               tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr, (float *)nullptr,
-                               (int *)nullptr, 0, (float)Bk, ad, tdef + b * dwords, (const int *)nullptr, 0,
-                               (const int *)nullptr);
-        else
-            hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 0>), gridA, block, 0, sa, U, I, D, tu + off, tp + off,
-                               tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr, (float *)nullptr,
-                               (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, (const int *)nullptr, 0,
-                               (const int *)nullptr);
-        WR_LAUNCH_CHECK("bprmf_user_phase (overlap, main)");
-        WR_HIP(hipEventRecord(evA, sa));
-        if (n_def > 0) {
-            hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 2>), gridD, block, 0, sb, U, I, D, tu + off, tp + off,
-                               tn + off, (int)Bk, lr, 0.f, w.Z, w.partials + gridA.x, (float *)nullptr, (int *)nullptr,
-                               (float *)nullptr, (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, def_q + b * def_cap,
-                               n_def, is_static ? def_count_dev + b : (const int *)nullptr);
-            WR_LAUNCH_CHECK("bprmf_user_phase (overlap, deferred)");
-        }
-        WR_HIP(hipEventRecord(evD, sb));
-        WR_HIP(hipStreamWaitEvent(sb, evA, 0));
-        hipLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, 0, false>), gridB, block, 0, sb, I, D, oc_item + 2 * off,
-                           oc_src + 2 * off, (int)(2 * Bk), w.Z, lr, 0.f, (float *)nullptr, (int *)nullptr, 0, w.partials,
-                           (int)(gridA.x + (n_def > 0 ? gridD.x : 0u)), (float)Bk, loss_out ? loss_out + k : nullptr, 0,
-                           (const unsigned long long *)nullptr, (int)gridB.x, (const int *)nullptr, (const int *)nullptr,
-                           (float *)nullptr, ad);
-        WR_LAUNCH_CHECK("bprmf_item_phase (overlap)");
-    }
-    WR_HIP(hipEventRecord(ev_join, sb));            // the caller's stream continues behind the last item phase
-    WR_HIP(hipStreamWaitEvent(sa, ev_join, 0));
-    return WR_OK;
-}
-
 // ----------------------------------------------------------------------------------------------- chained step launch
 // ONE launch per step: the item phase of step k-1 rides in the launch that carries the user phase of step k, so its ~5 us
 // of latency (two dependent round trips over ~8 K rows) and the kernel boundary in front of it are hidden behind 20 us of
@@ -1759,45 +1643,6 @@ int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float 
     return launch_step<2>(user_shard, const_cast<float *>(item_rows), D, tu, tp, tn, oc_item, oc_src, B, lr, 0.f, nullptr,
                           grad_slots, nullptr, nullptr, 0, loss_partial, workspace, reinterpret_cast<hipStream_t>(stream_),
                           nullptr, (float)global_batch, hot_of(hot, 0));
-}
-
-int32_t wr_bprmf_run_sgd_overlap(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
-                                 const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
-                                 const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
-                                 int64_t n_batches, float lr, float *loss_out, const int32_t *tdef, const int32_t *def_q,
-                                 const int32_t *def_count_host, const int32_t *def_count_dev, int64_t def_cap, void *workspace,
-                                 int64_t workspace_bytes, void *stream_main, void *stream_side, void *const *events,
-                                 int32_t n_events) {
-    int32_t rc;
-    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
-    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
-    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, batch_size)) != WR_OK) return rc;
-    WR_REQUIRE(tdef && def_q && (def_count_host || def_count_dev) && events, WR_E_NULL,
-               "overlap marks / events must not be NULL");
-    WR_REQUIRE(n_triplets > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
-    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
-    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
-               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
-    WR_REQUIRE(n_events >= 5, WR_E_RANGE, "wr_bprmf_run_sgd_overlap needs at least 5 events (got %d)", (int)n_events);
-    WR_REQUIRE(stream_main != stream_side, WR_E_RANGE, "the two streams must differ");
-    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 2 * step_ws_bytes(batch_size, D), WR_E_WORKSPACE,
-               "wr_bprmf_run_sgd_overlap: workspace %lld B < %lld B", (long long)workspace_bytes,
-               (long long)(2 * step_ws_bytes(batch_size, D)));
-    for (int64_t k = 1; def_count_host != nullptr && k < n_batches; ++k) {   // the lists must fit what the plan reserved
-        const int32_t c = def_count_host[first_batch + k];
-        WR_REQUIRE(c >= 0 && c <= def_cap, WR_E_RANGE, "batch %lld: %d deferred runs exceed the list capacity %lld",
-                   (long long)(first_batch + k), (int)c, (long long)def_cap);
-    }
-    for (int32_t j = 0; j < n_events; ++j) WR_REQUIRE(events[j] != nullptr, WR_E_NULL, "event %d is NULL", (int)j);
-    hipEvent_t *ev = reinterpret_cast<hipEvent_t *>(const_cast<void **>(events));
-    hipStream_t sa = reinterpret_cast<hipStream_t>(stream_main), sb = reinterpret_cast<hipStream_t>(stream_side);
-#define WR_CALL_OVL(T_, NV_, FULL_)                                                                                        \
-    return launch_overlap_steps<T_, NV_, FULL_>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, n_triplets, batch_size, \
-                                                first_batch, n_batches, lr, loss_out, tdef, def_q, def_count_host,          \
-                                                def_count_dev, def_cap, workspace, sa, sb, ev, (int)n_events)
-    WR_DISPATCH_D(D, WR_CALL_OVL);
-#undef WR_CALL_OVL
-    return WR_OK;
 }
 
 int32_t wr_bprmf_chain_supported(const float *user_tab, const float *item_tab, int32_t D) {

@@ -1,4 +1,4 @@
-// wr_overlap.hip — plan-time marks for the overlapped step stream (wr_bprmf_run_sgd_overlap, wr_bpr.hip).
+// wr_overlap.hip — plan-time marks of the chained step launch (wr_bprmf_run_sgd_chain, wr_bpr.hip).
 //
 // Reference semantics kept: BaseRunner.fit's loop (src/helpers/BaseRunner.py:194-200) is a strict sequence of
 // batch-synchronous steps.  The overlapped stream runs the item phase of step k beside the user phase of step k+1; that

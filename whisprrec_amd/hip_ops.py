@@ -704,19 +704,6 @@ class GroupPlan:
         return out
 
 
-class OverlapEvents:
-    """the ring of hipEvent_t handles wr_bprmf_run_sgd_overlap orders its two streams with (caller-owned, like every other
-    resource of the C-ABI)"""
-
-    def __init__(self, device, n=9):
-        self.events = [torch.cuda.Event() for _ in range(n)]
-        with torch.cuda.device(device):
-            for e in self.events:
-                e.record()                       # torch creates the hipEvent_t lazily on first record
-        self.array = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.events])
-        self.n = n
-
-
 _CHAIN_SYNC = {}      # (device, stream) -> [int32 tensors]: hand-off counters of the chained step launches (BprmfTables._chain_sync)
 _OVERLAP_WS_BYTES = {}       # (batch size, D) -> bytes of the two-slot step workspace
 
@@ -814,33 +801,6 @@ class BprmfTables:
                 abi.lib().wr_bprmf_step_workspace_bytes(batch_size, self.D), "wr_bprmf_step_workspace_bytes")
         return workspace(self.dev, "step_overlap").get(nbytes)
 
-    def run_sgd_overlap(self, plan, first, count, lr, losses, side, events, static=False, ws=None):
-        if plan.overlap is None or not plan.overlap.get("fits", True):
-            raise abi.WhisprRecHipError("run_sgd_overlap: the plan does not qualify (hot rows, or deferred-run lists beyond "
-                                        "capacity)")
-        return self._run_sgd_overlap(plan, first, count, lr, losses, side, events, static, ws)
-
-    def _run_sgd_overlap(self, plan, first, count, lr, losses, side, events, static=False, ws=None):
-        """`count` consecutive steps like run_sgd, as the overlapped stream (wr_bprmf_run_sgd_overlap): item phase of step k
-        on stream `side` beside the user phase of step k+1 on the current stream.  plan.overlap must be set (BatchPlan
-        built with overlap=True that qualified).  events: OverlapEvents.  Same tables, bit for bit, as run_sgd.
-        static: no host-side count enters the launches (the call may be captured into a hipGraph and replayed)."""
-        L = abi.lib()
-        o = plan.overlap
-        if ws is None:
-            ws = self.overlap_workspace(plan.batch_size)
-        if losses is None:
-            losses = torch.empty(count, dtype=torch.float32, device=self.dev)
-        abi.check(L.wr_bprmf_run_sgd_overlap(_p(self.U), self.U.shape[0], _p(self.I), self.I.shape[0], self.D, _p(plan.tu),
-                                             _p(plan.tp), _p(plan.tn), _p(plan.oc_item), _p(plan.oc_src), plan.n_triplets,
-                                             plan.batch_size, first, count, lr, _p(losses), _p(o["tdef"]), _p(o["def_q"]),
-                                             None if static else o["def_count_host"].data_ptr(),
-                                             _p(o["def_count_dev"]) if static else None, o["cap"], _p(ws), ws.numel(),
-                                             _stream(), side.cuda_stream, ctypes.addressof(events.array), events.n),
-                  "wr_bprmf_run_sgd_overlap")
-        self.step_id += count
-        return losses
-
     def chain_supported(self):
         """rows are whole 128-byte lines (D % 32 == 0, tables 128-byte aligned): the chained step launch applies"""
         return bool(abi.lib().wr_bprmf_chain_supported(_p(self.U), _p(self.I), self.D))
@@ -860,6 +820,12 @@ class BprmfTables:
             words = int(abi.lib().wr_bprmf_chain_sync_words(max(count, self.CHAIN_SYNC_STEPS)))
             bufs.append(torch.zeros(words, dtype=torch.int32, device=self.dev))      # older ones stay for check_chain
         return bufs[-1]
+
+    def sticky_words(self):
+        """the sticky "a bounded wait expired" words of the step launches issued on the current stream of this device (one
+        int32 view per hand-off buffer) — PipelinedSgd copies them to pinned memory behind every chunk"""
+        sid = torch.cuda.current_stream(self.dev).cuda_stream
+        return [buf[-4:-3] for key, bufs in _CHAIN_SYNC.items() if key[0] == str(self.dev) and key[1] == sid for buf in bufs]
 
     def check_chain(self):
         """raises if a bounded wait inside a chained step launch ever expired on this device (synchronises; call it where
@@ -1208,8 +1174,6 @@ class PipelinedSgd:
     # then runs beside more of the steps, and the chunk's steps go out in two calls).
     PREFETCH_AFTER_TRIPLETS = 0
     PLAN_TRIPLETS = 1 << 22
-    OVERLAP_MIN_BATCH = 8192      # below this a step is launch-bound and a third launch per step costs more than it hides
-
     GROUP_MIN_ROWS_PER_TRIPLET = 12   # group plans (no per-batch sort): both tables hold at least this many rows per triplet of a
                                       # batch — with fewer, the lists of shared rows outgrow their capacity (uniform ids: a
                                       # share 1 - exp(-2 B / rows) of the item occurrences is shared: 15 % at 12 rows per triplet)
@@ -1219,7 +1183,7 @@ class PipelinedSgd:
     CHAIN_MIN_ITEMS_PER_TRIPLET = 6   # item rows per triplet of a batch: with fewer, too many runs are deferred (uniform ids:
                                       # 2 * (1 - exp(-x)(1 + x)), x = 2 B / rows, of the runs: 1/20 at 6 rows per triplet)
 
-    def __init__(self, chunk=64, min_triplets=None, overlap=False, chain=True, inline_plan=False, group=True):
+    def __init__(self, chunk=64, min_triplets=None, chain=True, inline_plan=False, group=True):
         """group (default): batches that qualify (int32 ids; 4,096 <= B <= 131,072; rows = whole 128-B lines; both tables large
         against the batch; no popularity-skewed ids) are NOT sorted at all: the plan only groups the rows that recur in a batch
         (GroupPlan, wr_group_plan_build: one launch per chunk, LDS bitmaps, ~0.1 B of plan per triplet) and the step is one
@@ -1233,23 +1197,14 @@ class PipelinedSgd:
         chunk's steps, instead of on a side stream beside them.  OFF by default — measured, not assumed: in a kernel trace of
         1M x 1M x 64, B = 65,536 the ~11 step kernels per chunk that overlap a plan kernel take 49 us instead of 24 (~280 us
         per chunk), which looks like a reason to serialise; but the plan of a chunk takes ~330 us when it runs alone (it is
-        latency-bound: 32 K short workgroups), so in-stream costs MORE (29.9 against 29.4 us/step).
-        overlap: run plans that qualify (no hot rows; B >= OVERLAP_MIN_BATCH) as the overlapped stream — item phase of
-        step k beside the user phase of step k+1 (wr_bprmf_run_sgd_overlap); same tables bit for bit.  OFF by default: on
-        MI355X / ROCm 7.2 the cross-stream event hand-offs it needs cost more than the item phase they hide (measured at
-        1M x 1M, D = 64, B = 65,536: ordinary stream 29.1-30.2 us/step, overlapped 38.3-39.3 eagerly — host-bound on seven
-        runtime calls per step — and 72-77 as a hipGraph replay)."""
+        latency-bound: 32 K short workgroups), so in-stream costs MORE (29.9 against 29.4 us/step)."""
         import sys
         self.ops = sys.modules[__name__]
         self.chunk = int(chunk)
-        self.overlap = bool(overlap)
         self.chain = bool(chain)
         self.group = bool(group)
         self.inline_plan = inline_plan
-        self.item_stream = None
-        self._ovl_events = None
-        self._graphs = {}
-        self.stats = {"graph_replays": 0, "plain_calls": 0, "chain_calls": 0, "group_calls": 0, "group_fallbacks": 0}
+        self.stats = {"plain_calls": 0, "chain_calls": 0, "group_calls": 0, "group_fallbacks": 0}
         self._garenas = {}
         if min_triplets is not None:
             self.PLAN_TRIPLETS = int(min_triplets)
@@ -1304,89 +1259,27 @@ class PipelinedSgd:
         u_all, p_all, n_all = (_join_views([s[j] for s in live]) for j in (1, 2, 3))
         n_items = max([s[0].shape[0] for s in live] or [1])
         main = torch.cuda.current_stream(U.device)
-        # the overlapped stream runs whole plans as hipGraph replays (its seven runtime calls per step would otherwise make
-        # the host the bottleneck): full chunks of a single-table handle
-        use_overlap = self.overlap and B >= self.OVERLAP_MIN_BATCH and len(segs) == 1 and \
-            first >= self.chunk_batches(B) >= 2
-        if use_overlap and self.item_stream is None:
-            self.item_stream = side_stream(U.device)
-            self._ovl_events = self.ops.OverlapEvents(U.device)
-        if runner is not None:
-            use_overlap = False
-        use_chain = self.chain and runner is None and not use_overlap and B >= self.CHAIN_MIN_BATCH and first >= 2 and \
+        use_chain = self.chain and runner is None and B >= self.CHAIN_MIN_BATCH and first >= 2 and \
             min([s[0].shape[0] for s in live] or [0]) >= self.CHAIN_MIN_ITEMS_PER_TRIPLET * B and \
             all(sg["tabs"].chain_supported() for sg in segs if sg["tabs"] is not None)
         min_rows = min([U.shape[0]] + [s[0].shape[0] for s in live])
-        use_group = self.group and runner is None and not use_overlap and len(live) == 1 and first >= 2 and \
+        use_group = self.group and runner is None and len(live) == 1 and first >= 2 and \
             self.GROUP_MIN_BATCH <= B <= 131072 and u_all.dtype == torch.int32 and \
             min_rows >= self.GROUP_MIN_ROWS_PER_TRIPLET * B and \
             all(sg["tabs"].group_supported() for sg in segs if sg["tabs"] is not None)
         garenas = self._garena_pair(U.device, B, first, U.shape[0], n_items) if use_group else None
         # the sorted plans' arenas are made on demand when a group-plan stream has to fall back (skewed ids)
-        arenas = None if use_group else self._arena_pair(U.device, B, first, n_items if (use_overlap or use_chain) else 0)
+        arenas = None if use_group else self._arena_pair(U.device, B, first, n_items if use_chain else 0)
         for a in (arenas or []) + (garenas or []):     # a previous handle may have left steps queued that read these arrays
             a.release_after(main)
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
              "group": use_group, "garenas": garenas, "device": U.device,
-             "overlap": use_overlap, "chain": use_chain, "prep": prep, "runner": runner,
-             "inline": (not use_overlap) and bool(self.inline_plan),
+             "chain": use_chain, "prep": prep, "runner": runner, "inline": bool(self.inline_plan),
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
-        if use_overlap:
-            self._capture_graphs(h, segs[0]["tabs"], lr)
         self.plan_stream.wait_stream(main)   # the index tensors are ready
         self._prefetch(h)
         return h
-
-    def _capture_graphs(self, h, tabs, lr=None):
-        """one hipGraph per arena: all steps of a full plan as the overlapped stream (static form: the launches read the
-        deferred-run counts on the device, so the same graph serves every plan built into that arena).  Captured before the
-        step stream starts; per learning rate (a kernel argument)."""
-        B, nb = h["B"], self.chunk_batches(h["B"])
-        for a in h["arenas"]:
-            key = (id(a), nb, tabs.U.data_ptr(), tabs.I.data_ptr(), tabs.D)
-            if key in self._graphs:
-                continue
-            stage = torch.empty(nb, dtype=torch.float32, device=tabs.dev)
-            ws = tabs.overlap_workspace(B)
-            M, cb = a.max_triplets, a.max_batches
-            idx, o = a.idx, a.overlap
-            head = BatchPlan.META_HEAD
-            # the arena's arrays as a full plan sees them (BatchPlan.__init__)
-            shell = type("ArenaPlan", (), {})()
-            shell.tu, shell.tp, shell.tn = idx[:nb * B], idx[M:M + nb * B], idx[2 * M:2 * M + nb * B]
-            shell.oc_item, shell.oc_src = idx[3 * M:3 * M + 2 * nb * B], idx[5 * M:5 * M + 2 * nb * B]
-            shell.n_triplets, shell.batch_size = nb * B, B
-            shell.overlap = {"tdef": o["tdef"], "def_q": o["def_q"], "cap": o["cap"], "def_count_host": None,
-                             "def_count_dev": a.meta[head + 4 * cb:head + 5 * cb]}
-            self._graphs[key] = {"stage": stage, "lr": {}, "shell": shell, "ws": ws}
-        h["graph_tabs"] = tabs
-        if lr is not None:
-            for a in h["arenas"]:
-                self._graph_of(self._graphs[(id(a), nb, tabs.U.data_ptr(), tabs.I.data_ptr(), tabs.D)], tabs, nb, lr)
-
-    def _graph_of(self, rec, tabs, nb, lr):
-        g = rec["lr"].get(float(lr))
-        if g is None:
-            # first use of this learning rate (a kernel argument): capture.  torch synchronises the device around a capture.
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                tabs.run_sgd_overlap(rec["shell"], 0, nb, lr, rec["stage"], self.item_stream, self._ovl_events, static=True,
-                                     ws=rec["ws"])
-            tabs.step_id -= nb
-            rec["lr"][float(lr)] = g
-        return g
-
-    def _graph_for(self, h, plan, lr):
-        """the captured stream for this plan, or None (partial plan, lists beyond capacity, hot rows: ordinary stream)"""
-        if plan.overlap is None or not plan.overlap["fits"] or plan.n_triplets != plan.arena.max_triplets:
-            return None
-        tabs = h["graph_tabs"]
-        rec = self._graphs.get((id(plan.arena), plan.n_batches, tabs.U.data_ptr(), tabs.I.data_ptr(), tabs.D))
-        if rec is None:
-            return None
-        g = self._graph_of(rec, tabs, plan.n_batches, lr)
-        return g, rec["stage"]
 
     def _build_stream(self, h):
         return torch.cuda.current_stream(h["u"].device) if h["inline"] else self.plan_stream
@@ -1416,12 +1309,42 @@ class PipelinedSgd:
                 h["arenas"] = self._arena_pair(h["device"], B, h["nb"], h["n_items"] if h["chain"] else 0)
             plan = self.ops.BatchPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
                                       validate=False, ws_tag="rot%d" % h["tag"], bucket_map=bmap, arena=h["arenas"][h["tag"]],
-                                      defer=True, overlap=h["overlap"] or h["chain"])
+                                      defer=True, overlap=h["chain"])
         h["tag"] ^= 1
         h["next"] = (first, plan)
 
+    STICKY_MSG = "a wait inside a step launch expired (hand-off between the workgroups of one launch): the tables are not " \
+                 "valid — do not save or evaluate them; restart the run"
+
+    def _queue_sticky(self, h, tabs, main):
+        """behind a chunk's last step: the launches' sticky timeout words -> pinned memory, asynchronously; read when the next
+        chunk starts (or the run ends), i.e. before anything but ONE more chunk of steps can have used the tables"""
+        words = tabs.sticky_words()
+        if not words:
+            return
+        pin = h.get("sticky_pin")
+        if pin is None or pin.numel() < 2 * len(words):
+            pin = h["sticky_pin"] = torch.zeros(2 * max(len(words), 4), dtype=torch.int32, pin_memory=True)
+        half = pin.numel() // 2
+        off = half * (h.get("sticky_tag", 0) & 1)
+        h["sticky_tag"] = h.get("sticky_tag", 0) + 1
+        for j, wd in enumerate(words):
+            pin[off + j:off + j + 1].copy_(wd, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._check_sticky(h)                       # at most one chunk's check is ever outstanding
+        h["sticky_pending"] = (ev, pin[off:off + len(words)])
+
+    def _check_sticky(self, h):
+        pend = h.pop("sticky_pending", None)
+        if pend is not None:
+            pend[0].synchronize()
+            if bool(pend[1].numpy().any()):
+                raise abi.WhisprRecHipError(self.STICKY_MSG)
+
     def _take_next(self, h, pos, main):
         """the prefetched plan becomes the current one: its read-back is consumed here (flags, hot-run counts)"""
+        self._check_sticky(h)
         if h["next"] is None:
             self._prefetch(h)
         cur = h["next"]
@@ -1491,16 +1414,10 @@ class PipelinedSgd:
                     self._prefetch(h)
                 else:
                     c = min(c, mid - pos)
-            elif self.PREFETCH_AFTER_TRIPLETS > 0 and h["next"] is None and h["at"] < h["nb"] and not h["overlap"] and \
+            elif self.PREFETCH_AFTER_TRIPLETS > 0 and h["next"] is None and h["at"] < h["nb"] and \
                     c > (self.PREFETCH_AFTER_TRIPLETS + h["B"] - 1) // h["B"]:
                 c = (self.PREFETCH_AFTER_TRIPLETS + h["B"] - 1) // h["B"]      # see PREFETCH_AFTER_TRIPLETS
-            graph = self._graph_for(h, plan, lr) if (h["overlap"] and pos == base and c == plan.n_batches) else None
-            if graph is not None:
-                graph[0].replay()                                    # the whole plan as the overlapped stream, one launch
-                self.stats["graph_replays"] += 1
-                losses[loss_off:loss_off + c].copy_(graph[1])
-                sg["tabs"].step_id += c
-            elif isinstance(plan, GroupPlan):
+            if isinstance(plan, GroupPlan):
                 sg["tabs"].run_sgd_group(plan, pos - base, c, lr, losses=losses[loss_off:loss_off + c])
                 self.stats["group_calls"] += 1
             elif h["runner"] is not None:
@@ -1516,6 +1433,7 @@ class PipelinedSgd:
             loss_off += c
             if pos >= base + plan.n_batches:
                 plan.arena.release_after(main)                       # every step that reads the plan's arrays is queued
+                self._queue_sticky(h, sg["tabs"], main)
             if h["next"] is None and not h["inline"]:
                 self._prefetch(h)                                    # the next plan is built beside the queued steps
         h["pos"] = pos
@@ -1526,6 +1444,8 @@ class PipelinedSgd:
         if sg["nb"] == 0:
             return
         self._run_span(handle, sg, sg["first"], sg["first"] + sg["nb"], lr, losses, 0)
+        if seg == len(handle["segs"]) - 1:
+            self._check_sticky(handle)      # the last chunk's word (waits for the stream: the caller is about to read the losses)
 
     def run_steps(self, handle, count, lr, losses):
         """the next `count` steps of a single-segment handle (a step stream consumed piecewise: warm-up, then the timed

@@ -109,6 +109,7 @@ class RotatingBprmf:
         """Re-assemble the reference's checkpoint layout (user table, item table) on every rank."""
         self.complete_rotation()
         self._drain()
+        self.check_steps()       # a checkpoint never holds tables a step launch has declared invalid
         G, D = self.world, self.D
         capu = (self.n_users + G - 1) // G
         pu = torch.zeros(capu, D, device=self.device)
@@ -168,6 +169,13 @@ class RotatingBprmf:
     def _drain(self):
         for part in list(self._ready):
             self._await_part(part)
+
+    def check_steps(self):
+        """raises if a bounded wait inside a step launch ever expired on this device (hip_ops.BprmfTables.check_chain;
+        synchronises) — called before the tables leave this object (gather_full) and at the end of a benchmark"""
+        if self.U.device.type == "cuda":
+            from . import hip_ops
+            hip_ops.BprmfTables(self.U, self.I[:1] if self.I.shape[0] else self.I).check_chain()
 
     # ------------------------------------------------------------------ training
     def run_subepoch(self, u, p, n, steps_per_part, batch, lr):
@@ -388,11 +396,13 @@ def bench_run(args, rank, world, dev):
     torch.cuda.synchronize()
     import gc
     gc.disable()            # no cyclic-GC pass of the interpreter inside a sub-millisecond timed region (see bench.py)
-    t0 = time.perf_counter()
-    local_losses = model.run_prepared(prepared, args.lr, n_strata=len(timed), defer_last=True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    gc.enable()
+    try:
+        t0 = time.perf_counter()
+        local_losses = model.run_prepared(prepared, args.lr, n_strata=len(timed), defer_last=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    finally:
+        gc.enable()
     # every rank started behind the same barrier; the job's time is the MAX over ranks of (own completion - start), which is
     # what a closing barrier would measure without that barrier's own launch + rendezvous latency (~0.1 ms of a 0.7 ms region)
     dist.barrier()
@@ -401,6 +411,7 @@ def bench_run(args, rank, world, dev):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     model.complete_rotation()
     model._drain()
+    model.check_steps()
     losses = model.global_losses(local_losses)
     dt = float(dt.item())
     if rank != 0:
