@@ -72,6 +72,9 @@ def parse(argv=None):
                     help="N>1: 'rotate' = stratified schedule, item blocks move round the ring (whisprrec_amd/rotating.py); "
                          "'alltoall' = per-step row exchange (whisprrec_amd/sharded.py); 'both' = one after the other")
     ap.add_argument("--parts", type=int, default=2, help="rotate mode: parts per item block (overlap of transfer and compute)")
+    ap.add_argument("--loopback-world", type=int, default=0,
+                    help="with --force-sharded --gpus 1: also time rank 0's work of a G-rank all-to-all job on this one GPU, every "
+                         "exchange replaced by a device copy (reported under modes.alltoall.loopback)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even with one rank (testing)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N>1 path (nccl = RCCL; gloo only for the CPU dry run of the launcher)")
@@ -475,26 +478,36 @@ def epoch_extra(args, hip_ops, U, I, dev):
 # --------------------------------------------------------------------------------------------------- N > 1
 def multi_gpu(args, rank, world, local_rank):
     """One rank per GPU (RCCL).  Runs the sharding mode(s) asked for back to back inside one process group and prints one
-    line: `value` is the stratified-rotation mode's unless only 'alltoall' was asked for; every mode's numbers are under
-    `modes`."""
+    line: `value` is the all-to-all mode's (the one that keeps the reference's sampling) unless only 'rotate' was asked for;
+    every mode's numbers are under `modes`."""
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
     os.environ.setdefault("RANK", str(rank))
     os.environ.setdefault("WORLD_SIZE", str(world))
+    # stdout carries ONE JSON line: whatever libraries print there while the ranks initialise (RCCL's version banner) goes to
+    # stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
     if args.dry_run:
         dist.init_process_group(args.backend if args.backend == "gloo" else "gloo")
         dist.barrier()
         if rank == 0:
-            print(json.dumps(multi_line(args, world, {}, None, dry_run=True)))
+            emit(multi_line(args, world, {}, None, dry_run=True))
         dist.barrier()
         dist.destroy_process_group()
         return 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist.init_process_group("nccl", device_id=dev)
-    modes = ["rotate", "alltoall"] if args.shard_mode == "both" else [args.shard_mode]
+    modes = ["alltoall", "rotate"] if args.shard_mode == "both" else [args.shard_mode]
     results = {}
     for mode in modes:
         if mode == "rotate":
@@ -511,7 +524,7 @@ def multi_gpu(args, rank, world, local_rank):
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, min(args.cpu_seconds, 8.0))
     if rank == 0:
-        print(json.dumps(multi_line(args, world, results, cpu)))
+        emit(multi_line(args, world, results, cpu))
     dist.barrier()
     dist.destroy_process_group()
     return 0
@@ -520,7 +533,10 @@ def multi_gpu(args, rank, world, local_rank):
 def multi_line(args, world, results, cpu, dry_run=False):
     """the N>1 JSON line from the per-mode results (also the skeleton the CPU dry run of the launcher prints)"""
     B, D = args.batch, args.emb
-    primary = "alltoall" if args.shard_mode == "alltoall" else "rotate"
+    # the headline comes from the mode that takes the reference's batches as they are (row exchange by all-to-all, negatives
+    # from all items); the stratified rotation — which draws a triplet's negative from its positive's item block — is
+    # reported beside it under `modes.rotate` with that waiver
+    primary = "rotate" if args.shard_mode == "rotate" else "alltoall"
     head = results.get(primary, {})
     out = {"metric": "BPR training triplets/sec", "value": head.get("value"), "unit": "triplets/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head.get("ms_per_step"), "higher_is_better": True,

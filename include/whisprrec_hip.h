@@ -561,17 +561,50 @@ int32_t wr_apply_rows_sorted(float *tab, int64_t n_rows, int32_t D, const int32_
                              const float *src, int64_t n, float alpha, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * Row-sharded step (multi-GPU): the same two kernels with the user rows of this shard updated in place
- * (SGD, l2 = 0) and the item side exchanged: `item_rows` [n_slots, D] are the item rows this rank received
- * from their owners for this step (tp/tn/oc_item hold SLOT ids into it), `grad_slots` [n_slots, D] receives
- * the reduced gradient row of every slot (to be returned to the owners).  The loss term and coefficient are
- * scaled by 1/global_batch (the mean runs over all shards' triplets); loss_partial = this shard's share.
+ * Row-sharded step (multi-GPU) on a SORTED batch plan — the form for batches the group plan does not take (popularity-skewed
+ * ids, shards small against the batch; wr_bprmf_shard_step_group is the usual one): the same two kernels with the user rows
+ * of this shard updated in place (SGD, l2 = 0).  `item_rows` [n_rows, D] = the shard's own item rows [0, n_local_items),
+ * rewritten in place, followed by the rows received from their owners for this step (tp/tn/oc_item hold row ids into
+ * it); `grad_slots` [n_rows - n_local_items, D] receives the reduced gradient row of every received row (to be returned
+ * to the owners).  The loss term and coefficient are scaled by 1/global_batch (the mean runs over all shards' triplets);
+ * loss_partial = this shard's share.
  * --------------------------------------------------------------------------------------------------- */
-int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,
-                            const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, float *item_rows, int64_t n_rows, int64_t n_local_items,
+                            int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                             const int32_t *oc_src, int64_t B, int64_t global_batch, float lr, float *grad_slots,
                             float *loss_partial, const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes,
                             void *stream);
+
+/* Row-sharded step without a per-batch sort (whisprrec_amd/sharded.py; wr_shard.hip + wr_group.hip) — ONE BaseRunner.fit
+ * iteration (src/helpers/BaseRunner.py:196-199) over the union of the ranks' batches, negatives from ALL items
+ * (src/models/BaseModel.py:168,174).  Item row i lives on rank i % world at local row i / world; a rank owns the users of its
+ * triplets.  A rank's LOCAL item rows are read and rewritten in its shard in place; REMOTE ones are received from their
+ * owners into rows [n_local_items, n_local_items + slots) of the same buffer (`item_ext`) and their gradient rows go back.
+ *   wr_shard_route   index work for a chunk of batches: vu / vp / vn = the triplets with local user rows and "virtual" item
+ *       ids (local row, or n_local_items + slot; a step's distinct remote items get slots 0, 1, ... in ascending (owner, row)
+ *       order); send_rows [world][n_batches][list_cap] / send_cnt [world][n_batches] = per owner and batch the requested
+ *       local rows (ascending) and their number — exchanged by two fixed-size all-to-alls.  rows_per_owner: a multiple of
+ *       32 with world * rows_per_owner >= n_items.  err[0] != 0: an id out of range or a user of another rank; err[1] != 0:
+ *       a request list beyond list_cap.
+ *   wr_shard_pack    after the exchange (recv_rows / recv_cnt in the same layout, indexed by requester): per batch the rows
+ *       to serve, requester by requester (serve_rows [n_batches][serve_stride], int64) and where each requester's rows
+ *       start (serve_off [n_batches][world + 1]).  err[0] != 0: a peer asked for a row this shard does not have.
+ *   wr_bprmf_shard_step_group   batch `batch` of a group plan built on (vu, vp, vn) with n_items = n_ext_rows: user rows and
+ *       local item rows updated in place (SGD, l2 = 0), grad_slots[s] = the summed gradient row of slot s; coefficients and
+ *       the loss share are scaled by 1 / global_batch.  Two launches (the triplets, then the batch's own tiles).
+ *       workspace / sync as for wr_bprmf_run_sgd_group (sync: at least wr_bprmf_group_sync_words(1) words). */
+int32_t wr_shard_route(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets, int64_t batch_size, int32_t world,
+                       int32_t rank, int64_t n_users, int64_t n_items, int64_t rows_per_owner, int64_t n_local_items,
+                       int64_t list_cap, int32_t *vu, int32_t *vp, int32_t *vn, int32_t *send_rows, int32_t *send_cnt,
+                       int32_t *err, void *stream);
+int32_t wr_shard_pack(const int32_t *recv_rows, const int32_t *recv_cnt, int64_t n_batches, int32_t world, int64_t list_cap,
+                      int64_t n_local_items, int64_t *serve_rows, int64_t serve_stride, int32_t *serve_off, int32_t *err,
+                      void *stream);
+int32_t wr_bprmf_shard_step_group(float *user_shard, int64_t n_user_rows, float *item_ext, int64_t n_ext_rows,
+                                  int64_t n_local_items, int32_t D, const int32_t *vu, const int32_t *vp, const int32_t *vn,
+                                  int64_t n_triplets, int64_t batch_size, const int32_t *plan, int64_t plan_words, int64_t batch,
+                                  int64_t global_batch, float lr, float *grad_slots, float *loss_partial, void *workspace,
+                                  int64_t workspace_bytes, int32_t *sync, int64_t sync_words, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K6-K7  LightGCN propagation — src/models/general/LightGCN.py:134-148

@@ -57,9 +57,10 @@ def test_multi_gpu_line_carries_both_modes_and_the_single_gpu_definitions():
            "sampling": "reference rule", "roofline": dict(rot["roofline"], achieved=700.0, frac=0.0875)}
     line = bench.multi_line(args, 8, {"rotate": rot, "alltoall": a2a}, {"value": 1e6, "unit": "triplets/s", "cores": 1,
                                                                          "kind": "port", "sample": "x"})
-    assert line["value"] == 8e9 and line["config"]["value_from_mode"] == "rotate" and line["n_gpus"] == 8
+    # the headline is the mode that keeps the reference's sampling (all-to-all); the rotation is reported beside it
+    assert line["value"] == 2e9 and line["config"]["value_from_mode"] == "alltoall" and line["n_gpus"] == 8
     assert set(line["modes"]) == {"rotate", "alltoall"} and line["modes"]["alltoall"]["value"] == 2e9
-    assert line["config"]["sampling"].startswith("stratified") and line["config"]["rccl_world_size"] == 8
+    assert line["config"]["sampling"].startswith("reference rule") and line["config"]["rccl_world_size"] == 8
     assert line["config"]["emb_size"] == 128 and "10000000 users" in line["config"]["workload"]
     assert line["roofline"]["definition"].endswith("as at N=1") and line["cpu_baseline"]["kind"] == "port"
     json.dumps(line)

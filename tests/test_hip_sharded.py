@@ -1,7 +1,7 @@
-"""GPU test of the row-sharded step through RCCL with a single rank (the only multi-process-free configuration a 1-GPU
-box allows): exercises HipBackend — wr_gather_rows, wr_bprmf_shard_step (MODE 2), wr_apply_rows_sorted — and
-torch.distributed's nccl(=RCCL) all_to_all_single, against the oracle.  The multi-rank exchange logic itself is covered on
-CPU/gloo by tests/test_sharded_gloo.py."""
+"""GPU tests of the row-sharded step with a single rank over RCCL (the only multi-process-free configuration a 1-GPU box
+allows): with one rank every row is local and the step stream is the single-GPU one; the index kernels of the multi-rank
+path (wr_shard_route, wr_shard_pack) are checked here against their NumPy restatement.  The multi-rank exchange logic is
+covered on CPU/gloo by tests/test_sharded_gloo.py and with real kernels by tests/test_hip_sharded_two_ranks.py."""
 import os
 
 import numpy as np
@@ -66,28 +66,45 @@ def test_shard_step_global_batch_scaling(pg):
     assert rel_err(Uf.cpu().numpy(), Uo) < 1e-5 and rel_err(If.cpu().numpy(), Io) < 1e-5
 
 
-def test_plan_slots_equals_generic_slotify(pg):
-    """HipBackend.plan_slots (slots from the batch plan's sort) must give the unique-key lists and slot ids of the
-    torch.unique restatement that the CPU/gloo tests exercise"""
-    from whisprrec_amd.sharded import HipBackend, slotify_generic
+def test_route_and_pack_match_their_numpy_restatement(pg):
+    """wr_shard_route / wr_shard_pack (index work of the row-sharded step) against the NumPy restatement the CPU/gloo tests
+    exercise: virtual ids, request lists per owner, per-step serve lists — bit-exact, incl. a key space of several passes"""
+    from whisprrec_amd.sharded import HipBackend
+    from test_sharded_gloo import route_numpy
     dev = pg
     rng = np.random.RandomState(5)
-    G, nI, nUloc, B, N = 4, 5003, 700, 1024, 3 * 1024 + 300
-    M = (nI + G - 1) // G
-    u_loc = torch.from_numpy(rng.randint(0, nUloc, N)).to(dev)
-    p = torch.from_numpy(np.minimum((rng.pareto(1.0, N) * 40).astype(np.int64), nI - 1)).to(dev)
-    n = torch.from_numpy(rng.randint(1, nI, N)).to(dev)
-    rk_p, rk_n = (p % G) * M + p // G, (n % G) * M + n // G
-    sp, sn, key, step, nq = slotify_generic(u_loc, rk_p, rk_n, B, G * M)
-    plan, key2, step2, nq2 = HipBackend().plan_slots(u_loc, rk_p, rk_n, B, nUloc, G * M)
-    assert torch.equal(key, key2) and torch.equal(step, step2) and torch.equal(nq, nq2)
-    # the plan is sorted by user: undo through the slots it carries
-    tp = (plan.tp & 0x7FFFFFFF).cpu().numpy(); tn = (plan.tn & 0x7FFFFFFF).cpu().numpy(); tu = plan.tu.cpu().numpy()
-    for k in range(plan.n_batches):
-        lo, hi = k * B, min(N, (k + 1) * B)
-        order = lo + np.argsort(u_loc.cpu().numpy()[lo:hi], kind="stable")
-        assert np.array_equal(tu[lo:hi], u_loc.cpu().numpy()[order])
-        assert np.array_equal(tp[lo:hi], sp.cpu().numpy()[order]) and np.array_equal(tn[lo:hi], sn.cpu().numpy()[order])
+    hb = HipBackend()
+    for G, rank, nU, nI, B, N in ((4, 1, 2800, 5003, 1024, 3 * 1024 + 300), (3, 2, 999, 1_300_000, 4096, 2 * 4096)):
+        M = ((nI + G - 1) // G + 31) // 32 * 32
+        nL = (nI - rank + G - 1) // G
+        C = min(2 * B, (2 * B // G) * 3 // 2 + 1024)
+        u = rng.choice(np.arange(rank, nU, G), N).astype(np.int32)
+        p = np.minimum((rng.pareto(1.0, N) * 40).astype(np.int64), nI - 1).astype(np.int32) if nI < 10_000 else \
+            rng.randint(0, nI, N).astype(np.int32)
+        n = rng.randint(1, nI, N).astype(np.int32)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        vu, vp, vn, sr, sc, err = hb.route(t(u), t(p), t(n), B, G, rank, nU, nI, M, nL, C)
+        rvu, rvp, rvn, rsr, rsc = route_numpy(u, p, n, B, G, rank, nU, nI, M, nL, C)
+        assert not err.cpu().numpy().any()
+        nb = (N + B - 1) // B
+        assert np.array_equal(vu.cpu().numpy(), rvu) and np.array_equal(vp.cpu().numpy(), rvp) and np.array_equal(vn.cpu().numpy(), rvn)
+        got_cnt = sc.cpu().numpy().reshape(G, nb)
+        assert np.array_equal(got_cnt, rsc)
+        got_rows = sr.cpu().numpy().reshape(G, nb, C)
+        for o in range(G):
+            for k in range(nb):
+                assert np.array_equal(got_rows[o, k, :rsc[o, k]], rsr[o, k, :rsc[o, k]])
+        # pack: what arrived (here: the lists this rank sent, read as if they had been requested FROM it)
+        serve, off, err2 = hb.pack(sr, sc, nb, G, C, max(nL, M))
+        off = off.cpu().numpy()
+        assert not err2.cpu().numpy().any() and np.array_equal(np.diff(off, axis=1), rsc.T)
+        for k in range(nb):
+            want = np.concatenate([rsr[s, k, :rsc[s, k]] for s in range(G)])
+            assert np.array_equal(serve[k, :off[k, G]].cpu().numpy(), want)
+    # a user of another rank and an id out of range are reported
+    bad_u = u.copy()
+    bad_u[3] += 1
+    assert hb.route(t(bad_u), t(p), t(n), B, G, rank, nU, nI, M, nL, C)[5].cpu().numpy()[0] != 0
 
 
 def test_rotating_world1_matches_oracle(pg):

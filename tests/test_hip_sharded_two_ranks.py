@@ -100,3 +100,74 @@ def test_sharded_step_two_ranks_one_gpu_equals_single_process(tmp_path, world, n
     assert rel_err(got["loss"], np.asarray(ref_loss)) < 1e-5
     assert rel_err(got["U"], Uo) < 1e-5
     assert rel_err(got["I"], Io) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ configs[3] shard shape
+def _row_values(rows, D, salt):
+    """deterministic table rows from their global ids (both the ranks and the reference build them): [len(rows), D] float32"""
+    r = np.asarray(rows, dtype=np.float64)[:, None]
+    d = np.arange(D, dtype=np.float64)[None, :]
+    return (0.05 * np.sin(0.37 * r + 1.3 * d + salt) * np.cos(0.011 * r * (d + 1.0))).astype(np.float32)
+
+
+def _c4_worker(rank, world, port, payload, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _stage_collectives_through_host(dist)
+    try:
+        from whisprrec_amd.sharded import ShardedBprmf
+        nU, nI, D, B, steps, lr = payload["shape"]
+        m = ShardedBprmf(nU, nI, D, dev)
+        # the shard's rows from their global ids, chunk by chunk (no full table anywhere)
+        for tab, n_rows, salt in ((m.U, nU, 0.0), (m.I, nI, 1.0)):
+            ids = np.arange(rank, n_rows, world)
+            for lo in range(0, ids.size, 1 << 18):
+                tab[lo:lo + (1 << 18)].copy_(torch.from_numpy(_row_values(ids[lo:lo + (1 << 18)], D, salt)))
+        u, p, n = (torch.from_numpy(payload[k][rank]).to(dev) for k in ("u", "p", "n"))
+        cp = m.plan_chunk(u, p, n, B)
+        losses = m.global_losses(m.run_chunk(cp, lr, global_batch=B * world))
+        torch.cuda.synchronize()
+        tu, ti = payload["touched_u"], payload["touched_i"]
+        mine_u, mine_i = tu[tu % world == rank], ti[ti % world == rank]
+        np.savez(os.path.join(out_dir, "out%d.npz" % rank), u_ids=mine_u, i_ids=mine_i,
+                 U=m.U[torch.from_numpy(mine_u // world).to(dev)].cpu().numpy(),
+                 I=m.I[torch.from_numpy(mine_i // world).to(dev)].cpu().numpy(), loss=losses.cpu().numpy(),
+                 checksum=np.asarray([float(m.U.double().sum().item()), float(m.I.double().sum().item())]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_step_at_the_configs3_shard_shape(tmp_path, world):
+    """BASELINE.json configs[3] per-rank shape: D = 128, 1.25 M-row shards of both tables, B = 65,536 per rank — with one rank
+    and with two ranks on the one GPU (real kernels, exchange staged through the host), against the single-process oracle
+    on the union of the ranks' batches, restricted to the touched rows (compact tables, same arithmetic per row)."""
+    rng = np.random.RandomState(40 + world)
+    D, B, steps, lr = 128, 65536, 2, 0.1
+    nU = nI = 1_250_000 * world
+    per_rank = {"u": [], "p": [], "n": []}
+    for r in range(world):
+        per_rank["u"].append((rng.randint(0, nU // world, steps * B) * world + r).astype(np.int64))
+        per_rank["p"].append(rng.randint(0, nI, steps * B).astype(np.int64))
+        per_rank["n"].append(rng.randint(1, nI, steps * B).astype(np.int64))
+    tu = np.unique(np.concatenate(per_rank["u"]))
+    ti = np.unique(np.concatenate(per_rank["p"] + per_rank["n"]))
+    payload = dict(shape=(nU, nI, D, B, steps, lr), touched_u=tu, touched_i=ti, **per_rank)
+    mp.spawn(_c4_worker, args=(world, _free_port(), payload, str(tmp_path)), nprocs=world, join=True)
+    # reference on compact tables of the touched rows
+    Uc, Ic = _row_values(tu, D, 0.0), _row_values(ti, D, 1.0)
+    ref_loss = []
+    for k in range(steps):
+        sl = slice(k * B, (k + 1) * B)
+        gu = np.searchsorted(tu, np.concatenate([per_rank["u"][r][sl] for r in range(world)]))
+        gp = np.searchsorted(ti, np.concatenate([per_rank["p"][r][sl] for r in range(world)]))
+        gn = np.searchsorted(ti, np.concatenate([per_rank["n"][r][sl] for r in range(world)]))
+        ref_loss.append(oracle.bprmf_step_sgd(Uc, Ic, gu, gp, gn, lr, 0.0))
+    for r in range(world):
+        got = np.load(tmp_path / ("out%d.npz" % r))
+        assert rel_err(got["loss"], np.asarray(ref_loss)) < 1e-5
+        assert rel_err(got["U"], Uc[np.searchsorted(tu, got["u_ids"])]) < 1e-5
+        assert rel_err(got["I"], Ic[np.searchsorted(ti, got["i_ids"])]) < 1e-5

@@ -15,40 +15,86 @@ import oracle
 from conftest import rel_err
 
 
+def route_numpy(u, p, n, batch, world, rank, n_users, n_items, M, nL, C):
+    """NumPy restatement of wr_shard_route (whisprrec_amd/csrc/wr_shard.hip): local items keep their local row, a step's
+    distinct remote items get slots in ascending (owner, local row) order; per owner the requested rows, padded to C"""
+    u, p, n = (np.asarray(a, dtype=np.int64) for a in (u, p, n))
+    N = u.size
+    nb = (N + batch - 1) // batch
+    assert (u % world == rank).all() and u.max() < n_users and max(p.max(), n.max()) < n_items
+    vu, vp, vn = u // world, np.zeros(N, np.int64), np.zeros(N, np.int64)
+    send_rows = np.zeros((world, nb, C), np.int32)
+    send_cnt = np.zeros((world, nb), np.int32)
+    for k in range(nb):
+        sl = slice(k * batch, min(N, (k + 1) * batch))
+        ids = np.concatenate([p[sl], n[sl]])
+        owner, row = ids % world, ids // world
+        remote = owner != rank
+        keys = np.unique(owner[remote] * M + row[remote])
+        v = np.where(remote, nL + np.searchsorted(keys, owner * M + row), row)
+        vp[sl], vn[sl] = v[:sl.stop - sl.start], v[sl.stop - sl.start:]
+        for o in range(world):
+            rows_o = keys[keys // M == o] - o * M
+            assert rows_o.size <= C
+            send_rows[o, k, :rows_o.size] = rows_o
+            send_cnt[o, k] = rows_o.size
+    return vu, vp, vn, send_rows, send_cnt
+
+
 class OracleBackend:
+    """the backend's methods (whisprrec_amd.sharded.HipBackend) on CPU tensors, arithmetic from the CPU oracle"""
+
     class _Plan:
         pass
 
-    def plan_slots(self, u_loc, rk_p, rk_n, batch, n_user_rows, GM):
-        from whisprrec_amd.sharded import slotify_generic
-        slot_p, slot_n, u_key, u_step, nq = slotify_generic(u_loc, rk_p, rk_n, batch, GM)
+    def route(self, u, p, n, batch, world, rank, n_users, n_items, M, nL, C):
+        vu, vp, vn, sr, sc = route_numpy(u.numpy(), p.numpy(), n.numpy(), batch, world, rank, n_users, n_items, M, nL, C)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+        return (t(vu, torch.int32), t(vp, torch.int32), t(vn, torch.int32), t(sr.reshape(-1), torch.int32),
+                t(sc.reshape(-1), torch.int32), torch.zeros(2, dtype=torch.int32))
+
+    def pack(self, recv_rows, recv_cnt, nb, world, C, nL):
+        rr, rc = recv_rows.numpy().reshape(world, nb, C), recv_cnt.numpy().reshape(world, nb)
+        serve = np.zeros((nb, world * C), np.int64)
+        off = np.zeros((nb, world + 1), np.int32)
+        for k in range(nb):
+            for s in range(world):
+                c = int(rc[s, k])
+                serve[k, off[k, s]:off[k, s] + c] = rr[s, k, :c]
+                off[k, s + 1] = off[k, s] + c
+        assert serve.max() < max(nL, 1)
+        return torch.from_numpy(serve), torch.from_numpy(off), torch.zeros(1, dtype=torch.int32)
+
+    def plan_local(self, vu, vp, vn, batch, n_user_rows, n_ext_rows, n_local_items, D=64):
         pl = self._Plan()
-        pl.u, pl.p, pl.n, pl.batch_size = u_loc.numpy(), slot_p.numpy(), slot_n.numpy(), batch
-        assert pl.u.max() < n_user_rows
-        return pl, u_key, u_step, nq
+        pl.u, pl.p, pl.n, pl.batch_size = vu.numpy().astype(np.int64), vp.numpy().astype(np.int64), vn.numpy().astype(np.int64), batch
+        assert pl.u.max() < n_user_rows and max(pl.p.max(), pl.n.max()) < n_ext_rows
+        return pl
 
     def gather_rows(self, tab, idx):
         return torch.from_numpy(oracle.gather_rows(tab.numpy(), idx.numpy()))
 
-    def local_step(self, U, item_rows, plan, k, global_batch, lr, grad_slots, loss_out):
+    def local_step(self, U, I_ext, nL, plan, k, global_batch, lr, grad_slots, loss_out):
         lo = k * plan.batch_size
         u, p, n = plan.u[lo:lo + plan.batch_size], plan.p[lo:lo + plan.batch_size], plan.n[lo:lo + plan.batch_size]
         B = len(u)
-        Un, R = U.numpy(), item_rows.numpy()
+        Un, R = U.numpy(), I_ext.numpy()
         _, _, coef, loss = oracle.bpr_fwd(Un, R, u, p, n)
         coef = coef.astype(np.float64) * B / global_batch            # mean over the GLOBAL batch
         loss_out[0] = loss * B / global_batch
         gU = np.zeros(Un.shape, np.float64)
-        gS = np.zeros(R.shape, np.float64)
+        gI = np.zeros(R.shape, np.float64)
         np.add.at(gU, u, coef[:, None] * (R[p].astype(np.float64) - R[n]))
-        np.add.at(gS, p, coef[:, None] * Un[u])
-        np.add.at(gS, n, -coef[:, None] * Un[u])
+        np.add.at(gI, p, coef[:, None] * Un[u])
+        np.add.at(gI, n, -coef[:, None] * Un[u])
         Un -= (lr * gU).astype(np.float32)
-        grad_slots.copy_(torch.from_numpy(gS.astype(np.float32)))
+        R[:nL] -= (lr * gI[:nL]).astype(np.float32)                   # the shard's own rows: in place
+        ns = min(grad_slots.shape[0], R.shape[0] - nL)
+        grad_slots[:ns].copy_(torch.from_numpy(gI[nL:nL + ns].astype(np.float32)))     # received rows: gradients go back
 
-    def apply_sorted(self, tab, sorted_rows, perm, src, alpha):
+    def scatter_add(self, tab, idx, src, alpha):
         acc = np.zeros(tab.shape, np.float64)
-        np.add.at(acc, sorted_rows.numpy().astype(np.int64), src.numpy()[perm.numpy().astype(np.int64)].astype(np.float64))
+        np.add.at(acc, idx.numpy(), src.numpy().astype(np.float64))
         tab.numpy()[...] += (alpha * acc).astype(np.float32)
 
 

@@ -75,6 +75,11 @@ SIGNATURES = {
     "wr_bprmf_run_sgd_chain": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                        c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
                                        c_vp]),
+    "wr_shard_route": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
+                               c_vp, c_vp, c_vp, c_vp]),
+    "wr_shard_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "wr_bprmf_shard_step_group": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64,
+                                          c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "wr_group_plan_words": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "wr_group_plan_layout": (c_i32, [c_i64, c_i64, c_i64, c_i64, c_vp]),
     "wr_group_plan_build": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
@@ -139,7 +144,7 @@ SIGNATURES = {
     "wr_scatter_add_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "wr_scatter_add_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_i64, c_vp]),
     "wr_apply_rows_sorted": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
-    "wr_bprmf_shard_step": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32,
+    "wr_bprmf_shard_step": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32,
                                     c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_spmm_csr": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "wr_spmm_csr_chunked": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),

@@ -22,7 +22,9 @@
 //     are complete at the kernel boundary).  Block 0 also folds the user phase's per-block loss partials into the loss.
 // No float atomics anywhere: each row has one writer and a fixed summation order.
 #include "wr_common.h"
-#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: stop events attached to a dispatch (timing hooks of launch_step)
+#include <hip/hip_ext.h>
+
+#include <algorithm>   // hipExtLaunchKernelGGL: stop events attached to a dispatch (timing hooks of launch_step)
 
 #ifndef WR_USER_WAVES
 #define WR_USER_WAVES 8      // waves per SIMD the headline instantiation of the user phase is held to (64 VGPRs)
@@ -324,8 +326,9 @@ constexpr bool mode_has_state(int mode) { return mode == 3 || mode == 5 || mode 
 
 // ----------------------------------------------------------------------------------------------- user phase
 // MODE 0: SGD apply in place.  MODE 1: emit gradient rows + stamps, tables untouched.  MODE 3: Adam apply in place.
-// MODE 2 (row-sharded step): user rows applied in place, item gradients emitted (the item "table" is the buffer of
-// rows received from their owners and gradI the buffer of gradient rows sent back).
+// MODE 2 (row-sharded step): user rows applied in place; item rows below ad.t (the shard's own rows) too; the item rows
+// from ad.t on are rows received from their owners for this step: their gradients are emitted to gradI[row - ad.t] (the
+// buffer of gradient rows sent back).
 // Everything one triplet contributes, given the three rows in registers: loss term, coefficient, user-row gradient,
 // single-occurrence item rows finished in place (or their gradient emitted), stash for multi-occurrence item rows.
 template <int T, int NV, bool FULL, int MODE>
@@ -375,11 +378,14 @@ __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &p
         if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
         return;
     }
+    // MODE 2 (row-sharded step): item rows below ad.t are the shard's OWN rows — updated in place like MODE 0; rows from ad.t
+    // on were received from their owners: their gradient goes to gradI[row - ad.t] (ad.t = 0: every item row is a received one)
     if (!p_shared) {
+        const bool in_place = MODE == 0 || (MODE == 2 && p < ad.t);
         Row<NV> w;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            if (MODE == 0) {
+            if (in_place) {
                 w.v[k].x = pr.v[k].x - lr * fmaf(l2, pr.v[k].x, z.v[k].x);
                 w.v[k].y = pr.v[k].y - lr * fmaf(l2, pr.v[k].y, z.v[k].y);
                 w.v[k].z = pr.v[k].z - lr * fmaf(l2, pr.v[k].z, z.v[k].z);
@@ -388,14 +394,16 @@ __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &p
                 w.v[k] = z.v[k];
             }
         }
-        store_row<T, NV, FULL>(MODE == 0 ? I : gradI, p, D, lane, w);
+        if (in_place) store_row<T, NV, FULL>(I, p, D, lane, w);
+        else store_row<T, NV, FULL>(gradI, MODE == 2 ? p - ad.t : p, D, lane, w);
         if (stampI != nullptr && lane == 0) stampI[p] = step_id;
     }
     if (!n_shared) {
+        const bool in_place = MODE == 0 || (MODE == 2 && n < ad.t);
         Row<NV> w;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            if (MODE == 0) {
+            if (in_place) {
                 w.v[k].x = nr.v[k].x - lr * fmaf(l2, nr.v[k].x, -z.v[k].x);
                 w.v[k].y = nr.v[k].y - lr * fmaf(l2, nr.v[k].y, -z.v[k].y);
                 w.v[k].z = nr.v[k].z - lr * fmaf(l2, nr.v[k].z, -z.v[k].z);
@@ -404,7 +412,8 @@ __device__ __forceinline__ void triplet_body(const Row<NV> &ur, const Row<NV> &p
                 w.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
             }
         }
-        store_row<T, NV, FULL>(MODE == 0 ? I : gradI, n, D, lane, w);
+        if (in_place) store_row<T, NV, FULL>(I, n, D, lane, w);
+        else store_row<T, NV, FULL>(gradI, MODE == 2 ? n - ad.t : n, D, lane, w);
         if (stampI != nullptr && lane == 0) stampI[n] = step_id;
     }
     if (p_shared || n_shared) store_row<T, NV, FULL>(Z, t, D, lane, z);
@@ -735,7 +744,7 @@ __device__ __forceinline__ void finish_item_row(float *__restrict__ I, float *__
         opt_finish_row<T, NV, FULL, MODE>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
         return;
     }
-    if (MODE == 0) {
+    if (MODE == 0 || (MODE == 2 && r < ad.t)) {      // MODE 2: the shard's own rows (below ad.t) are updated in place
         Row<NV> w;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -747,7 +756,7 @@ __device__ __forceinline__ void finish_item_row(float *__restrict__ I, float *__
         if constexpr (WT) store_row_wt<T, NV, FULL>(I, r, D, lane, w);
         else store_row<T, NV, FULL>(I, r, D, lane, w);
     } else {
-        store_row<T, NV, FULL>(gradI, r, D, lane, g);
+        store_row<T, NV, FULL>(gradI, MODE == 2 ? r - ad.t : r, D, lane, g);
     }
     if (stampI != nullptr && lane == 0) stampI[r] = step_id;
 }
@@ -980,7 +989,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_hot_combine(float *__restri
         opt_finish_row<T, NV, FULL, MODE>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, g, ad);
         return;
     }
-    if (MODE == 0) {
+    if (MODE == 0 || (MODE == 2 && r < ad.t)) {
         const Row<NV> ir = load_row<T, NV, FULL>(I, r, D, lane);
         Row<NV> w;
 #pragma unroll
@@ -992,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void bprmf_item_hot_combine(float *__restri
         }
         store_row<T, NV, FULL>(I, r, D, lane, w);
     } else {
-        store_row<T, NV, FULL>(gradI, r, D, lane, g);
+        store_row<T, NV, FULL>(gradI, MODE == 2 ? r - ad.t : r, D, lane, g);
     }
     if (stampI != nullptr && lane == 0) stampI[r] = step_id;
 }
@@ -1180,8 +1189,9 @@ static int32_t launch_step(float *U, float *I, int32_t D, const int32_t *tu, con
 //                               until every item tile has signalled, then ONE agent-scope acquire, s_waitcnt vmcnt(0), a
 //                               workgroup barrier, and plain loads.
 // Forward progress does not rest on dispatch order: only the deferred workgroups ever wait, there are at most
-// kChainDefBlocks (128) of them — fewer than the 256 CUs each hold at least one workgroup — and nothing they wait for
-// waits itself, so a free slot always goes to a workgroup that runs to completion.  The poll is bounded all the same (an
+// min(kChainDefBlocks, CUs of the device / 2) of them (launch_chain_steps reads the device's CU count) — fewer than the CUs,
+// each of which holds at least one workgroup — and nothing they wait for waits itself, so a free slot always goes to a
+// workgroup that runs to completion.  The poll is bounded all the same (an
 // exit every wave reaches): on expiry the sticky word `timeout` is set and the workgroup goes on; the host treats a
 // non-zero word as a failed run (never observed).
 // Rows are handed over in whole 128-B lines (the host takes this path only when D * 4 is a multiple of 128 and the tables
@@ -1290,8 +1300,13 @@ static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *
                                   int64_t first_batch, int64_t n_batches, float lr, float *loss_out, const int32_t *tdef,
                                   const int32_t *def_q, const int32_t *def_count_host, int64_t def_cap, int64_t def_limit,
                                   void *workspace, uint32_t *sync, int64_t sync_words, hipStream_t stream,
-                                  void *const *events) {
+                                  void *const *events, int n_cu) {
     const int64_t ws_one = step_ws_bytes(batch_size, D);
+    // Forward progress: only the deferred workgroups ever wait, and nothing they wait for waits itself — so it is enough
+    // that they never fill the device: at most half a workgroup per CU of THIS device (a CPX partition or a smaller agent
+    // has fewer CUs than a whole MI355X's 256), never more than kChainDefBlocks.  With no room for even one, every step
+    // takes the two-launch form.
+    const int max_def_blocks = std::min(kChainDefBlocks, n_cu / 2);
     const StepWs w2[2] = {carve_step_ws(workspace, batch_size, D),
                           carve_step_ws(reinterpret_cast<char *>(workspace) + ws_one, batch_size, D)};
     const int64_t dwords = (batch_size + 31) / 32;
@@ -1331,10 +1346,10 @@ static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *
         const StepWs &w = w2[k & 1];
         const int nA = (int)n_blocks_for(Bk, D);
         const int n_def = (k == 0 || !pend.on) ? -1 : def_count_host[b];
-        const bool chained = pend.on && n_def >= 0 && n_def <= def_cap && n_def <= def_limit;
+        const bool chained = pend.on && n_def >= 0 && n_def <= def_cap && n_def <= def_limit && max_def_blocks >= 1;
         if (chained) {
             const int n_chunks = (WR_CHAIN_DBG & 16) ? 0 : (n_def + TEAMS - 1) / TEAMS;
-            const int nD = n_chunks < kChainDefBlocks ? n_chunks : kChainDefBlocks;
+            const int nD = n_chunks < max_def_blocks ? n_chunks : max_def_blocks;
             const int nI = (int)((2 * pend.Bk + WR_CHAIN_TILE - 1) / WR_CHAIN_TILE);
             const int item_at = (int)((int64_t)nA * WR_CHAIN_ITEM_AT / 16), def_at = (int)((int64_t)nA * WR_CHAIN_DEF_AT / 16);
             const StepWs &wp = w2[pend.k & 1];
@@ -1626,23 +1641,27 @@ int32_t wr_bprmf_run_stateful_bounded(int32_t kind, float *user_tab, int64_t n_u
     return WR_OK;
 }
 
-int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, const float *item_rows, int64_t n_slots, int32_t D,
-                            const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+int32_t wr_bprmf_shard_step(float *user_shard, int64_t n_user_rows, float *item_rows, int64_t n_rows, int64_t n_local_items,
+                            int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
                             const int32_t *oc_src, int64_t B, int64_t global_batch, float lr, float *grad_slots,
                             float *loss_partial, const wr_hot_runs *hot, void *workspace, int64_t workspace_bytes,
                             void *stream_) {
     int32_t rc;
     if ((rc = check_table(user_shard, n_user_rows, D, "user_shard")) != WR_OK) return rc;
-    if ((rc = check_table(item_rows, n_slots, D, "item_rows")) != WR_OK) return rc;
-    if ((rc = check_table(grad_slots, n_slots, D, "grad_slots")) != WR_OK) return rc;
+    if ((rc = check_table(item_rows, n_rows, D, "item_rows")) != WR_OK) return rc;
+    WR_REQUIRE(n_local_items >= 0 && n_local_items <= n_rows, WR_E_SHAPE, "n_local_items %lld outside [0, %lld]",
+               (long long)n_local_items, (long long)n_rows);
+    WR_REQUIRE(grad_slots != nullptr && aligned16(grad_slots), WR_E_NULL, "grad_slots is NULL or not 16-byte aligned");
     if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, B)) != WR_OK) return rc;
     WR_REQUIRE(global_batch >= B, WR_E_SHAPE, "global_batch %lld < local batch %lld", (long long)global_batch, (long long)B);
     WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= step_ws_bytes(B, D), WR_E_WORKSPACE,
                "wr_bprmf_shard_step: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)step_ws_bytes(B, D));
-    // MODE 2 never writes item_rows; the const_cast only serves the shared kernel signature.
-    return launch_step<2>(user_shard, const_cast<float *>(item_rows), D, tu, tp, tn, oc_item, oc_src, B, lr, 0.f, nullptr,
+    // MODE 2: rows below n_local_items are rewritten in place, the others only read (their gradients go to grad_slots)
+    AdamArgs ad{};
+    ad.t = (int)n_local_items;
+    return launch_step<2>(user_shard, item_rows, D, tu, tp, tn, oc_item, oc_src, B, lr, 0.f, nullptr,
                           grad_slots, nullptr, nullptr, 0, loss_partial, workspace, reinterpret_cast<hipStream_t>(stream_),
-                          nullptr, (float)global_batch, hot_of(hot, 0));
+                          nullptr, (float)global_batch, hot_of(hot, 0), 0, ad);
 }
 
 int32_t wr_bprmf_chain_supported(const float *user_tab, const float *item_tab, int32_t D) {
@@ -1676,12 +1695,18 @@ int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab
                "wr_bprmf_run_sgd_chain: %lld sync words < %lld", (long long)sync_words,
                (long long)(n_batches * kChainStepWords + 4));
     if (n_batches == 0) return WR_OK;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        WR_HIP(hipGetDevice(&dev));
+        WR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
 #define WR_CALL_CHAIN(T_, NV_, FULL_)                                                                                      \
     return launch_chain_steps<T_, NV_, FULL_>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, n_triplets, batch_size,   \
                                               first_batch, n_batches, lr, loss_out, tdef, def_q, def_count_host, def_cap,  \
                                               def_limit, workspace, reinterpret_cast<uint32_t *>(sync), sync_words, stream, \
-                                              events)
+                                              events, n_cu)
     WR_DISPATCH_D(D, WR_CALL_CHAIN);
 #undef WR_CALL_CHAIN
     return WR_OK;

@@ -350,6 +350,11 @@ struct GsArgs {
     int nA, nIT, nUT, nDS, tiles_at, side_at;
     int chained;                 // the tiles of `prev` ride in this launch: DF bits are honoured
     unsigned *done, *timeout;
+    // row-sharded step (multi-GPU, whisprrec_amd/sharded.py): item rows >= nL of the item table are rows RECEIVED from their
+    // owners for this step (slots); they are read like any row, but instead of being rewritten their gradient row (the sum
+    // of +-c U[u] over the batch) goes to Gs[row - nL], to be returned to the owner.  Gs == NULL: not sharded.
+    float *Gs;
+    int nL;
 };
 
 template <int NV>
@@ -394,20 +399,31 @@ __device__ __forceinline__ void gs_single(const GsArgs &a, int t, int u, int p, 
         store_row<T, NV, FULL>(a.ZU, t, a.D, lane, g);
     }
     if (!ps) {
-        Row<NV> w;
+        if (a.Gs != nullptr && p >= a.nL) {       // a received row: its gradient goes back to the owner
+            store_row<T, NV, FULL>(a.Gs, p - a.nL, a.D, lane, z);
+        } else {
+            Row<NV> w;
 #pragma unroll
-        for (int k = 0; k < NV; ++k)
-            w.v[k] = make_float4(pr.v[k].x - lr * z.v[k].x, pr.v[k].y - lr * z.v[k].y, pr.v[k].z - lr * z.v[k].z,
-                                 pr.v[k].w - lr * z.v[k].w);
-        store_row<T, NV, FULL>(a.I, p, a.D, lane, w);
+            for (int k = 0; k < NV; ++k)
+                w.v[k] = make_float4(pr.v[k].x - lr * z.v[k].x, pr.v[k].y - lr * z.v[k].y, pr.v[k].z - lr * z.v[k].z,
+                                     pr.v[k].w - lr * z.v[k].w);
+            store_row<T, NV, FULL>(a.I, p, a.D, lane, w);
+        }
     }
     if (!ns) {
-        Row<NV> w;
+        if (a.Gs != nullptr && n >= a.nL) {
+            Row<NV> zn;
 #pragma unroll
-        for (int k = 0; k < NV; ++k)
-            w.v[k] = make_float4(nr.v[k].x - lr * (-z.v[k].x), nr.v[k].y - lr * (-z.v[k].y), nr.v[k].z - lr * (-z.v[k].z),
-                                 nr.v[k].w - lr * (-z.v[k].w));
-        store_row<T, NV, FULL>(a.I, n, a.D, lane, w);
+            for (int k = 0; k < NV; ++k) zn.v[k] = make_float4(-z.v[k].x, -z.v[k].y, -z.v[k].z, -z.v[k].w);
+            store_row<T, NV, FULL>(a.Gs, n - a.nL, a.D, lane, zn);
+        } else {
+            Row<NV> w;
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                w.v[k] = make_float4(nr.v[k].x - lr * (-z.v[k].x), nr.v[k].y - lr * (-z.v[k].y), nr.v[k].z - lr * (-z.v[k].z),
+                                     nr.v[k].w - lr * (-z.v[k].w));
+            store_row<T, NV, FULL>(a.I, n, a.D, lane, w);
+        }
     }
     if (ps || ns) store_row<T, NV, FULL>(a.Z, t, a.D, lane, z);
 }
@@ -492,7 +508,8 @@ __device__ __forceinline__ void gs_tile_fetch(GsTile &tl, const int *__restrict_
 
 template <int T, int NV, bool FULL, bool WT>
 __device__ __forceinline__ void gs_tile_finish(float *__restrict__ W, int D, float lr, int B, const float *__restrict__ Z,
-                                               const GsTile &tl, int *__restrict__ lds) {
+                                               const GsTile &tl, int *__restrict__ lds, float *__restrict__ Gs = nullptr,
+                                               int nL = 0) {
     int *rows_t = lds, *src_t = rows_t + (kGsTile + kGsAhead), *heads = src_t + (kGsTile + kGsAhead);
     int &n_heads = heads[kGsTile];
     constexpr int TEAMS = kBlock / T;
@@ -514,7 +531,9 @@ __device__ __forceinline__ void gs_tile_finish(float *__restrict__ W, int D, flo
     for (int h = threadIdx.x / T; h < nh; h += TEAMS) {
         const int j0 = heads[h];
         const int r = rows_t[j0];
-        const Row<NV> ir = load_row<T, NV, FULL>(W, r, D, lane);
+        const bool slot = Gs != nullptr && r >= nL;     // row-sharded step: a received row — its summed gradient goes to Gs
+        Row<NV> ir = row_zero<NV>();
+        if (!slot) ir = load_row<T, NV, FULL>(W, r, D, lane);
         const int s0 = src_t[j0];
         const bool two = rows_t[j0 + 1] == r;     // kGsAhead >= 1: in the staged window
         const int s1 = src_t[j0 + 1];
@@ -556,6 +575,10 @@ __device__ __forceinline__ void gs_tile_finish(float *__restrict__ W, int D, flo
             if (j == kGsTile + kGsAhead)
                 for (int e = tl.e0 + j; e < tl.len && tl.lrow[e] == r; ++e) add_z(min(max(tl.lsrc[e], 0), 2 * B - 1));
         }
+        if (slot) {
+            store_row<T, NV, FULL>(Gs, r - nL, D, lane, g);
+            continue;
+        }
         Row<NV> wv;
 #pragma unroll
         for (int k = 0; k < NV; ++k)
@@ -576,13 +599,14 @@ __device__ __forceinline__ void gs_tile_finish(float *__restrict__ W, int D, flo
 template <int T, int NV, bool FULL, bool WT>
 __device__ __forceinline__ void gs_list_tiles(float *__restrict__ W, int D, float lr, const int *__restrict__ l_row,
                                               const int *__restrict__ l_src, const int *__restrict__ l_cnt, int R, int cap,
-                                              int B, const float *__restrict__ Z, int w, int nw, int *__restrict__ lds) {
+                                              int B, const float *__restrict__ Z, int w, int nw, int *__restrict__ lds,
+                                              float *__restrict__ Gs = nullptr, int nL = 0) {
     for (int q = w;; q += nw) {      // workgroup `w` of `nw` takes tiles w, w + nw, ...
         int seg, e0, len;
         if (!gs_tile_of(l_cnt, R, cap, q, seg, e0, len)) break;
         GsTile tl;
         gs_tile_fetch(tl, l_row, l_src, seg, cap, e0, len, B);
-        gs_tile_finish<T, NV, FULL, WT>(W, D, lr, B, Z, tl, lds);
+        gs_tile_finish<T, NV, FULL, WT>(W, D, lr, B, Z, tl, lds, Gs, nL);
     }
 }
 
@@ -604,9 +628,9 @@ __global__ __launch_bounds__(kBlock, NV == 1 ? WR_GS_WAVES : 1) void bprmf_group
         if (!(WR_GS_DBG & 1)) {
             if (w < a.nIT) {
                 if (wt) gs_list_tiles<T, NV, FULL, true>(a.I, a.D, a.lr, a.prev.il_row, a.prev.il_src, a.prev.il_cnt, a.prev.R_i, a.prev.cap_i,
-                                                         a.prev.B, a.Zp, w, a.nIT, lds);
+                                                         a.prev.B, a.Zp, w, a.nIT, lds, a.Gs, a.nL);
                 else gs_list_tiles<T, NV, FULL, false>(a.I, a.D, a.lr, a.prev.il_row, a.prev.il_src, a.prev.il_cnt, a.prev.R_i, a.prev.cap_i,
-                                                       a.prev.B, a.Zp, w, a.nIT, lds);
+                                                       a.prev.B, a.Zp, w, a.nIT, lds, a.Gs, a.nL);
             } else {
                 if (wt) gs_list_tiles<T, NV, FULL, true>(a.U, a.D, a.lr, a.prev.ul_row, a.prev.ul_src, a.prev.ul_cnt, a.prev.R_u, a.prev.cap_u,
                                                          a.prev.B, a.ZUp, w - a.nIT, a.nUT, lds);
@@ -750,7 +774,8 @@ template <int T, int NV, bool FULL>
 static int32_t launch_group_steps(float *U, float *I, int32_t D, const int32_t *u, const int32_t *p, const int32_t *n,
                                   int64_t n_triplets, const GroupLayout &L, const GpDev &G, int64_t first_batch,
                                   int64_t n_batches, float lr, float *loss_out, void *workspace, uint32_t *sync,
-                                  int64_t sync_words, hipStream_t stream, void *const *events, int n_cu) {
+                                  int64_t sync_words, hipStream_t stream, void *const *events, int n_cu,
+                                  float *grad_slots = nullptr, int64_t n_local_items = 0, int64_t global_batch = 0) {
     const int64_t B = L.B;
     const int64_t ws_one = gs_ws_one(B, D), zb = align_up(B * (int64_t)D * 4, 256);
     char *ws = reinterpret_cast<char *>(workspace);
@@ -782,13 +807,15 @@ static int32_t launch_group_steps(float *U, float *I, int32_t D, const int32_t *
         a.lr = lr;
         a.done = sync + (k < n_batches ? k : 0) * kGsStepWords;
         a.timeout = timeout;
+        a.Gs = grad_slots;
+        a.nL = (int)n_local_items;
         const bool have_cur = k < n_batches, have_prev = k > 0;
         if (have_cur) {
             a.cur = batch_of(first_batch + k);
             a.Z = Zs[k & 1];
             a.ZU = ZUs[k & 1];
             a.partials = Ps[k & 1];
-            a.denom = (float)a.cur.B;
+            a.denom = global_batch > 0 ? (float)global_batch : (float)a.cur.B;
             a.nA = (int)((a.cur.B + TEAMS - 1) / TEAMS);
             a.nDS = have_prev ? nDS : 0;
             a.chained = have_prev ? 1 : 0;
@@ -799,7 +826,7 @@ static int32_t launch_group_steps(float *U, float *I, int32_t D, const int32_t *
             a.ZUp = ZUs[(k - 1) & 1];
             a.partials_prev = Ps[(k - 1) & 1];
             a.n_partials_prev = n_partials_prev;
-            a.denom_prev = (float)a.prev.B;
+            a.denom_prev = global_batch > 0 ? (float)global_batch : (float)a.prev.B;
             a.loss_prev = loss_out ? loss_out + (k - 1) : nullptr;
             // one tile (32 list entries) per workgroup where the lists are as long as uniform ids make them; longer lists
             // are walked in strides
@@ -915,6 +942,45 @@ int32_t wr_bprmf_run_sgd_group(float *user_tab, int64_t n_users, float *item_tab
                                               events, n_cu)
     WR_DISPATCH_D(D, WR_CALL_GS);
 #undef WR_CALL_GS
+    return WR_OK;
+}
+
+int32_t wr_bprmf_shard_step_group(float *user_shard, int64_t n_user_rows, float *item_ext, int64_t n_ext_rows,
+                                  int64_t n_local_items, int32_t D, const int32_t *vu, const int32_t *vp, const int32_t *vn,
+                                  int64_t n_triplets, int64_t batch_size, const int32_t *plan, int64_t plan_words, int64_t batch,
+                                  int64_t global_batch, float lr, float *grad_slots, float *loss_partial, void *workspace,
+                                  int64_t workspace_bytes, int32_t *sync, int64_t sync_words, void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_shard, n_user_rows, D, "user_shard")) != WR_OK) return rc;
+    if ((rc = check_table(item_ext, n_ext_rows, D, "item_ext")) != WR_OK) return rc;
+    WR_REQUIRE(vu && vp && vn && plan && sync && grad_slots, WR_E_NULL, "index arrays / plan / sync words / grad_slots must not be NULL");
+    WR_REQUIRE(aligned16(grad_slots), WR_E_ALIGN, "grad_slots is not 16-byte aligned");
+    WR_REQUIRE(n_local_items >= 0 && n_local_items <= n_ext_rows, WR_E_SHAPE, "n_local_items %lld outside [0, %lld]",
+               (long long)n_local_items, (long long)n_ext_rows);
+    WR_REQUIRE(gs_shape_ok(user_shard, item_ext, D), WR_E_ALIGN,
+               "wr_bprmf_shard_step_group: rows must be whole 128-B lines (D %% 32 == 0, tables 128-B aligned); D = %d", (int)D);
+    GroupLayout L;
+    WR_REQUIRE(group_layout(n_triplets, batch_size, n_user_rows, n_ext_rows, L), WR_E_RANGE,
+               "group plan not applicable to n=%lld, batch=%lld", (long long)n_triplets, (long long)batch_size);
+    WR_REQUIRE(plan_words >= L.total, WR_E_WORKSPACE, "group plan: %lld words < %lld", (long long)plan_words, (long long)L.total);
+    WR_REQUIRE(batch >= 0 && batch < L.nb, WR_E_SHAPE, "batch %lld outside the plan's %lld", (long long)batch, (long long)L.nb);
+    WR_REQUIRE(global_batch >= batch_size, WR_E_SHAPE, "global_batch %lld < local batch %lld", (long long)global_batch,
+               (long long)batch_size);
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 2 * gs_ws_one(batch_size, D), WR_E_WORKSPACE,
+               "wr_bprmf_shard_step_group: workspace %lld B < %lld B", (long long)workspace_bytes,
+               (long long)(2 * gs_ws_one(batch_size, D)));
+    WR_REQUIRE(aligned16(sync) && sync_words >= 2 * kGsStepWords + 4, WR_E_WORKSPACE, "wr_bprmf_shard_step_group: %lld sync words < %lld",
+               (long long)sync_words, (long long)(2 * kGsStepWords + 4));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const GpDev G = group_dev(const_cast<int32_t *>(plan), L);
+    // one batch = the launch of its triplets + the launch of its own tiles (the tiles cannot ride in the next step's launch:
+    // the received rows and the gradient slots belong to THIS step's exchange)
+#define WR_CALL_GSS(T_, NV_, FULL_)                                                                                        \
+    return launch_group_steps<T_, NV_, FULL_>(user_shard, item_ext, D, vu, vp, vn, n_triplets, L, G, batch, 1, lr,         \
+                                              loss_partial, workspace, reinterpret_cast<uint32_t *>(sync), sync_words,     \
+                                              stream, nullptr, 256, grad_slots, n_local_items, global_batch)
+    WR_DISPATCH_D(D, WR_CALL_GSS);
+#undef WR_CALL_GSS
     return WR_OK;
 }
 

@@ -1,25 +1,34 @@
 """Row-sharded BPRMF step across the GPUs of one node: one process per GPU, RCCL all-to-all over xGMI.
 
-The reference is single-device; this module is new design, not a translation.  Semantics are those
-of ONE BaseRunner.fit iteration (reference src/helpers/BaseRunner.py:196-199) over the union of all ranks' batches:
-synchronous SGD, every gradient taken from the pre-step tables, loss = mean over the global batch.
+The reference is single-device; this module is new design, not a translation.  Semantics are those of ONE
+BaseRunner.fit iteration (reference src/helpers/BaseRunner.py:196-199) over the union of all ranks' batches: synchronous SGD,
+every gradient taken from the pre-step tables, loss = mean over the global batch, negatives drawn from ALL items
+(src/models/BaseModel.py:168,174).
 
 Layout
-  * both tables are row-sharded cyclically: row r lives on rank r % G at local index r // G (cyclic keeps popular —
-    low-id — items spread over all shards; a checkpoint is re-assembled by interleaving, ``gather_full``).
-  * interactions are partitioned by user owner, so the user row of every triplet is local and only ITEM rows cross
-    links.  Each rank draws its own batches (size B) from its partition; the global batch is their union.
-Per chunk of steps (plan time, amortised; index work only — it never depends on table values)
-  * per step: unique (owner, local row) item keys of the local batch -> slot ids; the triplets are rewritten to
-    (local user row, pos slot, neg slot) and planned with the ordinary BatchPlan;
-  * ONE all-to-all of the request lists of all steps of the chunk tells every owner which rows to serve at each
-    step; the owner pre-sorts, per step, the rows it will receive gradients for (fixed summation order).
+  * both tables are row-sharded cyclically: row r lives on rank r % G at local index r // G (cyclic keeps popular — low-id —
+    items spread over all shards; a checkpoint is re-assembled by interleaving, ``gather_full``).
+  * interactions are partitioned by user owner, so the user row of every triplet is local and only ITEM rows cross links.
+    Each rank draws its own batches (size B) from its partition; the global batch is their union.
+  * a rank's item buffer holds its own rows followed by 2 B "slot" rows: the rows a step receives from their owners land
+    right behind the shard, so the step kernels address local and received rows alike ("virtual" item ids).
+One rank (world = 1): every item row is local — the step stream is the single-GPU one (hip_ops.PipelinedSgd: group plans, one
+launch per step), nothing is exchanged.
+Per chunk of steps (index work only — it never depends on table values; native kernels, no host-side sort)
+  * wr_shard_route: local items keep their local row; a step's distinct REMOTE items get slots in ascending (owner, row) order
+    (LDS bitmap of the routed keys + prefix popcounts); per owner the requested rows go into a padded send buffer;
+  * TWO fixed-size all-to-alls carry the request lists and their lengths of all steps of the chunk; wr_shard_pack turns what
+    arrived into per-step lists of rows to serve; ONE read-back brings the lengths to the host (the split sizes of the
+    steps' row exchanges);
+  * the group plan of the chunk (wr_group_plan_build) on the virtual ids: which rows recur inside a batch.
 Per step (hot path)
-  1. owner: wr_gather_rows of the requested rows            -> all-to-all (rows to requesters)
-  2. requester: wr_bprmf_shard_step on (local user shard, received rows): user rows updated in place, one reduced
-     gradient row per slot                                   -> all-to-all (gradient rows back to owners)
-  3. owner: wr_apply_rows_sorted(alpha = -lr)               (segmented, duplicate rows from several ranks summed)
+  1. owner: wr_gather_rows of the rows requested from it            -> all-to-all (rows to the requesters' slot rows)
+  2. requester: wr_bprmf_shard_step_group — user rows and LOCAL item rows updated in place, one summed gradient row per slot
+                                                                    -> all-to-all (gradient rows back to the owners)
+  3. owner: wr_scatter_add_rows(alpha = -lr): rows requested by several ranks are summed in a fixed order
   No collective carries the loss: per-step partials are all-reduced once per chunk.
+A row that its owner also trains on is updated twice in a step (the owner's own contribution in place, the others' in 3.):
+the same sum, rounded once more — within the 1e-5 of the north star, and the same bits from run to run.
 Link budget per rank and step: 2 * D*4 * (unique remote items) bytes each way — see DESIGN.md §6.
 """
 import math
@@ -30,85 +39,87 @@ import torch
 import torch.distributed as dist
 
 
-def slotify_generic(u_loc, rk_p, rk_n, batch, GM):
-    """Per step: unique routed item keys (ascending) and the slot (rank of its key inside the step) of every occurrence.
-    Device-agnostic restatement with torch.unique; HipBackend.slotify gets the same result from the batch plan's sort.
-    Returns (slot_p, slot_n, uniq_key, uniq_step, nq)."""
-    dev = u_loc.device
-    N = u_loc.numel()
-    nb = (N + batch - 1) // batch
-    step_of = torch.arange(N, device=dev) // batch
-    ck = torch.cat([step_of * GM + rk_p, step_of * GM + rk_n])
-    uniq, inv = torch.unique(ck, return_inverse=True)                      # sorted by (step, routed key)
-    step_starts = torch.searchsorted(uniq, torch.arange(nb + 1, device=dev) * GM)
-    slots = inv - step_starts[torch.cat([step_of, step_of])]
-    return slots[:N], slots[N:], uniq % GM, uniq // GM, step_starts[1:] - step_starts[:-1]
-
-
 class HipBackend:
-    """Local compute through the C-ABI.  (Tests substitute an oracle-backed object with the same methods to exercise
-    the exchange logic on CPU/gloo; the product never does.)"""
+    """Local compute through the C-ABI.  (Tests substitute an oracle-backed object with the same methods to exercise the
+    exchange logic on CPU/gloo; the product never does.)"""
 
     def __init__(self):
         from . import abi, hip_ops
         self.abi, self.ops = abi, hip_ops
 
-    def plan_slots(self, u_loc, rk_p, rk_n, batch, n_user_rows, GM):
-        """Batch plan + slot ids in one go: the plan is built on the ROUTED item keys (a bijection of item ids, so runs and
-        flags are the same), the heads of the sorted runs are the step's unique keys, a prefix sum over the head flags
-        gives every occurrence its slot, and tp/tn/oc_item are rewritten from keys to slots.  The sort is the plan
-        builder's (hand-written kernels); what is left here is flag/prefix/scatter glue on int32 vectors."""
-        dev = u_loc.device
-        N, B = u_loc.numel(), batch
-        plan = self.ops.BatchPlan(u_loc.to(torch.int32), rk_p.to(torch.int32), rk_n.to(torch.int32), B, n_user_rows, GM,
-                                  validate=True)
-        nb = plan.n_batches
-        oi = plan.oc_item
-        pos = torch.arange(2 * N, device=dev)
-        bidx = pos // (2 * B)
-        head = torch.ones(2 * N, dtype=torch.bool, device=dev)
-        head[1:] = oi[1:] != oi[:-1]
-        head[bidx * (2 * B) == pos] = True
-        csum = torch.cumsum(head.to(torch.int32), 0)
-        slot = (csum - csum[bidx * (2 * B)]).to(torch.int32)               # 0-based rank of the run inside its batch
-        uniq_key = oi[head].to(torch.int64)
-        uniq_step = bidx[head]
-        nq = torch.bincount(uniq_step, minlength=nb)
-        t_idx = bidx * B + (plan.oc_src >> 1).to(torch.int64)
-        neg_side = (plan.oc_src & 1).bool()
-        slot_p = torch.empty(N, dtype=torch.int32, device=dev)
-        slot_n = torch.empty(N, dtype=torch.int32, device=dev)
-        slot_p[t_idx[~neg_side]] = slot[~neg_side]
-        slot_n[t_idx[neg_side]] = slot[neg_side]
-        flag = torch.tensor(-2 ** 31, dtype=torch.int32, device=dev)
-        plan.tp = (plan.tp & flag) | slot_p                                    # keep bit 31 (several occurrences), swap key for slot
-        plan.tn = (plan.tn & flag) | slot_n
-        plan.oc_item = slot.contiguous()
-        return plan, uniq_key, uniq_step, nq
+    def route(self, u, p, n, batch, world, rank, n_users, n_items, M, nL, C):
+        dev, N = u.device, u.numel()
+        nb = (N + batch - 1) // batch
+        i32 = dict(dtype=torch.int32, device=dev)
+        vu, vp, vn = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
+        send_rows, send_cnt = torch.empty(world * nb * C, **i32), torch.empty(world * nb, **i32)
+        err = torch.zeros(2, **i32)
+        u, p, n = (t.to(torch.int32).contiguous() for t in (u, p, n))
+        self.abi.check(self.abi.lib().wr_shard_route(u.data_ptr(), p.data_ptr(), n.data_ptr(), N, batch, world, rank, n_users,
+                                                     n_items, M, nL, C, vu.data_ptr(), vp.data_ptr(), vn.data_ptr(),
+                                                     send_rows.data_ptr(), send_cnt.data_ptr(), err.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "wr_shard_route")
+        return vu, vp, vn, send_rows, send_cnt, err
+
+    def pack(self, recv_rows, recv_cnt, nb, world, C, nL):
+        dev = recv_rows.device
+        serve_rows = torch.empty(nb * world * C, dtype=torch.int64, device=dev)
+        serve_off = torch.empty(nb * (world + 1), dtype=torch.int32, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.abi.check(self.abi.lib().wr_shard_pack(recv_rows.data_ptr(), recv_cnt.data_ptr(), nb, world, C, nL,
+                                                    serve_rows.data_ptr(), world * C, serve_off.data_ptr(), err.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), "wr_shard_pack")
+        return serve_rows.view(nb, world * C), serve_off.view(nb, world + 1), err
+
+    GROUP_MIN_ROWS_PER_TRIPLET = 12      # as hip_ops.PipelinedSgd: below this the lists of shared rows outgrow their capacity
+
+    def plan_local(self, vu, vp, vn, batch, n_user_rows, n_ext_rows, n_local_items, D=64):
+        """which rows recur inside a batch: the group plan (no sort) where the shard is large against the batch and rows are
+        whole 128-byte lines; otherwise — and for any chunk whose lists overflow (popularity-skewed ids) — the sorted batch
+        plan (wr_plan*.hip) and its two-kernel step with the hot-row path"""
+        ops = self.ops
+        tabs_ok = (int(D) * 4) % 128 == 0          # rows are whole 128-byte lines (torch allocations are 256-byte aligned)
+        if tabs_ok and batch <= 131072 and min(n_user_rows, n_local_items) >= self.GROUP_MIN_ROWS_PER_TRIPLET * batch:
+            plan = ops.GroupPlan(vu, vp, vn, batch, n_user_rows, n_ext_rows)
+            plan.validate()
+            if not plan.overflow and not plan.long_run:
+                return plan
+        return ops.BatchPlan(vu, vp, vn, batch, n_user_rows, n_ext_rows, validate=True)
 
     def gather_rows(self, tab, idx):
         return self.ops.gather_rows(tab, idx)
 
-    def local_step(self, U, item_rows, plan, k, global_batch, lr, grad_slots, loss_out):
+    def local_step(self, U, I_ext, nL, plan, k, global_batch, lr, grad_slots, loss_out):
         L, ops = self.abi.lib(), self.ops
-        off = k * plan.batch_size
-        B = plan.batch_len(k)
-        nbytes = self.abi.check_size(L.wr_bprmf_step_workspace_bytes(plan.batch_size, U.shape[1]), "workspace")
-        ws = ops.workspace(U.device, "step").get(nbytes)
-        import ctypes
-        hot = plan.hot_struct(k)
-        self.abi.check(L.wr_bprmf_shard_step(U.data_ptr(), U.shape[0], item_rows.data_ptr(), item_rows.shape[0], U.shape[1],
-                                             plan.tu.data_ptr() + 4 * off, plan.tp.data_ptr() + 4 * off,
-                                             plan.tn.data_ptr() + 4 * off, plan.oc_item.data_ptr() + 8 * off,
-                                             plan.oc_src.data_ptr() + 8 * off, B, global_batch, lr, grad_slots.data_ptr(),
-                                             loss_out.data_ptr(), ctypes.addressof(hot) if hot is not None else None,
-                                             ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
-                       "wr_bprmf_shard_step")
+        if isinstance(plan, ops.BatchPlan):
+            import ctypes
+            off, B = k * plan.batch_size, plan.batch_len(k)
+            nbytes = self.abi.check_size(L.wr_bprmf_step_workspace_bytes(plan.batch_size, U.shape[1]), "workspace")
+            ws = ops.workspace(U.device, "step").get(nbytes)
+            hot = plan.hot_struct(k)
+            self.abi.check(L.wr_bprmf_shard_step(U.data_ptr(), U.shape[0], I_ext.data_ptr(), I_ext.shape[0], nL, U.shape[1],
+                                                 plan.tu.data_ptr() + 4 * off, plan.tp.data_ptr() + 4 * off,
+                                                 plan.tn.data_ptr() + 4 * off, plan.oc_item.data_ptr() + 8 * off,
+                                                 plan.oc_src.data_ptr() + 8 * off, B, global_batch, lr, grad_slots.data_ptr(),
+                                                 loss_out.data_ptr(), ctypes.addressof(hot) if hot is not None else None,
+                                                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                           "wr_bprmf_shard_step")
+            return
+        nbytes = self.abi.check_size(L.wr_bprmf_group_workspace_bytes(plan.batch_size, U.shape[1]), "workspace")
+        ws = ops.workspace(U.device, "group_step").get(nbytes)
+        sync = ops.BprmfTables(U, I_ext)._group_sync(1)
+        self.abi.check(L.wr_bprmf_shard_step_group(U.data_ptr(), U.shape[0], I_ext.data_ptr(), I_ext.shape[0], nL, U.shape[1],
+                                                   plan.u.data_ptr(), plan.p.data_ptr(), plan.n.data_ptr(), plan.n_triplets,
+                                                   plan.batch_size, plan.buf.data_ptr(), plan.buf.numel(), k, global_batch, lr,
+                                                   grad_slots.data_ptr(), loss_out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   sync.data_ptr(), sync.numel(), torch.cuda.current_stream().cuda_stream),
+                       "wr_bprmf_shard_step_group")
 
-    def apply_sorted(self, tab, sorted_rows, perm, src, alpha):
-        self.abi.check(self.abi.lib().wr_apply_rows_sorted(tab.data_ptr(), tab.shape[0], tab.shape[1], sorted_rows.data_ptr(),
-                                                           perm.data_ptr(), src.data_ptr(), sorted_rows.numel(), alpha,
-                                                           torch.cuda.current_stream().cuda_stream), "wr_apply_rows_sorted")
+    def scatter_add(self, tab, idx, src, alpha):
+        self.ops.scatter_add_rows(tab, idx, src, alpha=alpha)
+
+    def check(self, U, I_ext):
+        self.ops.BprmfTables(U, I_ext).check_chain()
 
 
 def n_local_rows(n_rows, rank, world):
@@ -120,16 +131,37 @@ class ChunkPlan:
 
 
 class ShardedBprmf:
-    def __init__(self, n_users, n_items, emb_size, device, backend=None, group=None):
+    def __init__(self, n_users, n_items, emb_size, device, backend=None, group=None, loopback=0):
+        """loopback = G > 1 (measurement only, with ONE real rank): this rank does rank 0's work of a G-rank job — routing,
+        request lists, gathers, the step on received rows, gradient rows back, scatter-add — with every exchange replaced
+        by a device copy from itself (the other ranks are taken to be clones: what it requests from owner o is what
+        requester o is taken to request from it).  Prices the per-rank work beside the links; no result to compare."""
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.loopback = int(loopback) if int(loopback) > 1 else 0
+        if self.loopback:
+            assert self.world == 1, "loopback runs with one real rank"
+            self.rank, self.world = 0, self.loopback
         self.n_users, self.n_items, self.D = int(n_users), int(n_items), int(emb_size)
         self.device = device
         self.backend = backend if backend is not None else HipBackend()
-        self.M = (self.n_items + self.world - 1) // self.world          # slots of the routed key per owner
+        # rows per owner in the routed key space (owner * M + local row): a multiple of 32, so that a word of the routing
+        # bitmap belongs to one owner
+        self.M = ((self.n_items + self.world - 1) // self.world + 31) // 32 * 32
+        self.nL = n_local_rows(self.n_items, self.rank, self.world)
         self.U = torch.zeros(n_local_rows(self.n_users, self.rank, self.world), self.D, device=device)
-        self.I = torch.zeros(n_local_rows(self.n_items, self.rank, self.world), self.D, device=device)
+        self.I_ext = torch.zeros(max(self.nL, 1), self.D, device=device)       # grows by 2 B slot rows once the batch size is known
+        self.I = self.I_ext[:self.nL]
+        self._local = None               # world = 1: the single-GPU step stream
+
+    def _ensure_slots(self, batch):
+        """the item buffer = the shard's rows + 2 * batch slot rows (a step receives at most that many distinct rows)"""
+        need = self.nL + 2 * int(batch)
+        if self.I_ext.shape[0] < need:
+            ext = torch.zeros(need, self.D, device=self.device)
+            ext[:self.nL].copy_(self.I)
+            self.I_ext, self.I = ext, ext[:self.nL]
 
     # ------------------------------------------------------------------ tables
     def load_full(self, U_full, I_full):
@@ -147,6 +179,9 @@ class ShardedBprmf:
 
     def gather_full(self):
         """All-gather the shards into the reference's checkpoint layout (user_embeddings.weight, item_embeddings.weight)."""
+        if self.device.type == "cuda" and hasattr(self.backend, "check"):
+            self.backend.check(self.U, self.I_ext)      # never a checkpoint of tables a step launch has declared invalid
+        assert not self.loopback, "loopback objects hold one rank's share only"
         out = []
         for tab, n in ((self.U, self.n_users), (self.I, self.n_items)):
             cap = (n + self.world - 1) // self.world
@@ -159,85 +194,106 @@ class ShardedBprmf:
         return out
 
     # ------------------------------------------------------------------ plan (index work, once per chunk)
+    def list_cap(self, batch):
+        """entries of one (owner, step) request list: a step's 2 B item occurrences spread over the G owners, with room"""
+        G = self.world
+        return 2 * batch if G <= 2 else min(2 * batch, (2 * batch // G) * 3 // 2 + 1024)
+
     def plan_chunk(self, u, p, n, batch):
         """u, p, n: this rank's triplets of the chunk in batch order (global ids, every u % world == rank).
         All ranks must call this with the same number of steps."""
-        G, M, dev = self.world, self.M, u.device
+        G, dev = self.world, u.device
         N = u.numel()
         nb = (N + batch - 1) // batch
-        u, p, n = u.to(torch.int64), p.to(torch.int64), n.to(torch.int64)
-        GM = G * M
-        # routed key of an item: (owner, local row) — a bijection of the item id that makes each owner's rows contiguous
-        rk_p, rk_n = (p % G) * M + p // G, (n % G) * M + n // G
-        local_plan, u_key, u_step, nq = self.backend.plan_slots(u // G, rk_p, rk_n, batch, self.U.shape[0], GM)
-        u_owner, u_row = u_key // M, u_key % M
-        req_counts = torch.bincount(u_step * G + u_owner, minlength=nb * G).reshape(nb, G)   # rows requested per owner
-        # ---- exchange the request lists of the whole chunk: destination-major, then step
-        order = torch.sort(u_owner * nb + u_step, stable=True)[1]
-        send_rows = u_row[order]
-        send_counts = req_counts.t().contiguous()                              # [G, nb]
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts.view(-1), send_counts.view(-1), group=self.group)   # nb counts per peer
-        send_tot = send_counts.sum(1).tolist()
-        recv_tot = recv_counts.sum(1).tolist()
-        recv_rows = torch.empty(int(sum(recv_tot)), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(recv_rows, send_rows, output_split_sizes=recv_tot, input_split_sizes=send_tot, group=self.group)
-        # recv_rows is (source, step)-major; per step we serve the concatenation over sources: one stable sort by step
-        # regroups the whole chunk, a second one (by (step, row)) fixes every step's summation order
-        rc = recv_counts.cpu()                                                 # [G, nb]
-        seg_step = torch.arange(nb, device=dev).repeat(G)                      # step of each (source, step) segment
-        recv_step = torch.repeat_interleave(seg_step, recv_counts.reshape(-1))
-        order1 = torch.sort(recv_step, stable=True)[1]
-        serve_all = recv_rows[order1]                                          # step-major, sources in rank order inside a step
-        step_sorted = recv_step[order1]
-        serve_cnt = rc.sum(0)                                                  # rows served per step
-        serve_off = torch.zeros(nb + 1, dtype=torch.int64)
-        serve_off[1:] = torch.cumsum(serve_cnt, 0)
-        L = max(int(self.I.shape[0]), 1)
-        srt_key, order2 = torch.sort(step_sorted * L + serve_all, stable=True)
-        apply_rows_all = (srt_key % L).to(torch.int32)
-        apply_perm_all = (order2 - serve_off.to(dev)[step_sorted]).to(torch.int32)   # sorting keeps every element in its step
         cp = ChunkPlan()
         cp.nb, cp.batch, cp.N = nb, batch, N
-        cp.local = local_plan
-        cp.nq = nq.tolist()
-        cp.req_splits = req_counts.tolist()                                    # [nb][G] what I receive from owner d
-        cp.serve_splits = rc.t().contiguous().tolist()                         # [nb][G] what I send to requester s
-        so = serve_off.tolist()
-        cp.serve_rows = [serve_all[so[k]:so[k + 1]] for k in range(nb)]
-        cp.apply_rows = [apply_rows_all[so[k]:so[k + 1]] for k in range(nb)]
-        cp.apply_perm = [apply_perm_all[so[k]:so[k + 1]] for k in range(nb)]
-        cp.max_nq = max(cp.nq) if cp.nq else 0
-        cp.max_serve = max((r.numel() for r in cp.serve_rows), default=0)
+        if G == 1:
+            # every item row is local: the single-GPU step stream on this rank's tables
+            cp.u, cp.p, cp.n = (t.to(torch.int32).contiguous() for t in (u, p, n))
+            return cp
+        self._ensure_slots(batch)
+        C = self.list_cap(batch)
+        vu, vp, vn, send_rows, send_cnt, err = self.backend.route(u, p, n, batch, G, self.rank, self.n_users, self.n_items,
+                                                                  self.M, self.nL, C)
+        # the request lists of the whole chunk: two fixed-size all-to-alls (per peer: nb lists of C rows, nb lengths)
+        recv_rows, recv_cnt = torch.empty_like(send_rows), torch.empty_like(send_cnt)
+        self._a2a(recv_cnt, send_cnt)
+        self._a2a(recv_rows, send_rows)
+        if self.loopback:
+            recv_rows.clamp_(max=max(self.nL - 1, 0))      # the clones' shards may be one row shorter than rank 0's
+        serve_rows, serve_off, err2 = self.backend.pack(recv_rows, recv_cnt, nb, G, C, self.nL)
+        cp.local = self.backend.plan_local(vu, vp, vn, batch, self.U.shape[0], self.I_ext.shape[0], self.nL, self.D)
+        # ONE read-back per chunk: the lengths (split sizes of the steps' row exchanges) and the error words
+        host = torch.cat([send_cnt.view(G, nb).t().reshape(-1), serve_off.reshape(-1), err, err2]).cpu().numpy()
+        req = host[:nb * G].reshape(nb, G)                                        # rows I request from owner o at step k
+        off = host[nb * G:nb * G + nb * (G + 1)].reshape(nb, G + 1)               # where requester s's rows start in my serve list
+        e = host[nb * G + nb * (G + 1):]
+        if e[0] != 0:
+            raise IndexError("row-sharded step: id out of range, or a triplet whose user this rank does not own")
+        if e[1] != 0:
+            raise RuntimeError("row-sharded step: a request list exceeds its capacity (%d rows per owner and step)" % C)
+        if e[2] != 0:
+            raise RuntimeError("row-sharded step: a peer requested a row outside this shard")
+        cp.req_splits = req.tolist()
+        cp.serve_splits = np.diff(off, axis=1).tolist()
+        cp.nq = req.sum(1).tolist()
+        cp.ns = off[:, G].tolist()
+        cp.serve_rows = serve_rows
+        cp.max_nq, cp.max_ns = max(cp.nq + [1]), max(cp.ns + [1])
         return cp
 
     # ------------------------------------------------------------------ hot path
     def run_chunk(self, cp, lr, global_batch=None):
         """Runs the cp.nb steps; returns this rank's per-step loss shares (sum over ranks = global mean loss)."""
         D, dev = self.D, self.device
+        if self.world == 1:
+            return self._run_local(cp, lr, global_batch)
         losses = torch.zeros(cp.nb, dtype=torch.float32, device=dev)
-        recv_rows = torch.empty(max(cp.max_nq, 1), D, device=dev)
-        grad_slots = torch.empty(max(cp.max_nq, 1), D, device=dev)
-        grad_recv = torch.empty(max(cp.max_serve, 1), D, device=dev)
+        grad_slots = torch.empty(cp.max_nq, D, device=dev)
+        grad_recv = torch.empty(cp.max_ns, D, device=dev)
+        nL = self.nL
         for k in range(cp.nb):
             Bk = min(cp.batch, cp.N - k * cp.batch)
             gb = global_batch if global_batch is not None else Bk * self.world
-            nq, ns = cp.nq[k], cp.serve_rows[k].numel()
-            send = self.backend.gather_rows(self.I, cp.serve_rows[k]) if ns > 0 else grad_recv[:0]
-            rr = recv_rows[:nq]
-            dist.all_to_all_single(rr, send, output_split_sizes=cp.req_splits[k], input_split_sizes=cp.serve_splits[k],
-                                   group=self.group)
+            nq, ns = cp.nq[k], cp.ns[k]
+            send = self.backend.gather_rows(self.I, cp.serve_rows[k, :ns]) if ns > 0 else grad_recv[:0]
+            self._a2a(self.I_ext[nL:nL + nq], send, cp.req_splits[k], cp.serve_splits[k])
             gs = grad_slots[:nq]
-            self.backend.local_step(self.U, rr, cp.local, k, gb, lr, gs, losses[k:k + 1])
+            self.backend.local_step(self.U, self.I_ext, nL, cp.local, k, gb, lr, grad_slots, losses[k:k + 1])
             gr = grad_recv[:ns]
-            dist.all_to_all_single(gr, gs, output_split_sizes=cp.serve_splits[k], input_split_sizes=cp.req_splits[k],
-                                   group=self.group)
+            self._a2a(gr, gs, cp.serve_splits[k], cp.req_splits[k])
             if ns > 0:
-                self.backend.apply_sorted(self.I, cp.apply_rows[k], cp.apply_perm[k], gr, -lr)
+                self.backend.scatter_add(self.I, cp.serve_rows[k, :ns], gr, -lr)
         return losses
+
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        if self.loopback:
+            out.copy_(inp)          # the clone's answer has the same shape: a device copy stands in for the links
+            return
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+
+    def _run_local(self, cp, lr, global_batch):
+        """one rank: the single-GPU step stream (plans one chunk ahead on a side stream, one launch per step)"""
+        if hasattr(self.backend, "local_stream"):
+            return self.backend.local_stream(self, cp, lr, global_batch)
+        if global_batch is not None and global_batch != cp.batch:
+            # a caller that prices this rank's batch as a share of a larger global batch: gradients and loss scale with
+            # batch / global_batch — the same step at a learning rate scaled alike, its loss share scaled afterwards
+            scale = cp.batch / float(global_batch)
+        else:
+            scale = 1.0
+        if self._local is None:
+            from .hip_ops import PipelinedSgd
+            self._local = PipelinedSgd(chunk=max(cp.nb, 1), min_triplets=1)
+        losses = torch.empty(cp.nb, dtype=torch.float32, device=self.device)
+        handle = self._local.plan(self.U, [(self.I, cp.u, cp.p, cp.n)], cp.batch)
+        self._local.run(handle, 0, lr * scale, losses)
+        return losses * scale if scale != 1.0 else losses
 
     def global_losses(self, local_losses):
         out = local_losses.clone()
+        if self.loopback:
+            return out
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         return out
 
@@ -254,10 +310,11 @@ def bench_run(args, rank, world, dev):
     model.init_xavier(3407)
     g = torch.Generator(device=dev)
     g.manual_seed(3407 * 7919 + rank)
-    n_trip = (K + W) * B
-    u = torch.randint(0, model.U.shape[0], (n_trip,), generator=g, device=dev) * world + rank   # users this rank owns
-    p = torch.randint(0, args.items, (n_trip,), generator=g, device=dev)
-    n = torch.randint(1, args.items, (n_trip,), generator=g, device=dev)
+    spare = chunk if world == 1 else 0
+    n_trip = (K + W + spare) * B
+    u = (torch.randint(0, model.U.shape[0], (n_trip,), generator=g, device=dev) * world + rank).to(torch.int32)   # users this rank owns
+    p = torch.randint(0, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
+    n = torch.randint(1, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
 
     def run_range(first, count):
         out, done = [], 0
@@ -269,24 +326,54 @@ def bench_run(args, rank, world, dev):
             done += c
         return out
 
-    if W > 0:
-        run_range(0, W)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
     import gc
-    gc.disable()            # no cyclic-GC pass of the interpreter inside a sub-millisecond timed region (see bench.py)
-    t0 = time.perf_counter()
-    res = run_range(W, K)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    gc.enable()
+    if world == 1:
+        # one rank: every row is local and the step stream is the single-GPU one, consumed exactly as bench.py's N = 1 path
+        # consumes it — ONE stream of warm-up | timed steps | one spare chunk nobody trains on, so that the plan of the first
+        # timed chunk is built beside the warm-up and K batches' worth of plan builds run inside the timed region
+        from .hip_ops import PipelinedSgd
+        pipe = model._local = PipelinedSgd(chunk=chunk, min_triplets=1)
+        lw = torch.empty(max(W, 1), dtype=torch.float32, device=dev)
+        lt = torch.empty(K, dtype=torch.float32, device=dev)
+        gc.disable()
+        try:
+            handle = pipe.plan(model.U, [(model.I, u, p, n)], B, first_chunk=[W - W // 2, W // 2] if W > 0 else None)
+            if W > 0:
+                pipe.run_steps(handle, W, args.lr, lw)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.run_steps(handle, K, args.lr, lt)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+        finally:
+            gc.enable()
+        res = [lt]
+    else:
+        if W > 0:
+            run_range(0, W)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        gc.disable()            # no cyclic-GC pass of the interpreter inside a sub-millisecond timed region (see bench.py)
+        try:
+            t0 = time.perf_counter()
+            res = run_range(W, K)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+        finally:
+            gc.enable()
+    loop = None
+    if world == 1 and getattr(args, "loopback_world", 0) > 1:
+        loop = loopback_run(args, dev, chunk)
     # every rank started behind the same barrier; the job's time is the MAX over ranks of (own completion - start), which is
     # what a closing barrier would measure without that barrier's own launch + rendezvous latency (~0.1 ms of a 0.7 ms region)
     dist.barrier()
     torch.cuda.synchronize()
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    model.backend.check(model.U, model.I_ext)
     losses = model.global_losses(torch.cat(res))
     dt = float(dt.item())
     if rank != 0:
@@ -295,17 +382,56 @@ def bench_run(args, rank, world, dev):
     assert np.all(np.isfinite(lv)), "non-finite loss"
     value = world * K * B / dt
     lo = W * B
-    step_bytes, uu, ui = dedup_step_bytes(u[lo:], p[lo:], n[lo:], B, D)      # per GPU, duplicates counted once
+    step_bytes, uu, ui = dedup_step_bytes(u[lo:lo + K * B], p[lo:lo + K * B], n[lo:lo + K * B], B, D)   # per GPU, duplicates counted once
     link_mb = 2 * ui * (world - 1) / world * D * 4 / 1e6
-    return {"value": value, "ms_per_step": dt / K * 1e3, "loss_first": float(lv[0]), "loss_last": float(lv[-1]),
-            "parallelism": "row-sharded tables x%d, RCCL all-to-all of item rows + gradient rows" % world,
+    return {"value": value, "ms_per_step": dt / K * 1e3, "loss_first": float(lv[0]), "loss_last": float(lv[-1]), "loopback": loop,
+            "parallelism": "row-sharded tables x%d, RCCL all-to-all of item rows + gradient rows" % world
+                           if world > 1 else "row-sharded tables x1: every row local, the single-GPU step stream, no exchange",
             "sampling": "reference rule: negatives uniform over all items (src/models/BaseModel.py:168)",
             "plan_chunk_batches": chunk,
             "exchange": "per step and rank: ~%.1f MB of item rows in and as many gradient-row bytes out over xGMI "
-                        "(2 x all_to_all_single), index exchange once per chunk" % link_mb,
+                        "(2 x all_to_all_single), index exchange once per chunk (2 fixed-size all-to-alls)" % link_mb,
             "roofline": {"bound": "hbm", "achieved": step_bytes * K / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": step_bytes * K / dt / 1e9 / 8000.0, "traffic": None,
                          "kernel": "whole sharded step per GPU (exchange-bound for N > 1; see DESIGN.md 6)",
                          "algorithmic_bytes_per_step_per_gpu": step_bytes, "uniq_users_per_step": uu,
                          "uniq_items_per_step": ui,
                          "definition": "2*D*4*(unique users + unique items of the local batch) + 12*B, as at N=1"}}
+
+
+def loopback_run(args, dev, chunk):
+    """one GPU doing rank 0's work of a G-rank job with every exchange replaced by a device copy (ShardedBprmf(loopback=G)):
+    what the row-sharded step costs a rank BESIDE the links — routing + request lists + group plan per chunk, and per step
+    gather, step on local + received rows, scatter-add of the returned gradient rows"""
+    G, B, D, K, W = int(args.loopback_world), args.batch, args.emb, args.steps, args.warmup
+    model = ShardedBprmf(args.users, args.items, D, dev, loopback=G)
+    model.init_xavier(3407)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3407 * 31 + G)
+    n_trip = (K + W) * B
+    u = (torch.randint(0, model.U.shape[0], (n_trip,), generator=g, device=dev) * G).to(torch.int32)
+    p = torch.randint(0, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
+    n = torch.randint(1, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
+
+    def run_range(first, count):
+        done, t_plan = 0, 0.0
+        while done < count:
+            c = min(chunk, count - done)
+            lo = (first + done) * B
+            t0 = time.perf_counter()
+            cp = model.plan_chunk(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B)
+            torch.cuda.synchronize()
+            t_plan += time.perf_counter() - t0
+            model.run_chunk(cp, args.lr, global_batch=B * G)
+            done += c
+        return t_plan
+
+    run_range(0, max(W, 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t_plan = run_range(W, K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.backend.check(model.U, model.I_ext)
+    return {"virtual_world": G, "us_per_step": dt / K * 1e6, "plan_us_per_step": t_plan / K * 1e6,
+            "what": "rank 0's work of a %d-rank job on one GPU, exchanges replaced by device copies (no link traffic)" % G}
