@@ -51,3 +51,16 @@ for rep in range(2):
     t = timeit(lambda k: tabs.run_sgd_chain(plan_c, 0, NB, 0.05), 1) / NB
     print("chained step launch: %.2f us/step" % t)
 tabs.check_chain()
+
+# the group-plan step stream (round 3: no per-batch sort; one launch per step = triplets of batch k + tiles of batch k-1)
+u32, p32, n32 = u.to(torch.int32), p.to(torch.int32), n.to(torch.int32)
+garena = hip_ops.GroupArena(dev, NB * B, B, nU, nI)
+for rep in range(2):
+    t = timeit(lambda k: hip_ops.GroupPlan(u32, p32, n32, B, nU, nI, arena=garena).finish(), 1) / NB
+    print("group plan build: %.2f us/batch" % t)
+plan_g = hip_ops.GroupPlan(u32, p32, n32, B, nU, nI, arena=garena)
+tabs.run_sgd_group(plan_g, 0, 4, 0.05)
+for rep in range(2):
+    t = timeit(lambda k: tabs.run_sgd_group(plan_g, 0, NB, 0.05), 1) / NB
+    print("group step launch: %.2f us/step" % t)
+tabs.check_chain()

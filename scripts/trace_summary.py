@@ -24,7 +24,9 @@ def main():
     # the step stream: chained launches where the run used them, else the two-launch form.  The timed region of bench.py is
     # the FIRST long group of consecutive step kernels (groups are separated by host synchronisations: warm-up pieces before
     # it, the per-kernel timing passes after it)
-    name = "bprmf_chain_step" if sum("bprmf_chain_step" in r["Kernel_Name"] for r in rows) > 12 else "bprmf_user_phase"
+    count = lambda nm: sum(nm in r["Kernel_Name"] for r in rows)
+    name = "bprmf_group_step" if count("bprmf_group_step") > 12 else \
+        "bprmf_chain_step" if count("bprmf_chain_step") > 12 else "bprmf_user_phase"
     idx = [i for i, r in enumerate(rows) if name in r["Kernel_Name"]]
     groups, cur = [], []
     for i in idx:
