@@ -710,6 +710,20 @@ int32_t wr_embloss_grad(const float *user_tab, const float *item_tab, int32_t D,
                         const int32_t *oc_src, int64_t B, const float *sq3, float reg_weight, float *grad_user,
                         float *grad_item, void *stream);
 
+/* LightGCN.predict + its backward as ONE call (src/models/general/LightGCN.py:134-175; loss.backward() of
+ * src/helpers/BaseRunner.py:198): propagation of cat(user_tab, item_tab) through `n_layers` products with the chunked CSR
+ * adjacency (layer mean folded in; `levels` as for wr_spmm_csr_chunked_levels), BPR + reg_weight * EmbLoss -> loss[0] (shape
+ * (1,) like the reference's), and the dense gradient of that loss w.r.t. both tables -> grad [n_users + n_items, D] (user
+ * rows first).  The same kernels, in the same order, that the separate entry points run: same bits.  B <=
+ * wr_bprmf_plan_small_max_batch().  trusted_indices != 0: u / p / n were range-checked by the caller (no error flag is
+ * written); else err_flag[0] != 0 reports an id out of range.  No host round trip: capturable into a hipGraph. */
+int64_t wr_lightgcn_step_workspace_bytes(int64_t n_users, int64_t n_items, int32_t D, int64_t n_chunks, int64_t B);
+int32_t wr_lightgcn_step(const float *user_tab, const float *item_tab, int64_t n_users, int64_t n_items, int32_t D,
+                         int64_t n_chunks, const int64_t *chunk_ptr, const int32_t *chunk_row, const int32_t *col,
+                         const float *val, int32_t levels, int32_t n_layers, const int64_t *u, const int64_t *p, const int64_t *n,
+                         int64_t B, float reg_weight, int32_t trusted_indices, float *loss, float *grad, int32_t *err_flag,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,3 +271,29 @@ def test_fused_combine_equals_two_launch_product(D, L, N, monkeypatch):
     assert hasattr(crow, "_wr_fuse") and not crow._wr_fuse[1].any()      # the counters are back at zero
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_native_step_equals_the_call_by_call_step(g4):
+    """wr_lightgcn_step (predict + backward as ONE native call) runs the kernels of the call-by-call form in the same order on
+    the same kind of buffers: loss and both gradient tables bit for bit — on the golden graph and on an ml-1m-shaped one"""
+    from whisprrec_amd.lightgcn import LightGCN
+    dev = torch.device("cuda:0")
+    outs = []
+    for native in (True, False):
+        m = _model(g4, dev)
+        m.NATIVE_STEP = native
+        m.train()
+        loss = m.predict(_batch(g4, dev))
+        loss.backward()
+        outs.append((loss.detach().clone(), m.user_embedding.weight.grad.clone(), m.item_embedding.weight.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert abs(float(outs[0][0]) - float(g4["loss"][0])) / float(g4["loss"][0]) < TOL
+    assert rel_err(outs[0][1].cpu().numpy(), g4["gU"]) < TOL and rel_err(outs[0][2].cpu().numpy(), g4["gI"]) < TOL
+    # an id out of range raises like nn.Embedding
+    bad = _batch(g4, dev)
+    bad["pos_item"] = bad["pos_item"].clone()
+    bad["pos_item"][0] = 10 ** 6
+    m = _model(g4, dev)
+    with pytest.raises(IndexError):
+        m.predict(bad)

@@ -75,6 +75,9 @@ SIGNATURES = {
     "wr_bprmf_run_sgd_chain": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                        c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
                                        c_vp]),
+    "wr_lightgcn_step_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32, c_i64, c_i64]),
+    "wr_lightgcn_step": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                 c_i64, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_shard_route": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
                                c_vp, c_vp, c_vp, c_vp]),
     "wr_shard_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),

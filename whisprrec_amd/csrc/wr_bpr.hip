@@ -50,16 +50,20 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict
                                                           const int64_t *__restrict__ u, const int64_t *__restrict__ p,
                                                           const int64_t *__restrict__ n, int B, float *__restrict__ pos_out,
                                                           float *__restrict__ neg_out, float *__restrict__ coef_out,
-                                                          float *__restrict__ partials) {
+                                                          float *__restrict__ partials, int64_t n_users, int64_t n_items) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int b = blockIdx.x * TEAMS + threadIdx.x / T;
     float term_acc = 0.f;
     if (b < B) {
-        const Row<NV> ur = load_row<T, NV, FULL>(U, u[b], D, lane);
-        const Row<NV> pr = load_row<T, NV, FULL>(I, p[b], D, lane);
-        const Row<NV> nr = load_row<T, NV, FULL>(I, n[b], D, lane);
+        // ids clamped into the tables: an id out of range is the caller's to report (BatchPlan.validate: IndexError, as
+        // nn.Embedding raises); no kernel reads outside a table on the way there
+        const int64_t ub = min(max(u[b], (int64_t)0), n_users - 1), pb = min(max(p[b], (int64_t)0), n_items - 1),
+                      nb = min(max(n[b], (int64_t)0), n_items - 1);
+        const Row<NV> ur = load_row<T, NV, FULL>(U, ub, D, lane);
+        const Row<NV> pr = load_row<T, NV, FULL>(I, pb, D, lane);
+        const Row<NV> nr = load_row<T, NV, FULL>(I, nb, D, lane);
         const float sp = team_sum<T>(dot_partial<NV>(ur, pr));
         const float sn = team_sum<T>(dot_partial<NV>(ur, nr));
         float term, coef;
@@ -1423,7 +1427,7 @@ int32_t wr_bpr_fwd(const float *user_tab, int64_t n_users, const float *item_tab
     float *partials = reinterpret_cast<float *>(workspace);
 #define WR_CALL_FWD(T_, NV_, FULL_)                                                                               \
     hipLaunchKernelGGL((bpr_fwd_kernel<T_, NV_, FULL_>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, user_tab,  \
-                       item_tab, D, u, p, n, (int)B, pos_score, neg_score, coef, partials)
+                       item_tab, D, u, p, n, (int)B, pos_score, neg_score, coef, partials, n_users, n_items)
     WR_DISPATCH_D(D, WR_CALL_FWD);
 #undef WR_CALL_FWD
     WR_LAUNCH_CHECK("bpr_fwd_kernel");

@@ -734,14 +734,18 @@ __global__ __launch_bounds__(kBlock) void lightgcn_tail_fwd_kernel(const float *
                                                                     const float *__restrict__ U0, const float *__restrict__ I0,
                                                                     int D, const int64_t *__restrict__ u,
                                                                     const int64_t *__restrict__ p, const int64_t *__restrict__ n,
-                                                                    int B, float *__restrict__ partials, int n_blocks) {
+                                                                    int B, float *__restrict__ partials, int n_blocks,
+                                                                    int64_t n_users, int64_t n_items) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
     const int lane = threadIdx.x % T;
     const int b = blockIdx.x * TEAMS + threadIdx.x / T;
     float term = 0.f, su = 0.f, sp = 0.f, sn = 0.f;
     if (b < B) {
-        const int64_t ub = u[b], pb = p[b], nb = n[b];
+        // ids are clamped into the tables: an id out of range is REPORTED by the batch plan (nn.Embedding would raise), and
+        // no kernel ever reads outside a table on the way to that report
+        const int64_t ub = min(max(u[b], (int64_t)0), n_users - 1), pb = min(max(p[b], (int64_t)0), n_items - 1),
+                      nb = min(max(n[b], (int64_t)0), n_items - 1);
         const Row<NV> ua = load_row<T, NV, FULL>(Ua, ub, D, lane), pa = load_row<T, NV, FULL>(Ia, pb, D, lane),
                       na = load_row<T, NV, FULL>(Ia, nb, D, lane);
         const Row<NV> u0 = load_row<T, NV, FULL>(U0, ub, D, lane), p0 = load_row<T, NV, FULL>(I0, pb, D, lane),
@@ -1216,7 +1220,7 @@ int32_t wr_lightgcn_loss(const float *user_all, const float *item_all, const flo
     float *partials = reinterpret_cast<float *>(workspace);
 #define WR_CALL_LT(T_, NV_, FULL_)                                                                                         \
     hipLaunchKernelGGL((lightgcn_tail_fwd_kernel<T_, NV_, FULL_>), dim3(nblk), dim3(kBlock), 0, stream, user_all, item_all,  \
-                       user_ego, item_ego, D, u, p, n, (int)B, partials, nblk)
+                       user_ego, item_ego, D, u, p, n, (int)B, partials, nblk, n_users, n_items)
     WR_DISPATCH_D(D, WR_CALL_LT);
 #undef WR_CALL_LT
     WR_LAUNCH_CHECK("lightgcn_tail_fwd_kernel");

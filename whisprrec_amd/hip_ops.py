@@ -1937,6 +1937,28 @@ def axpy(y, x, alpha, overwrite=False):
     return y
 
 
+def lightgcn_step(user_tab, item_tab, csr, n_layers, u, p, n, reg_weight, trusted=False):
+    """LightGCN.predict + backward in one native call (wr_lightgcn_step): -> (loss (1,), gradient [n_users + n_items, D], error
+    flag tensor or None).  csr = (chunk_ptr, chunk_row, col, val) of the normalised adjacency on the device."""
+    cptr, crow, col, val = csr
+    u, p, n = _idx64(u, "u"), _idx64(p, "p"), _idx64(n, "n")
+    _req(user_tab, torch.float32, "user_tab", 2)
+    _req(item_tab, torch.float32, "item_tab", 2)
+    dev, D, B = user_tab.device, user_tab.shape[1], u.numel()
+    L = abi.lib()
+    nbytes = abi.check_size(L.wr_lightgcn_step_workspace_bytes(user_tab.shape[0], item_tab.shape[0], D, crow.numel(), B),
+                            "wr_lightgcn_step_workspace_bytes")
+    ws = workspace(dev, "lgcn_step").get(nbytes)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    grad = torch.empty(user_tab.shape[0] + item_tab.shape[0], D, dtype=torch.float32, device=dev)
+    err = None if trusted else torch.zeros(1, dtype=torch.int32, device=dev)
+    abi.check(L.wr_lightgcn_step(_p(user_tab), _p(item_tab), user_tab.shape[0], item_tab.shape[0], D, crow.numel(), _p(cptr),
+                                 _p(crow), _p(col), _p(val), spmm_levels_of(crow), int(n_layers), _p(u), _p(p), _p(n), B,
+                                 float(reg_weight), 1 if trusted else 0, _p(loss), _p(grad), _p(err), _p(ws), ws.numel(),
+                                 _stream()), "wr_lightgcn_step")
+    return loss, grad, err
+
+
 def embloss_grad(user_tab, item_tab, plan, k, sq3, reg_weight, grad_user, grad_item):
     """EmbLoss backward for batch k of a plan (wr_embloss_grad): adds into grad_user / grad_item, no host sync."""
     off = k * plan.batch_size

@@ -119,12 +119,17 @@ class _LightGcnLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, user_w, item_w, model, u, p, n):
         ctx.model, ctx.idx = model, (u, p, n)
+        ctx.grad = None
+        if model._native_step_ok(u):
+            # predict and its backward in ONE native call (wr_lightgcn_step): the gradient is ready when backward() asks
+            loss, ctx.grad = model._native_step(u, p, n)
+            return loss
         loss, ctx.saved = model._forward_loss(u, p, n)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        gE = ctx.model._backward(ctx.idx, ctx.saved)
+        gE = ctx.grad if ctx.grad is not None else ctx.model._backward(ctx.idx, ctx.saved)
         nU = ctx.model.n_users
         if not getattr(ctx.model, "_unit_root", False):     # HipRunner's captured step calls backward() with a root of ones
             gE.mul_(grad_out.reshape(-1)[0])                 # gE is this call's own buffer: one pass for both tables
@@ -244,6 +249,20 @@ def make_lightgcn(general_model_cls):
             hip_ops.embloss_grad(self.user_embedding.weight.data, self.item_embedding.weight.data, plan, 0, sq,
                                  self.reg_weight, gE[:nU], gE[nU:])
             return gE
+
+        NATIVE_STEP = True      # predict + backward as one native call where it applies (CSR kernels, B <= 4,096)
+
+        def _native_step_ok(self, u):
+            return self.NATIVE_STEP and u.is_cuda and not self._use_mfma and self.gcn_layers >= 1 and \
+                u.numel() <= int(hip_ops.abi.lib().wr_bprmf_plan_small_max_batch())
+
+        def _native_step(self, u, p, n):
+            trusted = bool(getattr(self, "_trusted_indices", False))
+            loss, grad, err = hip_ops.lightgcn_step(self.user_embedding.weight.data, self.item_embedding.weight.data, self._csr(),
+                                                    self.gcn_layers, u, p, n, self.reg_weight, trusted=trusted)
+            if err is not None and int(err.item()) != 0:      # nn.Embedding would have raised (one read-back per untrusted batch)
+                raise IndexError("index out of range in batch (user_id >= n_users or item id >= n_items)")
+            return loss, grad
 
         def _batch(self, feed_dict):
             dev = self.user_embedding.weight.device
