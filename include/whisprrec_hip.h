@@ -625,8 +625,8 @@ int32_t wr_spmm_csr_chunked(int64_t n_rows, int64_t n_chunks, const int64_t *chu
 /* Hybrid product for graphs with a dense head (popular items): the block (all users) x (head items) of the adjacency and
  * its transpose are kept DENSE and multiplied on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32), the rest stays on
  * the chunked CSR kernels.  Per 32-row output tile the dense block is stored as A_T[tile][k][32] (value of tile row r and
- * column k at [k][r], zeros included), k = 0..K_pad-1 with cols[k] the node id of column k (padding columns: any valid
- * node, zero values); rows[tile*32 + r] is the node id of tile row r (-1: padding row).  K_pad is cut into splits of
+ * column k at [k][r], zeros included), k = 0..K_pad-1 with cols[k] the node id of column k (padding columns: -1 —
+ * they contribute exact zeros whatever X holds — or any valid node with zero values); rows[tile*32 + r] is the node id of tile row r (-1: padding row).  K_pad is cut into splits of
  * k_per_split columns (a multiple of 64, at most 1024), one workgroup each; with one split the tile is written to Y (acc must be NULL:
  * such rows also have a CSR part, which adds the layer sum), with several the split tiles go to `partials`
  * (wr_spmm_dense_partials_bytes) and are added in split order, then Y[row] is written and acc[row] += it.  D in

@@ -297,3 +297,40 @@ def test_native_step_equals_the_call_by_call_step(g4):
     m = _model(g4, dev)
     with pytest.raises(IndexError):
         m.predict(bad)
+
+
+@pytest.mark.gpu
+def test_hybrid_product_small_graphs_and_padding_columns():
+    """HybridSpmm (--spmm_mfma 1): a graph with no more users than one K split holds stays on the CSR kernels; padding
+    columns of the dense tiles contribute exact zeros — a non-finite value in the last user's row must not reach head items
+    that user never rated"""
+    from whisprrec_amd import hip_ops
+    from whisprrec_amd.lightgcn import build_norm_adj_csr
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(3)
+
+    def graph(nU, nI, dens):
+        clicked = {uu: set(np.nonzero(rng.rand(nI) < dens)[0].tolist()) for uu in range(nU)}
+        clicked[nU - 1] = {nI - 1}                               # the last user rated one (tail) item only
+        return build_norm_adj_csr(nU, nI, clicked)
+
+    rp, col, val = graph(100, 256, 0.4)
+    assert not hip_ops.HybridSpmm(rp, col, val, 100, 256, dev).enabled
+    nU, nI, D = 300, 256, 64
+    rp, col, val = graph(nU, nI, 0.4)
+    hy = hip_ops.HybridSpmm(rp, col, val, nU, nI, dev)
+    assert hy.enabled
+    X = rng.standard_normal((nU + nI, D)).astype(np.float32)
+    ref = oracle_spmm(rp, col, val, X)
+    Y = hy.apply(torch.from_numpy(X).to(dev))
+    assert rel_err(Y.cpu().numpy(), ref) < TOL
+    X[nU - 1] = np.inf
+    Y = hy.apply(torch.from_numpy(X).to(dev)).cpu().numpy()
+    touched = np.zeros(nU + nI, bool)
+    touched[nU + nI - 1] = True                                  # the only neighbour of the last user
+    assert np.isfinite(Y[~touched]).all()
+
+
+def oracle_spmm(rp, col, val, X):
+    import oracle
+    return oracle.spmm_csr(rp, col, val, X)

@@ -193,7 +193,11 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
     }
     __syncthreads();
     // scan B: flag the shared occurrences and collect their sources (the list takes over the "seen" region); an id out of
-    // range was reported by scan A and its hashed bit is inside the bitmap anyway
+    // range was reported by scan A and its hashed bit is inside the bitmap anyway.
+    // (Measured on MI355X, 1M x 1M, B = 65,536, us of plan per batch — this form 2.76; the LDS operations of four ids issued
+    // together before any is waited for: 2.63; a wave per 64 consecutive positions, flag words from ballots by plain stores
+    // and one list atomic per wave: 3.82 — four 4-byte loads and ballots cost more than the 16-byte load's atomics.  Of the
+    // 2.7: launch + zeroing 0.6, first scan 0.55, second scan 1.25 (0.65 of it visits that find nothing), ordering 0.3.)
     auto several = [&](int row) -> bool {
         const unsigned h = (unsigned)row & mask;
         if ((h >> kGpRangeBits) != r) return false;

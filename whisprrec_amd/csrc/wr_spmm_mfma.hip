@@ -49,7 +49,8 @@ __device__ __forceinline__ void dense_load_stage(DenseStage<NJ> &st, const float
         }
         st.a[q] = At[(int64_t)kk * 32];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) st.b[q][j] = X[(int64_t)c * D + 32 * j + col];
+        // a padding column (cols[k] < 0) contributes exact zeros whatever X holds: 0 * inf would be a NaN in every row of the tile
+        for (int j = 0; j < NJ; ++j) st.b[q][j] = c >= 0 ? X[(int64_t)c * D + 32 * j + col] : 0.f;
     }
 }
 

@@ -1845,7 +1845,7 @@ class HybridSpmm:
     """Normalised-adjacency product with the dense head of the item popularity on the matrix cores (wr_spmm_mfma.hip) and
     the rest on the chunked CSR kernels.  Built once per graph from the symmetric bipartite CSR of LightGCN
     (reference src/models/general/LightGCN.py:54-121: nodes 0..n_users-1 are users, the others items).  Head = the items
-    rated by at least `min_density` of the users (at most `max_head`, in tiles of 32).  ``enabled`` is False when the graph
+    rated by at least `min_density` of the users (at most `max_head`, rounded up to a multiple of 64: two 32-row tiles).  ``enabled`` is False when the graph
     has no such items — then use spmm_csr_chunked."""
 
     def __init__(self, row_ptr, col, val, n_users, n_items, device, min_density=0.12, max_head=512, k_split=128):
@@ -1857,7 +1857,9 @@ class HybridSpmm:
         order = np.argsort(-deg[nU:], kind="stable")
         n_head = int((deg[nU:] >= min_density * nU).sum())
         H = min((n_head + 63) // 64 * 64, int(max_head) // 64 * 64, nI // 64 * 64)
-        self.enabled = H >= 64 and n_head >= 16
+        # the head-item tiles split K = all users over several workgroups: with no more users than one split holds there is
+        # nothing to split (and nothing to gain on so small a graph): CSR kernels only
+        self.enabled = H >= 64 and n_head >= 16 and nU > int(k_split)
         self.n_nodes, self.device = N, device
         if not self.enabled:
             return
@@ -1889,7 +1891,9 @@ class HybridSpmm:
         self.i_tiles = H // 32
         self.i_A = f32(Dk.reshape(K2, self.i_tiles, 32).transpose(1, 0, 2))            # [tile][k = user][32 head items]
         self.i_K = K2
-        self.i_cols = i32(np.minimum(np.arange(K2), nU - 1))                           # padding columns: zero values
+        i_cols = np.arange(K2)
+        i_cols[nU:] = -1                                                                # padding columns: masked in the kernel (exact zeros)
+        self.i_cols = i32(i_cols)
         self.i_rows = i32(head_nodes)
         # CSR part: everything but the (user, head item) entries and the head items' rows
         keep = ~(user_head | (pos_of[rows] >= 0))
