@@ -58,6 +58,19 @@ def bprmf_case(name, nU, nI, D, B, NB, opt="SGD", l2=0.0, zipf=0.0, lazy=False):
     elif opt == "SGD" and l2 == 0.0:
         tabs.run_sgd(plan, 0, min(NB, 4), 0.05)
         t = ev_time(lambda k: tabs.run_sgd(plan, 0, NB, 0.05), 1) / NB
+        # round 3: the step stream without a per-batch sort (group plans), where it applies
+        if zipf == 0.0 and 4096 <= B <= 81920 and min(nU, nI) >= 12 * B and tabs.group_supported():
+            t0 = time.perf_counter(); gplan = hip_ops.GroupPlan(u, p, n, B, nU, nI); torch.cuda.synchronize()
+            tg_plan = time.perf_counter() - t0
+            t0 = time.perf_counter(); gplan = hip_ops.GroupPlan(u, p, n, B, nU, nI); torch.cuda.synchronize()
+            tg_plan = time.perf_counter() - t0
+            if not gplan.overflow:
+                tabs.run_sgd_group(gplan, 0, min(NB, 4), 0.05)
+                tg = ev_time(lambda k: tabs.run_sgd_group(gplan, 0, NB, 0.05), 1) / NB
+                emit(case=name + " [group plan: no per-batch sort, one launch per step]", users=nU, items=nI, D=D, batch=B,
+                     optimizer=opt, step_us=tg * 1e6, plan_us_per_step=tg_plan / NB * 1e6, triplets_per_s_steps_only=B / tg,
+                     triplets_per_s_with_plan=B / (tg + tg_plan / NB), algorithmic_GBs=(6 * D * 4 + 12) * B / tg / 1e9)
+            del gplan
     elif opt == "SGD":
         tabs.step_sgd(plan, 0, 0.05, l2)
         t = ev_time(lambda k: tabs.step_sgd(plan, k, 0.05, l2), NB)

@@ -211,3 +211,30 @@ def test_expired_wait_is_raised_within_one_chunk(ops, g2):
         for w in words:
             w.zero_()
         torch.cuda.synchronize()
+
+
+def test_pipeline_falls_back_to_sorted_plans_on_skewed_ids(ops):
+    """PipelinedSgd starts with group plans where the SHAPE qualifies; ids it is not made for (a hot item row: the lists
+    overflow; a row with dozens of occurrences: `long_run`) send the stream to sorted plans — the overflowing chunk is
+    re-planned, later chunks are planned sorted from the start — and the result is the oracle's either way."""
+    dev = torch.device("cuda:0")
+    nU, nI, D, B, nb, lr = 120_000, 150_000, 64, 8192, 9, 0.05
+    for hot in (600, 60):                                             # 600 occurrences per batch: overflow; 60: long run
+        u, p, n = _epoch(50 + hot, nU, nI, nb * B)
+        for k in range(nb):
+            p[k * B:k * B + hot] = 4242
+        U, I = _tables(6, nU, nI, D)
+        pipe = ops.PipelinedSgd(chunk=3, min_triplets=1)
+        Ud, Id = T(U, dev), T(I, dev)
+        handle = pipe.plan(Ud, [(Id, T(u, dev), T(p, dev), T(n, dev))], B)
+        assert handle["group"]
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        pipe.run(handle, 0, lr, losses)
+        torch.cuda.synchronize()
+        handle["segs"][0]["tabs"].check_chain()
+        assert not handle["group"] and pipe.stats["group_fallbacks"] >= 1
+        Uo, Io = U.copy(), I.copy()
+        lo_ref = [oracle.bprmf_step_sgd(Uo, Io, u[k * B:(k + 1) * B], p[k * B:(k + 1) * B], n[k * B:(k + 1) * B], lr, 0.0)
+                  for k in range(nb)]
+        assert rel_err(losses.cpu().numpy(), np.asarray(lo_ref)) < TOL
+        assert rel_err(Ud.cpu().numpy(), Uo) < TOL and rel_err(Id.cpu().numpy(), Io) < TOL

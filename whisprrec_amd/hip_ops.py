@@ -1846,7 +1846,9 @@ class HybridSpmm:
     the rest on the chunked CSR kernels.  Built once per graph from the symmetric bipartite CSR of LightGCN
     (reference src/models/general/LightGCN.py:54-121: nodes 0..n_users-1 are users, the others items).  Head = the items
     rated by at least `min_density` of the users (at most `max_head`, rounded up to a multiple of 64: two 32-row tiles).  ``enabled`` is False when the graph
-    has no such items — then use spmm_csr_chunked."""
+    has no such items, no more users than one K split, or nothing but head items — then use spmm_csr_chunked.  The dense tiles
+    multiply their zero entries too: a non-finite value in a user row reaches every head item (0 x inf), which the CSR kernels
+    would not do; padding columns and rows are masked in the kernel."""
 
     def __init__(self, row_ptr, col, val, n_users, n_items, device, min_density=0.12, max_head=512, k_split=128):
         import numpy as np
@@ -1897,6 +1899,9 @@ class HybridSpmm:
         self.i_rows = i32(head_nodes)
         # CSR part: everything but the (user, head item) entries and the head items' rows
         keep = ~(user_head | (pos_of[rows] >= 0))
+        if not keep.any():
+            self.enabled = False        # every item is a head item: no CSR part to carry the user rows' layer sum
+            return
         r_deg = np.bincount(rows[keep], minlength=N)
         r_rp = np.zeros(N + 1, np.int64)
         np.cumsum(r_deg, out=r_rp[1:])
