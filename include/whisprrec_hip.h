@@ -546,13 +546,29 @@ int32_t wr_bprmf_run_sgd_lazy(float *user_tab, int64_t n_users, float *item_tab,
  *     src/models/sequential/SASRec.py:60,84,105-106; also the row-exchange primitive of the
  *     row-sharded multi-GPU step.
  * out[k,:] = tab[idx[k],:]                                        (gather; padding rows are read as stored)
- * grad[idx[k],:] += src[k,:] for idx[k] != padding_idx            (deterministic: sorted segmented sum)
+ * grad[idx[k],:] += src[k,:] for idx[k] != padding_idx            (deterministic: one writer per row, position order)
  * --------------------------------------------------------------------------------------------------- */
 int32_t wr_gather_rows(const float *tab, int64_t n_rows, int32_t D, const int64_t *idx, int64_t n, float *out,
                        void *stream);
 int64_t wr_scatter_add_workspace_bytes(int64_t n, int64_t n_rows);
 int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_t *idx, const float *src, int64_t n,
                             int64_t padding_idx, float alpha, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* The same scatter-add through a ROW PLAN instead of a sort of the positions (wr_scatter.hip; tables of any size, segments
+ * of at most 2^18 positions).  The plan is index work only, so a caller that knows the indices of several calls ahead — the
+ * row-sharded step knows the rows it will serve for a whole chunk of steps — builds ONE plan for all of them (segment s =
+ * idx[s * seg_stride .. + seg_len[s]), seg_len on the device or NULL = every segment full) and applies segment after
+ * segment: one launch per call.  Per segment: a flag bit per position (its row recurs in the segment) and the recurring
+ * positions ordered by (row, position); rows that occur once are added in place, runs are summed in position order (the
+ * bits of wr_scatter_add_rows).  plan[1] != 0 after a build: some range of rows held more than 8,192 recurring positions and
+ * is summed by brute force (slow, exact).  wr_scatter_add_rows itself takes this path for tables beyond 16,383 rows.
+ * wr_scatter_plan_words returns 0 when the plan does not apply (segments longer than 2^18 positions). */
+int64_t wr_scatter_plan_words(int64_t n_segments, int64_t seg_stride, int64_t n_rows);
+int32_t wr_scatter_plan_build(const int64_t *idx, int64_t n_segments, int64_t seg_stride, const int32_t *seg_len, int64_t n_rows,
+                              int64_t padding_idx, int32_t *plan, int64_t plan_words, void *stream);
+int32_t wr_scatter_add_planned(float *table, int64_t n_rows, int32_t D, const int64_t *idx, int64_t n_segments,
+                               int64_t seg_stride, int64_t segment, int64_t n, int64_t padding_idx, const float *src,
+                               float alpha, const int32_t *plan, int64_t plan_words, void *stream);
 
 /* tab[sorted_rows[q], :] += alpha * sum of src[perm[q'], :] over the run of equal sorted_rows (rows ascending; the
  * order was fixed when the exchange was planned, so the sum is reproducible).  Entries >= n_rows are skipped.

@@ -88,3 +88,65 @@ def test_scatter_add_both_sort_paths_match_oracle(n_rows, n, pad):
     again = hip_ops.scatter_add_rows(torch.zeros(n_rows, 64, device=dev), torch.from_numpy(idx).to(dev),
                                      torch.from_numpy(src).to(dev), padding_idx=pad)
     assert torch.equal(got, again)
+
+
+def _sorted_reference(table, idx, src, alpha, pad):
+    """the sorted path's bits: stable sort of the positions by row, runs summed in position order (wr_apply_rows_sorted)"""
+    from whisprrec_amd import abi
+    keys = torch.where((idx == pad) | (idx < 0) | (idx >= table.shape[0]), torch.full_like(idx, table.shape[0]), idx)
+    srt, perm = torch.sort(keys, stable=True)
+    srt, perm = srt.to(torch.int32), perm.to(torch.int32)
+    abi.check(abi.lib().wr_apply_rows_sorted(table.data_ptr(), table.shape[0], table.shape[1], srt.data_ptr(), perm.data_ptr(),
+                                             src.data_ptr(), idx.numel(), alpha, torch.cuda.current_stream().cuda_stream),
+              "wr_apply_rows_sorted")
+    return table
+
+
+@pytest.mark.parametrize("n_rows,n,D,hot", [(100_000, 45_056, 64, 0), (1_250_000, 114_688, 128, 0), (3_000_000, 200_000, 64, 0),
+                                            (50_000, 60_000, 64, 20_000), (20_000, 262_144, 32, 300), (1_000_000, 300_001, 64, 0),
+                                            (16_384, 17, 64, 0), (1_000_000, 45_056, 64, -12_000)])
+def test_scatter_add_large_tables_without_a_sort(n_rows, n, D, hot):
+    """tables beyond the LDS counting sort take the row plan of wr_scatter.hip (no sort of the positions): same BITS as the
+    sorted path — a hot row with more recurring positions than a range's list holds goes the brute-force way (hot = 20,000),
+    a long bin is ranked exactly (hot = 300), a range that draws more positions than its bucket holds scans the segment itself
+    (hot < 0), more than 2^18 positions still take the radix sort"""
+    import oracle
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(n_rows % 1000 + n)
+    idx = rng.randint(0, n_rows, n).astype(np.int64)
+    if hot > 0:
+        idx[rng.permutation(n)[:hot]] = n_rows // 3
+    elif hot < 0:                                                    # many positions in ONE range of rows, few of them shared: the
+        idx[rng.permutation(n)[:-hot]] = rng.randint(0, 40_000, -hot)    # range's bucket overflows, its list does not
+    idx[::11] = 0                                                    # the padding row
+    idx[5] = -1                                                      # out of range: skipped like padding
+    src = rng.standard_normal((n, D)).astype(np.float32)
+    base = rng.standard_normal((n_rows, D)).astype(np.float32) if n_rows <= 100_000 else None
+    t0 = torch.from_numpy(base).to(dev) if base is not None else torch.zeros(n_rows, D, device=dev)
+    idx_d, src_d = torch.from_numpy(idx).to(dev), torch.from_numpy(src).to(dev)
+    got = hip_ops.scatter_add_rows(t0.clone(), idx_d, src_d, padding_idx=0, alpha=-0.5)
+    ref_bits = _sorted_reference(t0.clone(), idx_d, src_d, -0.5, 0)
+    assert torch.equal(got, ref_bits)
+    if n_rows <= 100_000:
+        ref = base + (-0.5) * oracle.scatter_add_rows(n_rows, np.where(idx < 0, 0, idx), src, padding_idx=0)
+        assert rel_err(got.cpu().numpy(), ref) < TOL
+
+
+def test_scatter_plan_of_several_segments():
+    """one row plan for a chunk of calls (the row-sharded step's gradient rows): ragged segments, applied one by one"""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(5)
+    n_rows, D, S, stride = 125_000, 64, 5, 40_000
+    idx = torch.from_numpy(rng.randint(0, n_rows, (S, stride)).astype(np.int64)).to(dev)
+    lens = [40_000, 1, 0, 39_999, 12_345]
+    plan = hip_ops.ScatterPlan(idx, n_rows, seg_len=torch.tensor(lens, dtype=torch.int32, device=dev))
+    assert not plan.slow
+    tab, ref = torch.zeros(n_rows, D, device=dev), torch.zeros(n_rows, D, device=dev)
+    for s in range(S):
+        src = torch.from_numpy(rng.standard_normal((stride, D)).astype(np.float32)).to(dev)
+        plan.apply(tab, s, lens[s], src, alpha=0.25)
+        if lens[s]:
+            _sorted_reference(ref, idx[s, :lens[s]].contiguous(), src[:lens[s]].contiguous(), 0.25, -1)
+    assert torch.equal(tab, ref)

@@ -146,6 +146,10 @@ SIGNATURES = {
     "wr_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "wr_scatter_add_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "wr_scatter_add_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_i64, c_vp]),
+    "wr_scatter_plan_words": (c_i64, [c_i64, c_i64, c_i64]),
+    "wr_scatter_plan_build": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "wr_scatter_add_planned": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_f32, c_vp, c_i64,
+                                       c_vp]),
     "wr_apply_rows_sorted": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
     "wr_bprmf_shard_step": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32,
                                     c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -203,6 +203,11 @@ static inline int32_t check_table(const void *tab, int64_t n_rows, int32_t D, co
     return WR_OK;
 }
 
+// wr_scatter.hip: scatter-add through a row plan (no sort of the positions); 0 words = not applicable
+int64_t scatter_planned_words(int64_t n, int64_t n_rows);
+int32_t scatter_add_planned_once(float *tab, int64_t n_rows, int32_t D, const int64_t *idx, const float *src, int64_t n,
+                                 int64_t padding_idx, float alpha, int32_t *plan, hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------------ XCD placement
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, each XCD has its own L2).  This bijective
 // remap hands every XCD a CONTIGUOUS range of logical ids, so workgroups that read the same lines (one batch's index

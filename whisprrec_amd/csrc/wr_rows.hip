@@ -298,6 +298,7 @@ struct ScatterLayout {
     unsigned end_bit;
     int64_t total;
     bool small;                 // counting sort in LDS tiles (table of at most kSmallRows rows)
+    bool planned;               // row plan of wr_scatter.hip (no sort): larger tables, at most 2^18 positions
     int64_t n_tiles, comp_bytes, hist_bytes, base_bytes;
 };
 
@@ -314,6 +315,15 @@ static int32_t scatter_layout(int64_t n, int64_t n_rows, ScatterLayout &L) {
         L.temp = 0;
         L.end_bit = 0;
         L.total = L.comp_bytes + 2 * L.hist_bytes;
+        L.planned = false;
+        return WR_OK;
+    }
+    const int64_t pw = scatter_planned_words(n, n_rows);
+    L.planned = pw > 0;
+    if (L.planned) {
+        L.temp = 0;
+        L.end_bit = 0;
+        L.total = pw * 4;
         return WR_OK;
     }
     L.end_bit = 1;
@@ -910,6 +920,8 @@ int32_t wr_scatter_add_rows(float *grad, int64_t n_rows, int32_t D, const int64_
 #undef WR_CALL_ST
         WR_LAUNCH_CHECK("scatter_add_tiles_kernel");
         return WR_OK;
+    } else if (L.planned) {
+        return scatter_add_planned_once(grad, n_rows, D, idx, src, n, padding_idx, alpha, reinterpret_cast<int32_t *>(ws), stream);
     } else {
         uint32_t *keyA = reinterpret_cast<uint32_t *>(ws);
         keyB = reinterpret_cast<uint32_t *>(ws + L.arr_bytes);

@@ -666,6 +666,12 @@ class GroupPlan:
         self._finished = True
         return self
 
+    def finish_from(self, meta):
+        """the plan's first three words, read back by the caller together with words of its own"""
+        self.bad_index, self.overflow, self.long_run = bool(meta[0]), bool(meta[1]), bool(meta[2])
+        self._finished = True
+        return self
+
     def validate(self):
         """nn.Embedding raises IndexError for out-of-range ids; so does the plan."""
         self.finish()
@@ -1746,6 +1752,43 @@ def scatter_add_rows(grad, idx, src, padding_idx=-1, alpha=1.0):
     abi.check(L.wr_scatter_add_rows(_p(grad), grad.shape[0], grad.shape[1], _p(flat), _p(src2), flat.numel(),
                                     padding_idx, alpha, _p(ws), ws.numel(), _stream()), "wr_scatter_add_rows")
     return grad
+
+
+class ScatterPlan:
+    """Row plan of several scatter-adds whose indices are known ahead (wr_scatter.hip): idx [n_segments, seg_stride] int64
+    (segment s uses its first seg_len[s] positions; seg_len int32 on the device, or None = all).  ``apply(table, s, n, src,
+    alpha)`` is then ONE launch.  ``slow`` (read with the caller's own read-back of ``meta``): some range of rows was not
+    listed and is summed by brute force — exact, slow; callers with such ids stay with scatter_add_rows' sorted path."""
+
+    def __init__(self, idx, n_rows, seg_len=None, padding_idx=-1):
+        L = abi.lib()
+        _req(idx, torch.int64, "idx", 2)
+        self.idx = idx.contiguous()
+        self.n_segments, self.stride = self.idx.shape
+        self.n_rows, self.padding_idx = int(n_rows), int(padding_idx)
+        words = int(L.wr_scatter_plan_words(self.n_segments, self.stride, self.n_rows))
+        if words <= 0:
+            raise ValueError("row plan not applicable: segments of %d positions" % self.stride)
+        if seg_len is not None:
+            seg_len = _req(seg_len.contiguous(), torch.int32, "seg_len", 1)
+            assert seg_len.numel() == self.n_segments
+        self.buf = torch.empty(words, dtype=torch.int32, device=idx.device)
+        abi.check(L.wr_scatter_plan_build(_p(self.idx), self.n_segments, self.stride, _p(seg_len), self.n_rows,
+                                          self.padding_idx, _p(self.buf), words, _stream()), "wr_scatter_plan_build")
+        self.meta = self.buf[:4]
+
+    @property
+    def slow(self):
+        return bool(int(self.meta[1].item()) != 0)
+
+    def apply(self, table, segment, n, src, alpha=1.0):
+        _req(table, torch.float32, "table", 2)
+        _req(src, torch.float32, "src", 2)
+        assert table.shape[0] == self.n_rows and src.shape[0] >= n and src.shape[1] == table.shape[1] and src.is_contiguous()
+        abi.check(abi.lib().wr_scatter_add_planned(_p(table), self.n_rows, table.shape[1], _p(self.idx), self.n_segments,
+                                                   self.stride, int(segment), int(n), self.padding_idx, _p(src), float(alpha),
+                                                   _p(self.buf), self.buf.numel(), _stream()), "wr_scatter_add_planned")
+        return table
 
 
 # ----------------------------------------------------------------------------------------------- LightGCN pieces

@@ -73,18 +73,35 @@ class HipBackend:
 
     GROUP_MIN_ROWS_PER_TRIPLET = 12      # as hip_ops.PipelinedSgd: below this the lists of shared rows outgrow their capacity
 
-    def plan_local(self, vu, vp, vn, batch, n_user_rows, n_ext_rows, n_local_items, D=64):
+    def plan_local_begin(self, vu, vp, vn, batch, n_user_rows, n_ext_rows, n_local_items, D=64):
         """which rows recur inside a batch: the group plan (no sort) where the shard is large against the batch and rows are
-        whole 128-byte lines; otherwise — and for any chunk whose lists overflow (popularity-skewed ids) — the sorted batch
-        plan (wr_plan*.hip) and its two-kernel step with the hot-row path"""
+        whole 128-byte lines; otherwise — and for any chunk whose lists overflow (popularity-skewed ids, decided in
+        plan_local_end when the plan's words have been read) — the sorted batch plan (wr_plan*.hip) and its two-kernel step
+        with the hot-row path.  Nothing is read back here."""
         ops = self.ops
         tabs_ok = (int(D) * 4) % 128 == 0          # rows are whole 128-byte lines (torch allocations are 256-byte aligned)
         if tabs_ok and batch <= 131072 and min(n_user_rows, n_local_items) >= self.GROUP_MIN_ROWS_PER_TRIPLET * batch:
-            plan = ops.GroupPlan(vu, vp, vn, batch, n_user_rows, n_ext_rows)
+            return ops.GroupPlan(vu, vp, vn, batch, n_user_rows, n_ext_rows, defer=True)
+        return None
+
+    def plan_local_meta(self, plan):
+        """the three words plan_local_end wants to see (zeros when no group plan was started)"""
+        if plan is None:
+            return torch.zeros(3, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        return plan.buf[:3]
+
+    def plan_local_end(self, plan, meta, vu, vp, vn, batch, n_user_rows, n_ext_rows):
+        if plan is not None:
+            plan.finish_from(meta)
             plan.validate()
             if not plan.overflow and not plan.long_run:
                 return plan
-        return ops.BatchPlan(vu, vp, vn, batch, n_user_rows, n_ext_rows, validate=True)
+        return self.ops.BatchPlan(vu, vp, vn, batch, n_user_rows, n_ext_rows, validate=True)
+
+    def plan_local(self, vu, vp, vn, batch, n_user_rows, n_ext_rows, n_local_items, D=64):
+        plan = self.plan_local_begin(vu, vp, vn, batch, n_user_rows, n_ext_rows, n_local_items, D)
+        meta = plan.buf[:3].cpu().numpy() if plan is not None else None
+        return self.plan_local_end(plan, meta, vu, vp, vn, batch, n_user_rows, n_ext_rows)
 
     def gather_rows(self, tab, idx):
         return self.ops.gather_rows(tab, idx)
@@ -118,6 +135,15 @@ class HipBackend:
     def scatter_add(self, tab, idx, src, alpha):
         self.ops.scatter_add_rows(tab, idx, src, alpha=alpha)
 
+    def apply_plan(self, serve_rows, serve_len, n_rows):
+        """row plan of a chunk's gradient-row applications (wr_scatter.hip): which of the rows a step serves were requested
+        by several ranks, and in which order their gradient rows are summed — index work, once per chunk; None where it
+        does not apply (more than 2^18 rows served per step)"""
+        try:
+            return self.ops.ScatterPlan(serve_rows, n_rows, seg_len=serve_len)
+        except ValueError:
+            return None
+
     def check(self, U, I_ext):
         self.ops.BprmfTables(U, I_ext).check_chain()
 
@@ -128,6 +154,14 @@ def n_local_rows(n_rows, rank, world):
 
 class ChunkPlan:
     pass
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class ShardedBprmf:
@@ -154,6 +188,7 @@ class ShardedBprmf:
         self.I_ext = torch.zeros(max(self.nL, 1), self.D, device=device)       # grows by 2 B slot rows once the batch size is known
         self.I = self.I_ext[:self.nL]
         self._local = None               # world = 1: the single-GPU step stream
+        self._side = None                # index work of the next chunk runs on this stream beside the steps
 
     def _ensure_slots(self, batch):
         """the item buffer = the shard's rows + 2 * batch slot rows (a step receives at most that many distinct rows)"""
@@ -202,29 +237,69 @@ class ShardedBprmf:
     def plan_chunk(self, u, p, n, batch):
         """u, p, n: this rank's triplets of the chunk in batch order (global ids, every u % world == rank).
         All ranks must call this with the same number of steps."""
+        return self.plan_chunk_end(self.plan_chunk_begin(u, p, n, batch))
+
+    def plan_chunk_begin(self, u, p, n, batch):
+        """queues the chunk's index work — on a side stream when the tables live on a GPU, so that it runs beside the steps of
+        the chunk before (call it BEFORE run_chunk of that chunk, plan_chunk_end after); nothing is read back here"""
         G, dev = self.world, u.device
         N = u.numel()
         nb = (N + batch - 1) // batch
         cp = ChunkPlan()
         cp.nb, cp.batch, cp.N = nb, batch, N
+        cp.ready = None
         if G == 1:
             # every item row is local: the single-GPU step stream on this rank's tables
             cp.u, cp.p, cp.n = (t.to(torch.int32).contiguous() for t in (u, p, n))
             return cp
         self._ensure_slots(batch)
-        C = self.list_cap(batch)
-        vu, vp, vn, send_rows, send_cnt, err = self.backend.route(u, p, n, batch, G, self.rank, self.n_users, self.n_items,
-                                                                  self.M, self.nL, C)
-        # the request lists of the whole chunk: two fixed-size all-to-alls (per peer: nb lists of C rows, nb lengths)
-        recv_rows, recv_cnt = torch.empty_like(send_rows), torch.empty_like(send_cnt)
-        self._a2a(recv_cnt, send_cnt)
-        self._a2a(recv_rows, send_rows)
-        if self.loopback:
-            recv_rows.clamp_(max=max(self.nL - 1, 0))      # the clones' shards may be one row shorter than rank 0's
-        serve_rows, serve_off, err2 = self.backend.pack(recv_rows, recv_cnt, nb, G, C, self.nL)
-        cp.local = self.backend.plan_local(vu, vp, vn, batch, self.U.shape[0], self.I_ext.shape[0], self.nL, self.D)
-        # ONE read-back per chunk: the lengths (split sizes of the steps' row exchanges) and the error words
-        host = torch.cat([send_cnt.view(G, nb).t().reshape(-1), serve_off.reshape(-1), err, err2]).cpu().numpy()
+        C = cp.C = self.list_cap(batch)
+        side = None
+        if dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream(dev))      # the chunk before last is done with: its arrays may be reused
+        with torch.cuda.stream(side) if side is not None else _null():
+            vu, vp, vn, send_rows, send_cnt, err = self.backend.route(u, p, n, batch, G, self.rank, self.n_users, self.n_items,
+                                                                      self.M, self.nL, C)
+            # the request lists of the whole chunk: two fixed-size all-to-alls (per peer: nb lists of C rows, nb lengths)
+            recv_rows, recv_cnt = torch.empty_like(send_rows), torch.empty_like(send_cnt)
+            self._a2a(recv_cnt, send_cnt)
+            self._a2a(recv_rows, send_rows)
+            if self.loopback:
+                recv_rows.clamp_(max=max(self.nL - 1, 0))      # the clones' shards may be one row shorter than rank 0's
+            serve_rows, serve_off, err2 = self.backend.pack(recv_rows, recv_cnt, nb, G, C, self.nL)
+            cp.ids = (vu, vp, vn)
+            words = [send_cnt.view(G, nb).t().reshape(-1), serve_off.reshape(-1), err, err2]
+            cp.local = cp.apply = None
+            if hasattr(self.backend, "plan_local_begin"):
+                cp.local = self.backend.plan_local_begin(vu, vp, vn, batch, self.U.shape[0], self.I_ext.shape[0], self.nL, self.D)
+                words.append(self.backend.plan_local_meta(cp.local))
+                cp.apply = self.backend.apply_plan(serve_rows, serve_off[:, G].contiguous(), self.nL)
+                words.append(cp.apply.meta[1:2] if cp.apply is not None else err2[:0])
+            # ONE read-back per chunk: the lengths (split sizes of the steps' row exchanges) and the error words
+            cat = torch.cat(words)
+            if side is not None:
+                cp.host = torch.empty(cat.numel(), dtype=cat.dtype, pin_memory=True)
+                cp.host.copy_(cat, non_blocking=True)
+                cp.ready = torch.cuda.Event()
+                cp.ready.record(side)
+            else:
+                cp.host = cat
+            cp.serve_rows = serve_rows
+            cp.keep = (send_rows, send_cnt, recv_rows, recv_cnt, serve_off, cat)      # alive until the chunk is dropped
+        return cp
+
+    def plan_chunk_end(self, cp):
+        """waits for the chunk's index work, reads its lengths and error words; the calling stream is made to wait for it"""
+        if self.world == 1:
+            return cp
+        G, nb, C = self.world, cp.nb, cp.C
+        if cp.ready is not None:
+            cp.ready.synchronize()
+            torch.cuda.current_stream(self.device).wait_event(cp.ready)
+        host = cp.host.numpy()
         req = host[:nb * G].reshape(nb, G)                                        # rows I request from owner o at step k
         off = host[nb * G:nb * G + nb * (G + 1)].reshape(nb, G + 1)               # where requester s's rows start in my serve list
         e = host[nb * G + nb * (G + 1):]
@@ -234,11 +309,17 @@ class ShardedBprmf:
             raise RuntimeError("row-sharded step: a request list exceeds its capacity (%d rows per owner and step)" % C)
         if e[2] != 0:
             raise RuntimeError("row-sharded step: a peer requested a row outside this shard")
+        vu, vp, vn = cp.ids
+        if cp.local is not None or hasattr(self.backend, "plan_local_begin"):
+            cp.local = self.backend.plan_local_end(cp.local, e[3:6], vu, vp, vn, cp.batch, self.U.shape[0], self.I_ext.shape[0])
+            if cp.apply is not None and e[6] != 0:
+                cp.apply = None    # a few rows draw most of the requests: the per-step sorted scatter-add is made for that
+        else:
+            cp.local = self.backend.plan_local(vu, vp, vn, cp.batch, self.U.shape[0], self.I_ext.shape[0], self.nL, self.D)
         cp.req_splits = req.tolist()
         cp.serve_splits = np.diff(off, axis=1).tolist()
         cp.nq = req.sum(1).tolist()
         cp.ns = off[:, G].tolist()
-        cp.serve_rows = serve_rows
         cp.max_nq, cp.max_ns = max(cp.nq + [1]), max(cp.ns + [1])
         return cp
 
@@ -262,7 +343,9 @@ class ShardedBprmf:
             self.backend.local_step(self.U, self.I_ext, nL, cp.local, k, gb, lr, grad_slots, losses[k:k + 1])
             gr = grad_recv[:ns]
             self._a2a(gr, gs, cp.serve_splits[k], cp.req_splits[k])
-            if ns > 0:
+            if ns > 0 and cp.apply is not None:
+                cp.apply.apply(self.I, k, ns, gr, alpha=-lr)
+            elif ns > 0:
                 self.backend.scatter_add(self.I, cp.serve_rows[k, :ns], gr, -lr)
         return losses
 
@@ -317,13 +400,19 @@ def bench_run(args, rank, world, dev):
     n = torch.randint(1, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
 
     def run_range(first, count):
-        out, done = [], 0
+        # the index work of chunk c + 1 is queued (side stream) before the steps of chunk c and read back after them
+        spans, done = [], 0
         while done < count:
             c = min(chunk, count - done)
-            lo = (first + done) * B
-            cp = model.plan_chunk(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B)
-            out.append(model.run_chunk(cp, args.lr, global_batch=B * world))
+            spans.append(((first + done) * B, c))
             done += c
+        begin = lambda sp: model.plan_chunk_begin(u[sp[0]:sp[0] + sp[1] * B], p[sp[0]:sp[0] + sp[1] * B],
+                                                  n[sp[0]:sp[0] + sp[1] * B], B)
+        out, nxt = [], begin(spans[0])
+        for i in range(len(spans)):
+            cp = model.plan_chunk_end(nxt)
+            nxt = begin(spans[i + 1]) if i + 1 < len(spans) else None
+            out.append(model.run_chunk(cp, args.lr, global_batch=B * world))
         return out
 
     import gc
@@ -414,17 +503,23 @@ def loopback_run(args, dev, chunk):
     n = torch.randint(1, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
 
     def run_range(first, count):
-        done, t_plan = 0, 0.0
+        # as bench_run: the index work of chunk c + 1 is queued before the steps of chunk c and read back after them;
+        # t_wait = host time spent waiting for index work (what the side stream did not hide)
+        spans, done, t_wait = [], 0, 0.0
         while done < count:
             c = min(chunk, count - done)
-            lo = (first + done) * B
-            t0 = time.perf_counter()
-            cp = model.plan_chunk(u[lo:lo + c * B], p[lo:lo + c * B], n[lo:lo + c * B], B)
-            torch.cuda.synchronize()
-            t_plan += time.perf_counter() - t0
-            model.run_chunk(cp, args.lr, global_batch=B * G)
+            spans.append(((first + done) * B, c))
             done += c
-        return t_plan
+        begin = lambda sp: model.plan_chunk_begin(u[sp[0]:sp[0] + sp[1] * B], p[sp[0]:sp[0] + sp[1] * B],
+                                                  n[sp[0]:sp[0] + sp[1] * B], B)
+        nxt = begin(spans[0])
+        for i in range(len(spans)):
+            t0 = time.perf_counter()
+            cp = model.plan_chunk_end(nxt)
+            t_wait += time.perf_counter() - t0
+            nxt = begin(spans[i + 1]) if i + 1 < len(spans) else None
+            model.run_chunk(cp, args.lr, global_batch=B * G)
+        return t_wait
 
     run_range(0, max(W, 1))
     torch.cuda.synchronize()
@@ -433,5 +528,5 @@ def loopback_run(args, dev, chunk):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     model.backend.check(model.U, model.I_ext)
-    return {"virtual_world": G, "us_per_step": dt / K * 1e6, "plan_us_per_step": t_plan / K * 1e6,
+    return {"virtual_world": G, "us_per_step": dt / K * 1e6, "plan_wait_us_per_step": t_plan / K * 1e6,
             "what": "rank 0's work of a %d-rank job on one GPU, exchanges replaced by device copies (no link traffic)" % G}
