@@ -345,6 +345,10 @@ int64_t wr_group_plan_words(int64_t n_triplets, int64_t batch_size, int64_t n_us
  * user list sources, item list rows, item list sources [nb][R][cap]; total words; cap of a user segment; cap of an item
  * segment} — for tools and tests */
 int32_t wr_group_plan_layout(int64_t n_triplets, int64_t batch_size, int64_t n_users, int64_t n_items, int64_t *out);
+/* int64 index columns (the reference's batch layout, src/models/BaseModel.py:96-127) -> the int32 columns the group plan
+ * and its step read; ids outside [0, 2^31) become -1 (reported by the plan as out of range). */
+int32_t wr_narrow_ids_i64(const int64_t *u, const int64_t *p, const int64_t *n, int32_t *u32, int32_t *p32, int32_t *n32,
+                          int64_t count, void *stream);
 int32_t wr_group_plan_build(const int32_t *u, const int32_t *p, const int32_t *n, int64_t n_triplets, int64_t batch_size,
                             int64_t n_users, int64_t n_items, int32_t *plan, int64_t plan_words, void *stream);
 int64_t wr_bprmf_group_workspace_bytes(int64_t batch_size, int32_t D);

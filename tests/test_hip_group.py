@@ -238,3 +238,37 @@ def test_pipeline_falls_back_to_sorted_plans_on_skewed_ids(ops):
                   for k in range(nb)]
         assert rel_err(losses.cpu().numpy(), np.asarray(lo_ref)) < TOL
         assert rel_err(Ud.cpu().numpy(), Uo) < TOL and rel_err(Id.cpu().numpy(), Io) < TOL
+
+
+def test_int64_epoch_columns_take_the_group_path(ops):
+    """the reference hands int64 index columns (src/models/BaseModel.py:96-127): the step stream narrows them chunk by chunk
+    on the plan stream and runs on group plans all the same — same tables as with int32 columns, bit for bit; an id beyond
+    2^31 is an IndexError (as nn.Embedding's), not an alias of a valid row"""
+    dev = torch.device("cuda:0")
+    nU, nI, D, B, nb, lr = 130_000, 160_000, 64, 8192, 7, 0.05
+    u, p, n = _epoch(77, nU, nI, nb * B - 1000)
+    U, I = _tables(8, nU, nI, D)
+    out = {}
+    for dt in (torch.int32, torch.int64):
+        pipe = ops.PipelinedSgd(chunk=3, min_triplets=1)
+        Ud, Id = T(U, dev), T(I, dev)
+        handle = pipe.plan(Ud, [(Id, T(u, dev).to(dt), T(p, dev).to(dt), T(n, dev).to(dt))], B)
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        pipe.run(handle, 0, lr, losses)
+        torch.cuda.synchronize()
+        assert pipe.stats["group_calls"] > 0 and pipe.stats["group_fallbacks"] == 0
+        out[dt] = (Ud, Id, losses)
+    for a, b in zip(out[torch.int32], out[torch.int64]):
+        assert torch.equal(a, b)
+    Uo, Io = U.copy(), I.copy()
+    lo_ref = [oracle.bprmf_step_sgd(Uo, Io, u[k * B:(k + 1) * B], p[k * B:(k + 1) * B], n[k * B:(k + 1) * B], lr, 0.0)
+              for k in range(nb)]
+    assert rel_err(out[torch.int64][2].cpu().numpy(), np.asarray(lo_ref)) < TOL
+    assert rel_err(out[torch.int64][0].cpu().numpy(), Uo) < TOL and rel_err(out[torch.int64][1].cpu().numpy(), Io) < TOL
+    bad = T(p, dev).to(torch.int64)
+    bad[5] = (1 << 32) + 5
+    pipe = ops.PipelinedSgd(chunk=3, min_triplets=1)
+    with pytest.raises(IndexError):
+        handle = pipe.plan(T(U, dev), [(T(I, dev), T(u, dev).to(torch.int64), bad, T(n, dev).to(torch.int64))], B)
+        pipe.run(handle, 0, lr, torch.empty(nb, dtype=torch.float32, device=dev))
+        torch.cuda.synchronize()

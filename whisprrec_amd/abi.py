@@ -85,6 +85,7 @@ SIGNATURES = {
                                           c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "wr_group_plan_words": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "wr_group_plan_layout": (c_i32, [c_i64, c_i64, c_i64, c_i64, c_vp]),
+    "wr_narrow_ids_i64": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wr_group_plan_build": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "wr_bprmf_group_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "wr_bprmf_group_sync_words": (c_i64, [c_i64]),

@@ -322,6 +322,20 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
     if (threadIdx.x == 0) (item ? L.icnt : L.ucnt)[(int64_t)b * R + r] = m;
 }
 
+// The reference hands int64 index columns (src/models/BaseModel.py:96-127); the group plan and its step read int32.  One
+// pass narrows a range of the three columns; an id outside [0, 2^31) becomes -1 (the plan then reports it as out of range
+// instead of letting it alias a valid row).
+__global__ __launch_bounds__(kBlock) void narrow_ids_kernel(const int64_t *__restrict__ u, const int64_t *__restrict__ p,
+                                                             const int64_t *__restrict__ n, int *__restrict__ u32,
+                                                             int *__restrict__ p32, int *__restrict__ n32, int64_t cnt) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cnt) return;
+    const int64_t a = u[i], b = p[i], c = n[i];
+    u32[i] = (a >= 0 && a < (int64_t(1) << 31)) ? (int)a : -1;
+    p32[i] = (b >= 0 && b < (int64_t(1) << 31)) ? (int)b : -1;
+    n32[i] = (c >= 0 && c < (int64_t(1) << 31)) ? (int)c : -1;
+}
+
 // ----------------------------------------------------------------------------------------------- step
 constexpr int kGsTile = 32;      // list entries per tile: ~16 runs, one per team of the workgroup
 constexpr int kGsAhead = 8;      // entries staged beyond the tile
@@ -871,6 +885,17 @@ int32_t wr_group_plan_layout(int64_t n_triplets, int64_t batch_size, int64_t n_u
     const int64_t v[16] = {L.nb, L.fw, L.R_u, L.R_i, (int64_t)L.mask_u, (int64_t)L.mask_i, L.flags, L.ucnt, L.icnt, L.ul_row,
                            L.ul_src, L.il_row, L.il_src, L.total, L.cap_u, L.cap_i};
     for (int i = 0; i < 16; ++i) out[i] = v[i];
+    return WR_OK;
+}
+
+int32_t wr_narrow_ids_i64(const int64_t *u, const int64_t *p, const int64_t *n, int32_t *u32, int32_t *p32, int32_t *n32,
+                          int64_t count, void *stream_) {
+    WR_REQUIRE(u && p && n && u32 && p32 && n32, WR_E_NULL, "index arrays must not be NULL");
+    WR_REQUIRE(count >= 0 && count < (int64_t(1) << 40), WR_E_SHAPE, "count out of range");
+    if (count == 0) return WR_OK;
+    hipLaunchKernelGGL(narrow_ids_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream_), u, p, n, u32, p32, n32, count);
+    WR_LAUNCH_CHECK("narrow_ids_kernel");
     return WR_OK;
 }
 

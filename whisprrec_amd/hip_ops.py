@@ -1270,7 +1270,7 @@ class PipelinedSgd:
             all(sg["tabs"].chain_supported() for sg in segs if sg["tabs"] is not None)
         min_rows = min([U.shape[0]] + [s[0].shape[0] for s in live])
         use_group = self.group and runner is None and len(live) == 1 and first >= 2 and \
-            self.GROUP_MIN_BATCH <= B <= 131072 and u_all.dtype == torch.int32 and \
+            self.GROUP_MIN_BATCH <= B <= 131072 and u_all.dtype in (torch.int32, torch.int64) and \
             min_rows >= self.GROUP_MIN_ROWS_PER_TRIPLET * B and \
             all(sg["tabs"].group_supported() for sg in segs if sg["tabs"] is not None)
         garenas = self._garena_pair(U.device, B, first, U.shape[0], n_items) if use_group else None
@@ -1281,6 +1281,10 @@ class PipelinedSgd:
         h = {"segs": segs, "B": B, "u": u_all, "p": p_all, "n": n_all, "nb": first, "n_users": U.shape[0], "n_items": n_items,
              "at": 0, "tag": 0, "next": None, "cur": None, "map": None, "arenas": arenas, "pos": 0,
              "group": use_group, "garenas": garenas, "device": U.device,
+             # int64 columns (the reference's batch layout): the group plan and its step read int32 shadows, narrowed chunk by
+             # chunk on the plan stream (12 B per triplet, once per epoch; the sorted plans read the int64 columns themselves)
+             "ids32": [torch.empty(u_all.numel(), dtype=torch.int32, device=U.device) for _ in range(3)]
+                      if use_group and u_all.dtype == torch.int64 else None,
              "chain": use_chain, "prep": prep, "runner": runner, "inline": bool(self.inline_plan),
              "lead": [int(c) for c in (first_chunk if isinstance(first_chunk, (list, tuple)) else [first_chunk or 0]) if c]}
         self.plan_stream.wait_stream(main)   # the index tensors are ready
@@ -1306,7 +1310,12 @@ class PipelinedSgd:
             if h["prep"] is not None:
                 h["prep"].fill(lo, hi)       # this chunk's rows: shuffle + negatives, on the plan stream, before its plan
             if h["group"]:
-                plan = self.ops.GroupPlan(h["u"][lo:hi], h["p"][lo:hi], h["n"][lo:hi], B, h["n_users"], h["n_items"],
+                cols = (h["u"], h["p"], h["n"])
+                if h["ids32"] is not None:
+                    abi.check(abi.lib().wr_narrow_ids_i64(*[_p(c[lo:hi]) for c in cols], *[_p(c[lo:hi]) for c in h["ids32"]],
+                                                          hi - lo, _stream()), "wr_narrow_ids_i64")
+                    cols = h["ids32"]
+                plan = self.ops.GroupPlan(cols[0][lo:hi], cols[1][lo:hi], cols[2][lo:hi], B, h["n_users"], h["n_items"],
                                           arena=h["garenas"][h["tag"]], defer=True)
                 h["tag"] ^= 1
                 h["next"] = (first, plan)
