@@ -14,7 +14,7 @@ timeout -k 10 400 python3 bench.py > "$OUT/bench_n1.log" 2>&1                   
 tail -n 1 "$OUT/bench_n1.log" > "$OUT/bench_n1.json"
 echo "bench done" >> "$OUT/progress.log"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-epoch > "$OUT/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-epoch --no-adam > "$OUT/trace.log" 2>&1
 echo "trace done" >> "$OUT/progress.log"
 cd "$R"
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -n 1)" "$OUT/kernel_stats.csv"
