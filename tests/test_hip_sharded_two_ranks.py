@@ -64,8 +64,20 @@ def _worker(rank, world, port, payload, out_dir):
         m = ShardedBprmf(nU, nI, D, dev)                       # HipBackend: the C-ABI library
         m.load_full(torch.from_numpy(payload["U"]), torch.from_numpy(payload["I"]))
         u, p, n = (torch.from_numpy(payload[k][rank]).to(dev) for k in ("u", "p", "n"))
-        cp = m.plan_chunk(u, p, n, B)
-        losses = m.global_losses(m.run_chunk(cp, lr, global_batch=B * world))
+        if payload.get("pipelined"):
+            # bench_run's order: chunk c + 1's index work goes to the side stream BEFORE chunk c's steps are queued
+            cuts = [0, (steps // 3) * B, (2 * steps // 3) * B, steps * B]
+            spans = [(cuts[i], cuts[i + 1]) for i in range(3) if cuts[i + 1] > cuts[i]]
+            begin = lambda sp: m.plan_chunk_begin(u[sp[0]:sp[1]], p[sp[0]:sp[1]], n[sp[0]:sp[1]], B)
+            nxt, parts = begin(spans[0]), []
+            for i in range(len(spans)):
+                cp = m.plan_chunk_end(nxt)
+                nxt = begin(spans[i + 1]) if i + 1 < len(spans) else None
+                parts.append(m.run_chunk(cp, lr, global_batch=B * world))
+            losses = m.global_losses(torch.cat(parts))
+        else:
+            cp = m.plan_chunk(u, p, n, B)
+            losses = m.global_losses(m.run_chunk(cp, lr, global_batch=B * world))
         Uf, If = m.gather_full()
         torch.cuda.synchronize()
         if rank == 0:
@@ -74,10 +86,13 @@ def _worker(rank, world, port, payload, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nU,nI,D,B", [(2, 5001, 3001, 64, 2048), (3, 997, 401, 32, 512)])
-def test_sharded_step_two_ranks_one_gpu_equals_single_process(tmp_path, world, nU, nI, D, B):
+@pytest.mark.parametrize("world,nU,nI,D,B,pipelined", [(2, 5001, 3001, 64, 2048, False), (3, 997, 401, 32, 512, False),
+                                                       (2, 300_001, 260_001, 64, 4096, True)])
+def test_sharded_step_two_ranks_one_gpu_equals_single_process(tmp_path, world, nU, nI, D, B, pipelined):
+    """pipelined: three chunks, every chunk's index work queued on the side stream before the steps of the chunk before
+    (bench_run's order); shards large enough for group plans"""
     rng = np.random.RandomState(world)
-    steps, lr = 3, 0.2
+    steps, lr = (6 if pipelined else 3), 0.2
     U = (rng.standard_normal((nU, D)) * 0.5).astype(np.float32)
     I = (rng.standard_normal((nI, D)) * 0.5).astype(np.float32)
     per_rank = {"u": [], "p": [], "n": []}
@@ -86,7 +101,7 @@ def test_sharded_step_two_ranks_one_gpu_equals_single_process(tmp_path, world, n
         per_rank["u"].append(rng.choice(owned, size=steps * B).astype(np.int64))
         per_rank["p"].append(rng.randint(0, nI, steps * B).astype(np.int64))      # cross-rank duplicates of item rows
         per_rank["n"].append(rng.randint(1, nI, steps * B).astype(np.int64))
-    payload = dict(shape=(nU, nI, D, B, steps, lr), U=U, I=I, **per_rank)
+    payload = dict(shape=(nU, nI, D, B, steps, lr), U=U, I=I, pipelined=pipelined, **per_rank)
     mp.spawn(_worker, args=(world, _free_port(), payload, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     Uo, Io = U.copy(), I.copy()

@@ -108,8 +108,21 @@ def _worker(rank, world, port, payload, out_dir):
         m.load_full(torch.from_numpy(payload["U"]), torch.from_numpy(payload["I"]))
         u, p, n = (torch.from_numpy(payload[k][rank]) for k in ("u", "p", "n"))
         assert bool((u % world == rank).all())
-        cp = m.plan_chunk(u, p, n, B)
-        losses = m.global_losses(m.run_chunk(cp, lr, global_batch=B * world))
+        if payload.get("pipelined"):
+            # bench_run's order: the index work of chunk c + 1 (its two index all-to-alls included) is queued BEFORE the steps
+            # of chunk c and read back after them — the same sequence of collectives on every rank
+            cut = (steps // 2) * B
+            spans = [(0, cut), (cut, steps * B)]
+            nxt, parts = m.plan_chunk_begin(u[:cut], p[:cut], n[:cut], B), []
+            for i, (lo, hi) in enumerate(spans):
+                cp = m.plan_chunk_end(nxt)
+                nxt = m.plan_chunk_begin(u[spans[i + 1][0]:spans[i + 1][1]], p[spans[i + 1][0]:spans[i + 1][1]],
+                                         n[spans[i + 1][0]:spans[i + 1][1]], B) if i + 1 < len(spans) else None
+                parts.append(m.run_chunk(cp, lr, global_batch=B * world))
+            losses = m.global_losses(torch.cat(parts))
+        else:
+            cp = m.plan_chunk(u, p, n, B)
+            losses = m.global_losses(m.run_chunk(cp, lr, global_batch=B * world))
         Uf, If = m.gather_full()
         if rank == 0:
             np.savez(os.path.join(out_dir, "out.npz"), U=Uf.numpy(), I=If.numpy(), loss=losses.numpy())
@@ -125,10 +138,10 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world,nI", [(2, 61), (3, 40)])
-def test_sharded_step_equals_single_process(tmp_path, world, nI):
+@pytest.mark.parametrize("world,nI,pipelined", [(2, 61, False), (3, 40, False), (2, 53, True)])
+def test_sharded_step_equals_single_process(tmp_path, world, nI, pipelined):
     rng = np.random.RandomState(world)
-    nU, D, B, steps, lr = 47, 16, 64, 3, 0.2
+    nU, D, B, steps, lr = 47, 16, 64, 4 if pipelined else 3, 0.2
     U = (rng.standard_normal((nU, D)) * 0.5).astype(np.float32)
     I = (rng.standard_normal((nI, D)) * 0.5).astype(np.float32)
     per_rank = {"u": [], "p": [], "n": []}
@@ -137,7 +150,7 @@ def test_sharded_step_equals_single_process(tmp_path, world, nI):
         per_rank["u"].append(rng.choice(owned, size=steps * B).astype(np.int64))
         per_rank["p"].append(rng.randint(0, nI, steps * B).astype(np.int64))   # few items: heavy cross-rank duplicates
         per_rank["n"].append(rng.randint(1, nI, steps * B).astype(np.int64))
-    payload = dict(shape=(nU, nI, D, B, steps, lr), U=U, I=I, **per_rank)
+    payload = dict(shape=(nU, nI, D, B, steps, lr), U=U, I=I, pipelined=pipelined, **per_rank)
     mp.spawn(_worker, args=(world, _free_port(), payload, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     # single-process reference: the global batch of step k is the union of the ranks' k-th batches
