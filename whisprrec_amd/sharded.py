@@ -393,27 +393,11 @@ def bench_run(args, rank, world, dev):
     model.init_xavier(3407)
     g = torch.Generator(device=dev)
     g.manual_seed(3407 * 7919 + rank)
-    spare = chunk if world == 1 else 0
+    spare = chunk         # one chunk behind the timed steps that is planned inside the region and never trained (see below)
     n_trip = (K + W + spare) * B
     u = (torch.randint(0, model.U.shape[0], (n_trip,), generator=g, device=dev) * world + rank).to(torch.int32)   # users this rank owns
     p = torch.randint(0, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
     n = torch.randint(1, args.items, (n_trip,), generator=g, device=dev, dtype=torch.int32)
-
-    def run_range(first, count):
-        # the index work of chunk c + 1 is queued (side stream) before the steps of chunk c and read back after them
-        spans, done = [], 0
-        while done < count:
-            c = min(chunk, count - done)
-            spans.append(((first + done) * B, c))
-            done += c
-        begin = lambda sp: model.plan_chunk_begin(u[sp[0]:sp[0] + sp[1] * B], p[sp[0]:sp[0] + sp[1] * B],
-                                                  n[sp[0]:sp[0] + sp[1] * B], B)
-        out, nxt = [], begin(spans[0])
-        for i in range(len(spans)):
-            cp = model.plan_chunk_end(nxt)
-            nxt = begin(spans[i + 1]) if i + 1 < len(spans) else None
-            out.append(model.run_chunk(cp, args.lr, global_batch=B * world))
-        return out
 
     import gc
     if world == 1:
@@ -440,19 +424,42 @@ def bench_run(args, rank, world, dev):
             gc.enable()
         res = [lt]
     else:
-        if W > 0:
-            run_range(0, W)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+        # ONE sequence of chunks — warm-up | timed steps | one spare chunk nobody trains on — through the chunk pipeline: the
+        # index work of chunk c + 1 is queued (side stream) before the steps of chunk c and read back after them.  The plan of
+        # the first timed chunk is therefore built beside the warm-up, and the timed region carries the index work of the
+        # chunks behind its own (the last of them the spare one): K steps' worth of planning for K trained steps, the N = 1
+        # arrangement.
+        def cut(first, count):
+            spans, done = [], 0
+            while done < count:
+                c = min(chunk, count - done)
+                spans.append(((first + done) * B, c))
+                done += c
+            return spans
+        warm, timed, tail = cut(0, W), cut(W, K), cut(W + K, spare)
+        spans = warm + timed + tail
+        begin = lambda sp: model.plan_chunk_begin(u[sp[0]:sp[0] + sp[1] * B], p[sp[0]:sp[0] + sp[1] * B],
+                                                  n[sp[0]:sp[0] + sp[1] * B], B)
+        res, nxt = [], begin(spans[0])
+        t0 = t1 = None
         gc.disable()            # no cyclic-GC pass of the interpreter inside a sub-millisecond timed region (see bench.py)
         try:
-            t0 = time.perf_counter()
-            res = run_range(W, K)
-            torch.cuda.synchronize()
+            for i in range(len(warm) + len(timed)):
+                if i == len(warm):
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                cp = model.plan_chunk_end(nxt)
+                nxt = begin(spans[i + 1])
+                out = model.run_chunk(cp, args.lr, global_batch=B * world)
+                if i >= len(warm):
+                    res.append(out)
+            torch.cuda.synchronize()      # the steps and the spare chunk's index work
             t1 = time.perf_counter()
         finally:
             gc.enable()
+        model.plan_chunk_end(nxt)         # all ranks consume the spare chunk's read-back alike; it is not trained
     loop = None
     if world == 1 and getattr(args, "loopback_world", 0) > 1:
         loop = loopback_run(args, dev, chunk)
