@@ -422,8 +422,10 @@ def adam_extra(args, hip_ops, U, I, u, p, n, dev):
     st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(U, I), "Adam", 1e-3, 0.0)
     pipe = hip_ops.PipelinedSgd(chunk=64, min_triplets=1)
     nn = total * B
-    handle = pipe.plan(U, [(I, u[:nn], p[:nn], n[:nn])], B, first_chunk=[warm],
-                       runner=lambda plan, first, count, out: st.run(plan, first, count, out))
+    def runner(plan, first, count, out):
+        return st.run(plan, first, count, out)
+    runner.wants_chain_marks = not getattr(args, "no_chain", False)   # folded Adam steps as one launch per step
+    handle = pipe.plan(U, [(I, u[:nn], p[:nn], n[:nn])], B, first_chunk=[warm], runner=runner)
     lw = torch.empty(max(warm, 1), dtype=torch.float32, device=dev)
     lt = torch.empty(steps, dtype=torch.float32, device=dev)
     if warm > 0:
@@ -437,8 +439,9 @@ def adam_extra(args, hip_ops, U, I, u, p, n, dev):
     torch.cuda.synchronize()
     return {"metric": "BPR training triplets/sec, Adam (lr 1e-3, l2 0)", "value": steps * B / dt, "unit": "triplets/s",
             "us_per_step": dt / steps * 1e6, "steps": steps, "warmup": warm,
-            "how": "exact lazy rows, catch-up %s; plan builds inside the timed region" %
-                   ("folded into the step kernels' row loads" if st._folds(handle["cur"][1]) else "in a pass of its own"),
+            "how": "exact lazy rows, catch-up %s%s; plan builds inside the timed region" %
+                   ("folded into the step kernels' row loads" if st._folds(handle["cur"][1]) else "in a pass of its own",
+                    ", one launch per step (%d chained calls)" % st.chain_calls if st.chain_calls else ""),
             "loss_last": float(lt[-1])}
 
 

@@ -491,6 +491,21 @@ int32_t wr_bprmf_run_adam_folded(float *user_tab, int64_t n_users, float *item_t
                                  int64_t adam_step0, float lr, const float *consts, int64_t n_consts, float l2, float beta1,
                                  float beta2, float eps, float *loss_out, const wr_hot_runs *hot, void *workspace,
                                  int64_t workspace_bytes, void *stream);
+/* wr_bprmf_run_adam_folded as ONE launch per step (round 3): the item phase of step k-1 — the rows that recur in batch k-1:
+ * weights, both moments and the step stamp, stored write-through — rides in the launch of step k's user phase; the user runs
+ * of batch k that read such a row wait for it inside the launch (the chained launch of wr_bprmf_run_sgd_chain, same marks:
+ * tdef / def_q / def_count_host / def_cap / def_limit from wr_bprmf_plan_overlap_deferred).  No batch of the range may have
+ * hot rows (the caller takes wr_bprmf_run_adam_folded for such plans).  workspace: 2 x wr_bprmf_step_workspace_bytes; sync:
+ * wr_bprmf_chain_sync_words(n_batches).  Same bits as the dense optimizer. */
+int32_t wr_bprmf_run_adam_folded_chain(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                                       float *m_u, float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i,
+                                       const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                                       const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                                       int64_t n_batches, int64_t adam_step0, float lr, const float *consts, int64_t n_consts,
+                                       float l2, float beta1, float beta2, float eps, float *loss_out, const int32_t *tdef,
+                                       const int32_t *def_q, const int32_t *def_count_host, int64_t def_cap, int64_t def_limit,
+                                       void *workspace, int64_t workspace_bytes, int32_t *sync, int64_t sync_words,
+                                       void *stream);
 /* wr_bprmf_run_adam_lazy with a bounded lag: before every step a rotating window of ceil(rows / max_lag) consecutive rows
  * of each table is brought to the previous step (wr_adam_catchup_all on the sub-range), so that no row ever misses more
  * than max_lag steps and the replays of a batch's rows stay short (small batches on big tables: a geometric tail of

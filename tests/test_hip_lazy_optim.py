@@ -155,3 +155,39 @@ def test_native_multi_batch_loop_equals_per_batch_calls(name, l2, zipf):
         outs.append((losses, Ua, Ia))
     for o in outs[1:]:
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
+
+
+@pytest.mark.parametrize("l2,D,nI", [(0.0, 64, 200_000), (1e-3, 64, 60_000), (0.0, 128, 120_000), (0.0, 32, 25_000)])
+def test_chained_folded_adam_equals_two_launch_folded_adam_bitwise(l2, D, nI):
+    """round 3: the folded Adam step as ONE launch per step (wr_bprmf_run_adam_folded_chain: the item phase of step k-1 —
+    weights, both moments and the step stamp of the rows that recur, stored write-through — inside the launch of step k's
+    user phase) leaves the bits of the two-launch folded step in tables, moments and stamps (losses to 1e-6: a few more
+    partials); cut into calls of several lengths; nI = 25,000: most steps defer more runs than the list holds and go out as two launches in between"""
+    from whisprrec_amd import hip_ops
+    dev = torch.device("cuda:0")
+    nU, B, nb, lr = 70_000, 8192, 9, 1e-2
+    g = torch.Generator(device=dev); g.manual_seed(11 + D)
+    U0 = torch.randn(nU, D, generator=g, device=dev) * 0.1
+    I0 = torch.randn(nI, D, generator=g, device=dev) * 0.1
+    N = nb * B - 1000                                                 # short last batch
+    u = torch.randint(0, nU, (N,), generator=g, device=dev, dtype=torch.int32)
+    p = torch.randint(0, nI, (N,), generator=g, device=dev, dtype=torch.int32)
+    n = torch.randint(1, nI, (N,), generator=g, device=dev, dtype=torch.int32)
+    arena = hip_ops.PlanArena(dev, N, B, overlap_items=nI)
+    plan = hip_ops.BatchPlan(u, p, n, B, nU, nI, arena=arena, overlap=True)
+    assert plan.overlap is not None and plan.hot is None
+    out = []
+    for chain in (False, True):
+        st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(U0.clone(), I0.clone()), "Adam", lr, l2, fold=True)
+        st.chain = chain
+        losses = torch.empty(nb, dtype=torch.float32, device=dev)
+        for first, count in ((0, 4), (4, 1), (5, 4)):                 # a call of one step is never chained
+            st.run(plan, first, count, losses[first:first + count])
+        torch.cuda.synchronize()
+        st.tabs.check_chain()
+        assert (st.chain_calls > 0) == chain
+        out.append((st.tabs.U, st.tabs.I, st.m_u, st.v_u, st.m_i, st.v_i, st.last_u, st.last_i, losses))
+    for a, b in zip(out[0][:-1], out[1][:-1]):
+        assert torch.equal(a, b)
+    # a chained step's loss is summed over a few more partials (one per chunk of deferred runs): same terms, another grouping
+    assert torch.allclose(out[0][-1], out[1][-1], rtol=1e-6, atol=0)

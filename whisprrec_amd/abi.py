@@ -129,6 +129,10 @@ SIGNATURES = {
     "wr_bprmf_run_adam_folded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                          c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                          c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "wr_bprmf_run_adam_folded_chain": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_i64, c_f32, c_f32,
+                                               c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                               c_vp]),
     "wr_bprmf_run_sgd_lazy_bounded": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp,
                                               c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_vp, c_vp, c_i64,
                                               c_vp, c_vp, c_i64, c_vp]),

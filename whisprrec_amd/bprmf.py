@@ -306,8 +306,10 @@ def make_bprmf(general_model_cls):
             # switched to load-balanced buckets after the first overflow), steps issued by the fused optimizer
             if getattr(self, "_pipe", None) is None:
                 self._pipe = hip_ops.PipelinedSgd(chunk)
-            handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size, prep=prep,
-                                     runner=lambda plan, first, count, out: opt.run_batches(tabs, plan, first, count, out))
+            def runner(plan, first, count, out):
+                return opt.run_batches(tabs, plan, first, count, out)
+            runner.wants_chain_marks = optimizer == "Adam"      # folded Adam steps go out as one launch per step
+            handle = self._pipe.plan(tabs.U, [(tabs.I, u, p, n)], batch_size, prep=prep, runner=runner)
             self._pipe.run(handle, 0, lr, losses)
             return losses
 

@@ -230,8 +230,9 @@ __device__ __forceinline__ void adam_replay_balanced(Row<NV> &w, Row<NV> &m, Row
     }
 }
 
-// step t on a row whose caught-up weights and moments are in registers
-template <int T, int NV, bool FULL>
+// step t on a row whose caught-up weights and moments are in registers (WT: the three rows and the row's step stamp are
+// stored write-through — the chained launch hands them to other workgroups of the same launch)
+template <int T, int NV, bool FULL, bool WT = false>
 __device__ __forceinline__ void adam_finish_row_regs(float *__restrict__ W, float *__restrict__ M, float *__restrict__ V,
                                                      int *__restrict__ last, int row, int D, int lane, Row<NV> w, Row<NV> m,
                                                      Row<NV> v, const Row<NV> &g, const AdamArgs &a) {
@@ -242,10 +243,17 @@ __device__ __forceinline__ void adam_finish_row_regs(float *__restrict__ W, floa
         adam_elem(w.v[k].z, m.v[k].z, v.v[k].z, g.v[k].z, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
         adam_elem(w.v[k].w, m.v[k].w, v.v[k].w, g.v[k].w, a.l2, a.b1, a.b2, a.eps, a.step_size, a.inv_bc2_sqrt);
     }
-    store_row<T, NV, FULL>(W, row, D, lane, w);
-    store_row<T, NV, FULL>(M, row, D, lane, m);
-    store_row<T, NV, FULL>(V, row, D, lane, v);
-    if (lane == 0) last[row] = a.t;
+    if constexpr (WT) {
+        store_row_wt<T, NV, FULL>(W, row, D, lane, w);
+        store_row_wt<T, NV, FULL>(M, row, D, lane, m);
+        store_row_wt<T, NV, FULL>(V, row, D, lane, v);
+        if (lane == 0) store_i32_wt(last + row, a.t);
+    } else {
+        store_row<T, NV, FULL>(W, row, D, lane, w);
+        store_row<T, NV, FULL>(M, row, D, lane, m);
+        store_row<T, NV, FULL>(V, row, D, lane, v);
+        if (lane == 0) last[row] = a.t;
+    }
 }
 
 template <int T, int NV, bool FULL>
@@ -774,7 +782,7 @@ __device__ __forceinline__ void item_tile_block(float *__restrict__ I, int D, co
                                                 float *__restrict__ loss_out, const unsigned long long *__restrict__ hot_loss,
                                                 const AdamArgs &ad, int vblock) {
     static_assert(TILE <= kBlock && TILE >= 32, "item tile");
-    static_assert(!WT || MODE == 0, "write-through rows: plain SGD only");
+    static_assert(!WT || MODE == 0 || MODE == 4, "write-through rows: plain SGD and the folded Adam step");
     __shared__ float scratch[kBlock / 64];
     __shared__ int heads[TILE];
     // entries staged beyond the tile: with a hot-run list every run that starts in the tile is in LDS up to the entry that
@@ -857,7 +865,7 @@ __device__ __forceinline__ void item_tile_block(float *__restrict__ I, int D, co
                     }
                 }
                 if constexpr (MODE == 4)
-                    adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
+                    adam_finish_row_regs<T, NV, FULL, WT>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
                 else
                     finish_item_row<T, NV, FULL, MODE, WT>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             } else {
@@ -929,7 +937,7 @@ __device__ __forceinline__ void item_tile_block(float *__restrict__ I, int D, co
                     ++j;
                 }
                 if constexpr (MODE == 4)
-                    adam_finish_row_regs<T, NV, FULL>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
+                    adam_finish_row_regs<T, NV, FULL, WT>(I, ad.mI, ad.vI, ad.lastI, r, D, lane, ir, imv.m, imv.v, g, ad);
                 else
                     finish_item_row<T, NV, FULL, MODE, WT>(I, gradI, stampI, step_id, r, D, lane, lr, l2, ir, g, ad);
             }
@@ -1215,8 +1223,10 @@ constexpr int kChainShardStride = 16;   // words between shards (64 B)
 constexpr int kChainStepWords = kChainShards * kChainShardStride;
 constexpr unsigned kChainSpinLimit = 1u << 22;   // polls of ~0.25 us (s_sleep 8): about a second
 
-template <int T, int NV, bool FULL, int TILE>
-__global__ __launch_bounds__(kBlock, NV == 1 ? WR_USER_WAVES : 1) void bprmf_chain_step(
+// MODE 0: plain SGD.  MODE 4: the folded Adam step — the tiles apply step t-1 (`ad_prev`), the user runs step t (`ad`); a row
+// handed over is its weights, both moments and its step stamp.
+template <int T, int NV, bool FULL, int TILE, int MODE = 0>
+__global__ __launch_bounds__(kBlock, NV == 1 ? (MODE == 4 ? WR_ADAM_WAVES : WR_USER_WAVES) : 1) void bprmf_chain_step(
     float *__restrict__ U, float *I, int D,
     // item tiles: batch k-1
     const int *__restrict__ oc_item, const int *__restrict__ oc_src, int B2_prev, const float *__restrict__ Z_prev,
@@ -1226,16 +1236,16 @@ __global__ __launch_bounds__(kBlock, NV == 1 ? WR_USER_WAVES : 1) void bprmf_cha
     const int *__restrict__ tu, const int *__restrict__ tp, const int *__restrict__ tn, int B, float lr,
     float *__restrict__ Z, float *__restrict__ partials, float denom, const int *__restrict__ dmask,
     const int *__restrict__ dlist, int n_def, int n_user_blocks, int def_at, int n_def_blocks,
-    unsigned *__restrict__ done, unsigned *__restrict__ timeout) {
+    unsigned *__restrict__ done, unsigned *__restrict__ timeout, float l2 = 0.f, AdamArgs ad_prev = AdamArgs{},
+    AdamArgs ad = AdamArgs{}) {
     __shared__ float scratch[kBlock / 64];
     constexpr int TEAMS = kBlock / T;
-    const AdamArgs ad{};
     // blockIdx.x -> kind: [user 0 .. item_at) [item tiles] [user item_at .. def_at) [deferred] [user def_at .. n_user_blocks)
     int b = (int)blockIdx.x;
     if (b >= item_at && b < item_at + n_item_blocks) {
         if (!(WR_CHAIN_DBG & 8))
-        item_tile_block<T, NV, FULL, 0, false, !(WR_CHAIN_DBG & 2), TILE>(I, D, oc_item, oc_src, B2_prev, Z_prev, lr, 0.f, nullptr, nullptr, 0,
-                                                           partials_prev, n_partials_prev, denom_prev, loss_prev, nullptr, ad,
+        item_tile_block<T, NV, FULL, MODE, false, !(WR_CHAIN_DBG & 2), TILE>(I, D, oc_item, oc_src, B2_prev, Z_prev, lr, l2, nullptr, nullptr, 0,
+                                                           partials_prev, n_partials_prev, denom_prev, loss_prev, nullptr, ad_prev,
                                                            b - item_at);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its write-through stores have left
         __syncthreads();
@@ -1270,7 +1280,7 @@ __global__ __launch_bounds__(kBlock, NV == 1 ? WR_USER_WAVES : 1) void bprmf_cha
         __syncthreads();
         const int n_chunks = (n_def + TEAMS - 1) / TEAMS;
         for (int c = b - def_at; c < n_chunks; c += n_def_blocks) {
-            user_phase_block<T, NV, FULL, 0, 1, false, 2>(U, I, D, tu, tp, tn, B, lr, 0.f, Z, partials + n_user_blocks + c, nullptr,
+            user_phase_block<T, NV, FULL, MODE, 1, false, 2>(U, I, D, tu, tp, tn, B, lr, l2, Z, partials + n_user_blocks + c, nullptr,
                                                           nullptr, nullptr, nullptr, 0, denom, ad, nullptr, dlist, n_def, nullptr,
                                                           c, scratch);
             __syncthreads();   // the next chunk reuses the loss scratch
@@ -1278,7 +1288,7 @@ __global__ __launch_bounds__(kBlock, NV == 1 ? WR_USER_WAVES : 1) void bprmf_cha
         return;
     }
     if (b >= def_at) b -= n_def_blocks;
-    user_phase_block<T, NV, FULL, 0, 1, false, 1>(U, I, D, tu, tp, tn, B, lr, 0.f, Z, partials + b, nullptr, nullptr, nullptr,
+    user_phase_block<T, NV, FULL, MODE, 1, false, 1>(U, I, D, tu, tp, tn, B, lr, l2, Z, partials + b, nullptr, nullptr, nullptr,
                                                   nullptr, 0, denom, ad, dmask, nullptr, 0, nullptr, b, scratch);
 }
 
@@ -1298,13 +1308,14 @@ static inline bool chain_shape_ok(const float *U, const float *I, int32_t D) {
     return (D * 4) % 128 == 0 && (reinterpret_cast<uintptr_t>(U) & 127u) == 0 && (reinterpret_cast<uintptr_t>(I) & 127u) == 0;
 }
 
-template <int T, int NV, bool FULL>
+template <int T, int NV, bool FULL, int MODE = 0>
 static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *tu, const int32_t *tp, const int32_t *tn,
                                   const int32_t *oc_item, const int32_t *oc_src, int64_t n_triplets, int64_t batch_size,
                                   int64_t first_batch, int64_t n_batches, float lr, float *loss_out, const int32_t *tdef,
                                   const int32_t *def_q, const int32_t *def_count_host, int64_t def_cap, int64_t def_limit,
                                   void *workspace, uint32_t *sync, int64_t sync_words, hipStream_t stream,
-                                  void *const *events, int n_cu) {
+                                  void *const *events, int n_cu, float l2 = 0.f, AdamArgs ad_base = AdamArgs{},
+                                  int64_t adam_step0 = 0) {
     const int64_t ws_one = step_ws_bytes(batch_size, D);
     // Forward progress: only the deferred workgroups ever wait, and nothing they wait for waits itself — so it is enough
     // that they never fill the device: at most half a workgroup per CU of THIS device (a CPX partition or a smaller agent
@@ -1316,7 +1327,15 @@ static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *
     const int64_t dwords = (batch_size + 31) / 32;
     constexpr int TEAMS = kBlock / T;
     const dim3 block(kBlock);
-    const AdamArgs ad{};
+    // MODE 4: the optimizer step of batch k of this call is adam_step0 + k; its constants are those of wr_adam_consts
+    auto ad_of = [&](int64_t k) {
+        AdamArgs a = ad_base;
+        if (MODE == 4) {
+            a.t = (int)(adam_step0 + k);
+            adam_step_consts(adam_step0 + k, lr, a.b1, a.b2, &a.step_size, &a.inv_bc2_sqrt);
+        }
+        return a;
+    };
     // sync: one sharded counter per step of this call, zeroed here (the block starts the allocation and is a multiple of 16
     // bytes); the sticky timeout word is the first of the buffer's last four words
     const int64_t n_ctr = n_batches * kChainStepWords;
@@ -1328,15 +1347,16 @@ static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *
     auto launch_item = [&](const Pending &q, hipEvent_t e0, hipEvent_t e1) -> int32_t {
         const StepWs &w = w2[q.k & 1];
         const dim3 gridB((unsigned)((2 * q.Bk + kItemTile - 1) / kItemTile));
+        const AdamArgs ad = ad_of(q.k);
         if (e0 != nullptr || e1 != nullptr)
-            hipExtLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, 0, false>), gridB, block, 0, stream, e0, e1, 0, I, D,
-                                  oc_item + 2 * q.off, oc_src + 2 * q.off, (int)(2 * q.Bk), w.Z, lr, 0.f, (float *)nullptr,
+            hipExtLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, MODE, false>), gridB, block, 0, stream, e0, e1, 0, I, D,
+                                  oc_item + 2 * q.off, oc_src + 2 * q.off, (int)(2 * q.Bk), w.Z, lr, l2, (float *)nullptr,
                                   (int *)nullptr, 0, w.partials, q.n_partials, (float)q.Bk, loss_out ? loss_out + q.k : nullptr, 0,
                                   (const unsigned long long *)nullptr, (int)gridB.x, (const int *)nullptr, (const int *)nullptr,
                                   (float *)nullptr, ad);
         else
-            hipLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, 0, false>), gridB, block, 0, stream, I, D, oc_item + 2 * q.off,
-                               oc_src + 2 * q.off, (int)(2 * q.Bk), w.Z, lr, 0.f, (float *)nullptr, (int *)nullptr, 0, w.partials,
+            hipLaunchKernelGGL((bprmf_item_phase<T, NV, FULL, MODE, false>), gridB, block, 0, stream, I, D, oc_item + 2 * q.off,
+                               oc_src + 2 * q.off, (int)(2 * q.Bk), w.Z, lr, l2, (float *)nullptr, (int *)nullptr, 0, w.partials,
                                q.n_partials, (float)q.Bk, loss_out ? loss_out + q.k : nullptr, 0,
                                (const unsigned long long *)nullptr, (int)gridB.x, (const int *)nullptr, (const int *)nullptr,
                                (float *)nullptr, ad);
@@ -1363,12 +1383,12 @@ static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *
     U, I, D, oc_item + 2 * pend.off, oc_src + 2 * pend.off, (int)(2 * pend.Bk), wp.Z, wp.partials, pend.n_partials,           \
         (float)pend.Bk, loss_out ? loss_out + pend.k : (float *)nullptr, nI, item_at, tu + off, tp + off, tn + off, (int)Bk, lr,  \
         w.Z, w.partials, (float)Bk, tdef + b * dwords, def_q + b * def_cap, n_def, nA, def_at, nD, sync + k * kChainStepWords,   \
-        timeout
+        timeout, l2, ad_of(pend.k), ad_of(k)
             if (e0 != nullptr || e1 != nullptr)
-                hipExtLaunchKernelGGL((bprmf_chain_step<T, NV, FULL, WR_CHAIN_TILE>), grid, block, 0, stream, e0, e1, 0,
+                hipExtLaunchKernelGGL((bprmf_chain_step<T, NV, FULL, WR_CHAIN_TILE, MODE>), grid, block, 0, stream, e0, e1, 0,
                                       WR_CHAIN_ARGS);
             else
-                hipLaunchKernelGGL((bprmf_chain_step<T, NV, FULL, WR_CHAIN_TILE>), grid, block, 0, stream, WR_CHAIN_ARGS);
+                hipLaunchKernelGGL((bprmf_chain_step<T, NV, FULL, WR_CHAIN_TILE, MODE>), grid, block, 0, stream, WR_CHAIN_ARGS);
 #undef WR_CHAIN_ARGS
             WR_LAUNCH_CHECK("bprmf_chain_step");
             pend = Pending{true, off, Bk, nA + n_chunks, k};
@@ -1378,14 +1398,15 @@ static int32_t launch_chain_steps(float *U, float *I, int32_t D, const int32_t *
                 if (rc != WR_OK) return rc;
             }
             hipEvent_t e0 = ev(k, 0), e1 = ev(k, 1);
+            const AdamArgs ad = ad_of(k);
 #define WR_PLAIN_ARGS                                                                                                       \
-    U, I, D, tu + off, tp + off, tn + off, (int)Bk, lr, 0.f, w.Z, w.partials, (float *)nullptr, (int *)nullptr,              \
+    U, I, D, tu + off, tp + off, tn + off, (int)Bk, lr, l2, w.Z, w.partials, (float *)nullptr, (int *)nullptr,               \
         (float *)nullptr, (int *)nullptr, 0, (float)Bk, ad, (const int *)nullptr, (const int *)nullptr, 0, (const int *)nullptr
             if (e0 != nullptr || e1 != nullptr)
-                hipExtLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 0>), dim3((unsigned)nA), block, 0, stream, e0, e1,
+                hipExtLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, MODE, 1, false, 0>), dim3((unsigned)nA), block, 0, stream, e0, e1,
                                       0, WR_PLAIN_ARGS);
             else
-                hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, 0, 1, false, 0>), dim3((unsigned)nA), block, 0, stream,
+                hipLaunchKernelGGL((bprmf_user_phase<T, NV, FULL, MODE, 1, false, 0>), dim3((unsigned)nA), block, 0, stream,
                                    WR_PLAIN_ARGS);
 #undef WR_PLAIN_ARGS
             WR_LAUNCH_CHECK("bprmf_user_phase (chain, first)");
@@ -1713,6 +1734,61 @@ int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab
                                               events, n_cu)
     WR_DISPATCH_D(D, WR_CALL_CHAIN);
 #undef WR_CALL_CHAIN
+    return WR_OK;
+}
+
+
+int32_t wr_bprmf_run_adam_folded_chain(float *user_tab, int64_t n_users, float *item_tab, int64_t n_items, int32_t D,
+                                       float *m_u, float *v_u, float *m_i, float *v_i, int32_t *last_u, int32_t *last_i,
+                                       const int32_t *tu, const int32_t *tp, const int32_t *tn, const int32_t *oc_item,
+                                       const int32_t *oc_src, int64_t n_triplets, int64_t batch_size, int64_t first_batch,
+                                       int64_t n_batches, int64_t adam_step0, float lr, const float *consts, int64_t n_consts,
+                                       float l2, float beta1, float beta2, float eps, float *loss_out, const int32_t *tdef,
+                                       const int32_t *def_q, const int32_t *def_count_host, int64_t def_cap, int64_t def_limit,
+                                       void *workspace, int64_t workspace_bytes, int32_t *sync, int64_t sync_words,
+                                       void *stream_) {
+    int32_t rc;
+    if ((rc = check_table(user_tab, n_users, D, "user_tab")) != WR_OK) return rc;
+    if ((rc = check_table(item_tab, n_items, D, "item_tab")) != WR_OK) return rc;
+    if ((rc = check_table(m_u, n_users, D, "m_u")) != WR_OK) return rc;
+    if ((rc = check_table(v_u, n_users, D, "v_u")) != WR_OK) return rc;
+    if ((rc = check_table(m_i, n_items, D, "m_i")) != WR_OK) return rc;
+    if ((rc = check_table(v_i, n_items, D, "v_i")) != WR_OK) return rc;
+    if ((rc = check_plan_args(tu, tp, tn, oc_item, oc_src, batch_size)) != WR_OK) return rc;
+    WR_REQUIRE(last_u && last_i && consts && tdef && def_q && def_count_host && sync, WR_E_NULL,
+               "last_u / last_i / consts / chain marks / sync words must not be NULL");
+    WR_REQUIRE(chain_shape_ok(user_tab, item_tab, D) && chain_shape_ok(m_u, m_i, D) && chain_shape_ok(v_u, v_i, D), WR_E_ALIGN,
+               "wr_bprmf_run_adam_folded_chain: rows must be whole 128-B lines (D %% 32 == 0, tables 128-B aligned); D = %d", (int)D);
+    WR_REQUIRE(n_triplets > 0 && first_batch >= 0 && n_batches >= 0, WR_E_SHAPE, "bad batch range");
+    const int64_t total_batches = (n_triplets + batch_size - 1) / batch_size;
+    WR_REQUIRE(first_batch + n_batches <= total_batches, WR_E_SHAPE, "batches [%lld,%lld) exceed the plan's %lld",
+               (long long)first_batch, (long long)(first_batch + n_batches), (long long)total_batches);
+    WR_REQUIRE(adam_step0 >= 1 && adam_step0 + n_batches <= n_consts && adam_step0 + n_batches < INT32_MAX, WR_E_RANGE,
+               "adam steps [%lld,%lld) outside the consts table (%lld entries)", (long long)adam_step0,
+               (long long)(adam_step0 + n_batches), (long long)n_consts);
+    WR_REQUIRE(def_cap > 0 && def_limit >= 0, WR_E_RANGE, "bad deferred-run capacity");
+    WR_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 2 * step_ws_bytes(batch_size, D), WR_E_WORKSPACE,
+               "wr_bprmf_run_adam_folded_chain: workspace %lld B < %lld B", (long long)workspace_bytes,
+               (long long)(2 * step_ws_bytes(batch_size, D)));
+    WR_REQUIRE(aligned16(sync) && sync_words >= n_batches * kChainStepWords + 4, WR_E_WORKSPACE,
+               "wr_bprmf_run_adam_folded_chain: %lld sync words < %lld", (long long)sync_words,
+               (long long)(n_batches * kChainStepWords + 4));
+    if (n_batches == 0) return WR_OK;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        WR_HIP(hipGetDevice(&dev));
+        WR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const AdamArgs base{m_u, v_u, m_i, v_i, last_u, last_i, 0.f, 0.f, beta1, beta2, eps, l2, 0, consts};
+#define WR_CALL_ACHAIN(T_, NV_, FULL_)                                                                                       \
+    return launch_chain_steps<T_, NV_, FULL_, 4>(user_tab, item_tab, D, tu, tp, tn, oc_item, oc_src, n_triplets, batch_size,  \
+                                                 first_batch, n_batches, lr, loss_out, tdef, def_q, def_count_host, def_cap,   \
+                                                 def_limit, workspace, reinterpret_cast<uint32_t *>(sync), sync_words, stream, \
+                                                 nullptr, n_cu, l2, base, adam_step0)
+    WR_DISPATCH_D(D, WR_CALL_ACHAIN);
+#undef WR_CALL_ACHAIN
     return WR_OK;
 }
 

@@ -141,6 +141,10 @@ __device__ __forceinline__ void store16_wt(float4 *p, const float4 &v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
 }
 
+__device__ __forceinline__ void store_i32_wt(int *p, int v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 template <int T, int NV, bool FULL>
 __device__ __forceinline__ void store_row_wt(float *__restrict__ base, int64_t row, int D, int lane, const Row<NV> &r) {
     float4 *p = reinterpret_cast<float4 *>(base + row * (int64_t)D);

@@ -1265,7 +1265,8 @@ class PipelinedSgd:
         u_all, p_all, n_all = (_join_views([s[j] for s in live]) for j in (1, 2, 3))
         n_items = max([s[0].shape[0] for s in live] or [1])
         main = torch.cuda.current_stream(U.device)
-        use_chain = self.chain and runner is None and B >= self.CHAIN_MIN_BATCH and first >= 2 and \
+        use_chain = self.chain and (runner is None or getattr(runner, "wants_chain_marks", False)) and \
+            B >= self.CHAIN_MIN_BATCH and first >= 2 and \
             min([s[0].shape[0] for s in live] or [0]) >= self.CHAIN_MIN_ITEMS_PER_TRIPLET * B and \
             all(sg["tabs"].chain_supported() for sg in segs if sg["tabs"] is not None)
         min_rows = min([U.shape[0]] + [s[0].shape[0] for s in live])
@@ -1503,6 +1504,7 @@ class LazyOptimizerState:
         (scripts/exp/adam_epoch.py), us/step at max_lag = unbounded / 1024 / 512 / 256 / 128 / 64 / 32 / 16: B = 2,048: 206 /
         151 / 96 / 76 / 66 / 61.6 / 62.4 / 78 (the window's row traffic grows as the lag shrinks); B = 8,192: - / 133 / 109 /
         - / 80 / 72.5 / 73.5 / 89; B = 16,384 (a row misses ~61 steps): 88 either way."""
+        self.chain, self.chain_calls = True, 0     # folded Adam steps as one launch per step where the plan carries the marks
         if name not in ("SGD", "Adam"):
             raise ValueError(name)
         self.tabs, self.name, self.lr, self.l2, self.betas, self.eps = tabs, name, float(lr), float(l2), betas, float(eps)
@@ -1607,7 +1609,17 @@ class LazyOptimizerState:
                     first, count, t0, self.lr, _p(self.consts), self.n_consts, self.l2, self.betas[0], self.betas[1], self.eps,
                     _p(losses), hp)
             lag = self._lag(plan)
-            if self._folds(plan):
+            o = getattr(plan, "overlap", None)
+            if self._folds(plan) and self.chain and o is not None and hot is None and count >= 2 and tabs.chain_supported():
+                # one launch per step: the item phase of step k-1 inside the launch of step k's user phase
+                ws2 = tabs.overlap_workspace(plan.batch_size)
+                sync = tabs._chain_sync(count)
+                abi.check(L.wr_bprmf_run_adam_folded_chain(*head[:-1], _p(o["tdef"]), _p(o["def_q"]),
+                                                           o["def_count_host"].data_ptr(), o["cap"], o["cap"], _p(ws2),
+                                                           ws2.numel(), _p(sync), sync.numel(), _stream()),
+                          "wr_bprmf_run_adam_folded_chain")
+                self.chain_calls += 1
+            elif self._folds(plan):
                 abi.check(L.wr_bprmf_run_adam_folded(*head, _p(ws), ws.numel(), _stream()), "wr_bprmf_run_adam_folded")
             elif lag > 0:
                 abi.check(L.wr_bprmf_run_adam_lazy_bounded(*head, lag, ctypes.addressof(self._sweep_pos), _p(ws), ws.numel(),
