@@ -5,7 +5,9 @@
     (uniform, mildly skewed items, a hot row, hashed table sizes beyond 2^21 rows);
   * the group plan's arrays against the NumPy restatement (oracle.group_plan);
   * scatter-add through the row plan against the sorted path (bitwise), random sizes, padding, clumped and hot rows,
-    one call and several segments planned ahead."""
+    one call and several segments planned ahead;
+  * the folded Adam step as one launch per step against the two-launch form (tables, moments, stamps bitwise), random
+    shapes, weight decay, cuts into calls."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,7 +19,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end, t_note = time.time() + budget, time.time()
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-n_cases = n_group = n_fallback = n_scatter = n_slow = 0
+n_cases = n_group = n_fallback = n_scatter = n_slow = n_adam_chain = 0
 
 
 def sorted_reference(table, idx, src, alpha, pad):
@@ -117,10 +119,37 @@ while time.time() < t_end:
         sorted_reference(ref2, idx_d[sl].contiguous(), src[sl].contiguous(), -1.0, 0)
     assert torch.equal(tab2, ref2), ("scatter segments", n_rows, n, Ds, mode, S)
     n_scatter += 1
+    # ---- folded Adam, one launch per step against two (tables, moments, stamps bitwise)
+    Da = int(rng.choice([32, 64, 128]))
+    Ba = int(rng.choice([8192, 8192, 16384]))
+    nUa, nIa = int(rng.randint(2 * Ba, 30 * Ba)), int(rng.randint(2 * Ba, 30 * Ba))
+    nba = int(rng.randint(3, 9))
+    Na = nba * Ba - int(rng.randint(0, Ba // 2))
+    l2a = float(rng.choice([0.0, 0.0, 1e-3]))
+    ua = T(rng.randint(0, nUa, Na).astype(np.int32)); pa = T(rng.randint(0, nIa, Na).astype(np.int32))
+    na = T(rng.randint(1, nIa, Na).astype(np.int32))
+    arena = hip_ops.PlanArena(dev, Na, Ba, overlap_items=nIa)
+    plan_a = hip_ops.BatchPlan(ua, pa, na, Ba, nUa, nIa, arena=arena, overlap=True)
+    if plan_a.overlap is not None and plan_a.hot is None:
+        U0 = torch.randn(nUa, Da, device=dev) * 0.1
+        I0 = torch.randn(nIa, Da, device=dev) * 0.1
+        cuts = sorted(set([0, nba] + [int(x) for x in rng.randint(1, nba, int(rng.randint(0, 3)))]))
+        outs = []
+        for chain in (False, True):
+            st = hip_ops.LazyOptimizerState(hip_ops.BprmfTables(U0.clone(), I0.clone()), "Adam", 1e-2, l2a, fold=True)
+            st.chain = chain
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                st.run(plan_a, a, b - a)
+            torch.cuda.synchronize()
+            st.tabs.check_chain()
+            outs.append((st.tabs.U, st.tabs.I, st.m_u, st.v_u, st.m_i, st.v_i, st.last_u, st.last_i, st.chain_calls))
+        for x, y in zip(outs[0][:-1], outs[1][:-1]):
+            assert torch.equal(x, y), ("adam chain", Da, Ba, nUa, nIa, nba, l2a, cuts)
+        n_adam_chain += int(outs[1][-1] > 0)
     n_cases += 1
     if time.time() - t_note > 30:
         print("%d cases (%d on group plans, %d fell back), %d scatter cases (%d with a brute-force range)" %
               (n_cases, n_group, n_fallback, n_scatter, n_slow), flush=True)
         t_note = time.time()
-print("done: %d cases (%d on group plans, %d fell back to sorted plans), %d scatter cases (%d with a brute-force range)" %
-      (n_cases, n_group, n_fallback, n_scatter, n_slow))
+print("done: %d cases (%d on group plans, %d fell back to sorted plans), %d scatter cases (%d with a brute-force range), "
+      "%d Adam cases with chained launches" % (n_cases, n_group, n_fallback, n_scatter, n_slow, n_adam_chain))
