@@ -2,7 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from whisprrec_amd import hip_ops
+from whisprrec_amd import abi, hip_ops
+if os.environ.get("WR_LIB"):
+    abi.LIB_PATH = os.path.abspath(os.environ["WR_LIB"])
 dev = torch.device("cuda:0")
 nU = nI = 1_000_000
 D, B, NB = 64, 65536, 64
