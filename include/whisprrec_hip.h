@@ -327,7 +327,7 @@ int32_t wr_bprmf_run_sgd_chain(float *user_tab, int64_t n_users, float *item_tab
  *       wr_group_plan_words(...) int32 words (0: shape not supported — batch_size > 131,072), 16-byte aligned, caller-owned.
  *       plan[0] != 0: an id was out of range (nn.Embedding would raise IndexError); plan[1] != 0: a list overflowed
  *       (tables small against the batch, or popularity-skewed ids) — the plan is NOT usable, build a sorted plan instead;
- *       plan[2] != 0: some row has more than 32 occurrences in a batch (usable, but slow: prefer the sorted plan's hot-row
+ *       plan[2] != 0: some row has more than 64 occurrences in a batch (usable, but slow: prefer the sorted plan's hot-row
  *       path).  Tables beyond 2^21 rows are hashed into 2^21 bits: a collision makes a row look shared, never the reverse.
  *   wr_bprmf_run_sgd_group  the steps of batches [first_batch, first_batch + n_batches) of that plan; `u, p, n` are the
  *       arrays the plan was built from.  The item rows with several occurrences in batch k are rewritten by workgroups

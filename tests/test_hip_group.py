@@ -219,7 +219,7 @@ def test_pipeline_falls_back_to_sorted_plans_on_skewed_ids(ops):
     re-planned, later chunks are planned sorted from the start — and the result is the oracle's either way."""
     dev = torch.device("cuda:0")
     nU, nI, D, B, nb, lr = 120_000, 150_000, 64, 8192, 9, 0.05
-    for hot in (600, 60):                                             # 600 occurrences per batch: overflow; 60: long run
+    for hot in (600, 100):                                            # 600 occurrences per batch: overflow; 100: long run
         u, p, n = _epoch(50 + hot, nU, nI, nb * B)
         for k in range(nb):
             p[k * B:k * B + hot] = 4242

@@ -13,7 +13,8 @@
 //   lists   the shared occurrences only (~6 % of the triplets by user, ~12 % of the occurrences by item at 1M x 1M,
 //           B = 65,536), sorted by (row, position): (user, t << 1) and (item, t << 1 | negative), in R segments per batch
 //           and side (a segment = a range of hashed rows), with their lengths.
-// How: a workgroup owns (batch, side, range of 2^18 hashed rows) and keeps two bitmaps of that range in LDS: a first scan
+// How: a workgroup owns (batch, side, range of 2^18 hashed rows: the rows whose hashed id has the range's low bits, so that
+// the popular — low — ids of a popularity-sorted id space are dealt round the ranges) and keeps two bitmaps of that range in LDS: a first scan
 // of the batch's ids sets "seen" bits and, where the bit was set already, "several" bits; a second scan flags the
 // triplets whose row has its "several" bit set, appends them to a list in LDS (bitonic sort by (row, position)) and — item
 // side — flags the NEXT batch's triplets against the same bitmap (DF).  No global sort, no scatter: the ids are read
@@ -44,7 +45,7 @@ constexpr int kGpBins = 4096;                         // counting-sort bins of a
 constexpr int kGpMaxBin = 256;                        // longest bin ordered by ranking (else: overflow)
 constexpr int kGpMaxRanges = 8;                       // hashed space <= 2^21 rows (gs_tile_of loads 8 lengths)
 constexpr int64_t kGpMaxBatch = 1 << 17;              // three flag arrays of B / 32 words in LDS
-constexpr int kGpLongRun = 32;                        // a bin with more entries than this sets meta[2] (a hot row: the caller goes
+constexpr int kGpLongRun = 64;                        // a ROW with more occurrences than this sets meta[2] (a hot row: the caller goes
                                                       // back to the sorted plan, whose hot-row path is made for it)
 constexpr int kGpMetaWords = 16;
 #ifndef WR_GP_DBG
@@ -163,7 +164,10 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
     const int Bb = (int)((base + B <= n_total) ? B : (n_total - base));
     const unsigned n_rows = (unsigned)(item ? n_items : n_users);
     const unsigned mask = item ? L.mask_i : L.mask_u;
-    constexpr unsigned rmask = (1u << kGpRangeBits) - 1u;
+    // A hashed row h belongs to range h & (R - 1) and has bit h >> rb of that range's bitmaps (rb = log2 R): consecutive ids
+    // — the popular items of an id space sorted by popularity — are dealt round the ranges, and round the bins of the ordering
+    // below (bin = low 12 bits of the bit index), instead of filling one list and one bin.
+    const unsigned rb = (item ? L.hbits_i : L.hbits_u) - kGpRangeBits, rsel = (1u << rb) - 1u;
     for (int i = threadIdx.x; i < kGpWords; i += kGpThreads) {
         seen[i] = 0u;
         multi[i] = 0u;
@@ -178,8 +182,8 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
             return;
         }
         const unsigned h = (unsigned)row & mask;
-        if ((h >> kGpRangeBits) != r) return;
-        const unsigned bit = h & rmask, m = 1u << (bit & 31u);
+        if ((h & rsel) != r) return;
+        const unsigned bit = h >> rb, m = 1u << (bit & 31u);
         const unsigned old = atomicOr(&seen[bit >> 5], m);
         if (old & m) atomicOr(&multi[bit >> 5], m);
     };
@@ -200,8 +204,8 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
     // 2.7: launch + zeroing 0.6, first scan 0.55, second scan 1.25 (0.65 of it visits that find nothing), ordering 0.3.)
     auto several = [&](int row) -> bool {
         const unsigned h = (unsigned)row & mask;
-        if ((h >> kGpRangeBits) != r) return false;
-        const unsigned bit = h & rmask;
+        if ((h & rsel) != r) return false;
+        const unsigned bit = h >> rb;
         return (multi[bit >> 5] >> (bit & 31u)) & 1u;
     };
     auto append = [&](int row, unsigned src) {
@@ -258,14 +262,14 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
         if (threadIdx.x == 0) L.meta[1] = 1;
         m = cap;
     }
-    // Order the m keys by (hashed row, row, source) without a comparison sort: a counting sort over bins of 64 hashed rows
+    // Order the m keys by (bin, row, source) without a comparison sort: a counting sort over 4,096 bins of the range's rows
     // places the keys' INDICES (16 bits each) grouped by bin, and a key's final position is its bin's start + the number of
     // smaller keys in its bin (keys are unique; a bin holds ~1 key).  Equal rows end up adjacent, in source order: what the
     // tiles need.  (A bitonic sort of the same keys took 2.1 of the 4.7 us per batch of the first version.)
     int *cnt = reinterpret_cast<int *>(multi);                                      // the "several" bitmap is done with
     unsigned short *out16 = reinterpret_cast<unsigned short *>(multi + kGpBins);
     int *wave_tot = reinterpret_cast<int *>(f0);                                    // the flag arrays have been written out
-    auto bin_of = [&](unsigned long long k) -> int { return (int)((((unsigned)(k >> 32) & mask) & rmask) >> 6); };
+    auto bin_of = [&](unsigned long long k) -> int { return (int)(((((unsigned)(k >> 32)) & mask) >> rb) & (kGpBins - 1)); };
     int *lrow = (item ? L.il_row : L.ul_row) + ((int64_t)b * R + r) * cap, *lsrc = (item ? L.il_src : L.ul_src) + ((int64_t)b * R + r) * cap;
     __syncthreads();      // every thread has read n_list and written its flag words out
     for (int i = threadIdx.x; i < kGpBins; i += kGpThreads) cnt[i] = 0;
@@ -303,13 +307,17 @@ __global__ __launch_bounds__(kGpThreads) void group_plan_kernel(const int *__res
             const unsigned long long k = keys[j];
             const int bin = bin_of(k);
             const int lo = bin ? cnt[bin - 1] : 0, hi = cnt[bin];
-            if (hi - lo > kGpLongRun) L.meta[2] = 1;
             if (hi - lo > kGpMaxBin) {
                 L.meta[1] = 1;
                 continue;
             }
-            int pos = lo;
-            for (int jj = lo; jj < hi; ++jj) pos += keys[out16[jj]] < k ? 1 : 0;
+            int pos = lo, same = 0;
+            for (int jj = lo; jj < hi; ++jj) {
+                const unsigned long long o = keys[out16[jj]];
+                pos += o < k ? 1 : 0;
+                same += (unsigned)(o >> 32) == (unsigned)(k >> 32) ? 1 : 0;
+            }
+            if (same > kGpLongRun) L.meta[2] = 1;
             lrow[pos] = (int)(k >> 32);
             lsrc[pos] = (int)(unsigned)k;
         }

@@ -611,7 +611,7 @@ class GroupPlan:
     where they are (``u, p, n`` int32, batch order — kept by the plan, the step kernels read them); per batch the plan holds
     four flag bits per triplet and the shared occurrences only, as sorted lists.  One launch per build, ~0.1 B of plan per
     triplet.  ``finish()`` publishes ``bad_index`` / ``overflow`` (the plan is unusable: fall back to BatchPlan) /
-    ``long_run`` (usable, but a row has more than 32 occurrences in a batch)."""
+    ``long_run`` (usable, but a row has more than 64 occurrences in a batch)."""
 
     META = 16
 
