@@ -22,7 +22,8 @@ def wrapped(self, *a, **k):
     return r
 hip_ops.BprmfTables.run_sgd_group = wrapped
 import gc
-for rep in range(5):
+for rep in range(8):
+    spin = rep % 2 == 1
     pipe = hip_ops.PipelinedSgd(chunk=20, min_triplets=1)
     lw = torch.empty(W, device=dev); l = torch.empty(K, device=dev)
     gc.disable()
@@ -32,8 +33,13 @@ for rep in range(5):
     t0 = T()
     pipe.run_steps(h, K, 0.05, l)
     t1 = T()
+    if spin:                                   # poll an event instead of sleeping in hipDeviceSynchronize
+        ev = torch.cuda.Event(); ev.record()
+        while not ev.query():
+            pass
     torch.cuda.synchronize()
     t2 = T()
     gc.enable()
+    print("spin" if spin else "sync", end=": ")
     print("native call entered at %.0f us, returned at %.0f; run_steps returned at %.0f; device done at %.0f (%.1f us/step)" %
           ((marks["enter"] - t0) * 1e6, (marks["leave"] - t0) * 1e6, (t1 - t0) * 1e6, (t2 - t0) * 1e6, (t2 - t0) / K * 1e6), flush=True)
